@@ -1,0 +1,177 @@
+/* sgmcmc_oracle.c -- CPU restatement of the pysgmcmc SG-MCMC update path.
+ *
+ * TEST INFRASTRUCTURE ONLY. This file is the *checker* for the HIP kernels in
+ * pysgmcmc_amd/csrc/. Only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py may load it. The product path
+ * (pysgmcmc_amd.*) never imports, links or calls anything under oracle/.
+ *
+ * What it restates (reference file:line, relative to the pysgmcmc repo):
+ *   SGHMC step ............ pysgmcmc/samplers/sghmc.py:111-117,126-155,165-251
+ *   SGLD step ............. pysgmcmc/samplers/sgld.py:106-108,117-141,149-211
+ *   relativistic SGHMC .... pysgmcmc/samplers/relativistic_sghmc.py:100-140
+ *   burn-in switch ........ pysgmcmc/samplers/base_classes.py:393-456
+ *   safe_divide/safe_sqrt . pysgmcmc/tensor_utils.py:269,319-323
+ *
+ * PARITY PINNING STATUS
+ *   The reference is pure Python on TensorFlow 1.x; TensorFlow is absent from
+ *   this image and cannot be installed, so the reference cannot be executed
+ *   here, and its own sampler tests hold no golden trajectories (they assert
+ *   run-to-run equality under one seed only,
+ *   pysgmcmc/tests/samplers/sampler_testing.py:55-59).
+ *   => Sampler-trajectory parity is UNPINNED against reference outputs.
+ *   What IS pinned (tests/test_oracle_pins.py):
+ *     - safe_divide / safe_sqrt doctest known answers (tensor_utils.py:241-265,
+ *       304-316),
+ *     - BNN prior golden constants from the reference's .npy fixtures
+ *       (tests/bayesian_neural_network/test_priors.py:20-81),
+ *     - Philox4x32-10 against the published Random123 known-answer vectors,
+ *     - this fused C restatement against an independent op-by-op numpy
+ *       restatement (oracle/sgmcmc_oracle.py) written directly from the TF op
+ *       graph, bit for bit.
+ *
+ * Noise. TF's `random_normal` stream cannot be reproduced (TF absent); the
+ * arithmetic is therefore checked with injected xi. When xi == NULL the
+ * oracle draws xi from the SAME counter-based stream the HIP kernels use:
+ * Philox4x32-10 (Salmon et al., SC'11; third-party algorithm, restated from
+ * the paper / Random123 v1.14 `philox.h`, constants below), counter =
+ * (step_lo, step_hi, quad_lo, quad_hi), key = (seed_lo, seed_hi), quad = i/4.
+ * That is rocRAND's philox4x32_10 layout with subsequence = quad and
+ * offset = 4*step. Uniforms are bit-exact integers on both sides; the
+ * Box-Muller transcendental part is evaluated here in double precision libm
+ * and compared with the GPU's fast intrinsics under a stated tolerance.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ Philox */
+
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+
+void oracle_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr_in[0], c1 = ctr_in[1], c2 = ctr_in[2], c3 = ctr_in[3];
+    uint32_t k0 = key_in[0], k1 = key_in[1];
+    int round;
+    for (round = 0; round < 10; ++round) {
+        uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += PHILOX_W0; k1 += PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static inline void philox_quad(uint64_t seed, uint64_t step, uint64_t quad, uint32_t x[4])
+{
+    uint32_t ctr[4] = { (uint32_t)step, (uint32_t)(step >> 32),
+                        (uint32_t)quad, (uint32_t)(quad >> 32) };
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    oracle_philox4x32_10(ctr, key, x);
+}
+
+void oracle_philox_uniform_bits(uint64_t seed, uint64_t step, size_t n, uint32_t *out)
+{
+    size_t i;
+    for (i = 0; i < n; ++i) {
+        uint32_t x[4];
+        philox_quad(seed, step, (uint64_t)(i >> 2), x);
+        out[i] = x[i & 3];
+    }
+}
+
+static const double TWO_PI = 6.283185307179586476925286766559;
+
+/* Element i of the N(0,1) stream: words (x0,x1) -> elements 4q+0 (sin), 4q+1
+ * (cos); words (x2,x3) -> 4q+2 (sin), 4q+3 (cos).
+ * f32: u = fmaf((float)x, 2^-32, 2^-33) in (0,1] exactly as the kernel forms it
+ *      (uint->float conversion is round-to-nearest-even on both sides).        */
+static inline float philox_normal_at_f32(uint64_t seed, uint64_t step, uint64_t i)
+{
+    uint32_t x[4];
+    philox_quad(seed, step, i >> 2, x);
+    unsigned pair = (unsigned)((i >> 1) & 1);
+    float u = fmaf((float)x[2 * pair], 0x1p-32f, 0x1p-33f);
+    float rev = fmaf((float)x[2 * pair + 1], 0x1p-32f, 0x1p-33f);
+    double s = sqrt(-2.0 * log((double)u));
+    double ang = TWO_PI * (double)rev;
+    double z = (i & 1) ? s * cos(ang) : s * sin(ang);
+    return (float)z;
+}
+
+/* f64: u = (x + 0.5) * 2^-32 (exact in double), same word assignment.          */
+static inline double philox_normal_at_f64(uint64_t seed, uint64_t step, uint64_t i)
+{
+    uint32_t x[4];
+    philox_quad(seed, step, i >> 2, x);
+    unsigned pair = (unsigned)((i >> 1) & 1);
+    double u = ((double)x[2 * pair] + 0.5) * 0x1p-32;
+    double rev = ((double)x[2 * pair + 1] + 0.5) * 0x1p-32;
+    double s = sqrt(-2.0 * log(u));
+    double ang = TWO_PI * rev;
+    return (i & 1) ? s * cos(ang) : s * sin(ang);
+}
+
+/* ------------------------------------------------------------ typed bodies */
+
+#define REAL float
+#define SFX(x) x##_f32
+#define R(x) x##f
+#define RSQRT sqrtf
+#define RPOW powf
+#include "sgmcmc_oracle_body.inc"
+#undef REAL
+#undef SFX
+#undef R
+#undef RSQRT
+#undef RPOW
+
+#define REAL double
+#define SFX(x) x##_f64
+#define R(x) x
+#define RSQRT sqrt
+#define RPOW pow
+#include "sgmcmc_oracle_body.inc"
+#undef REAL
+#undef SFX
+#undef R
+#undef RSQRT
+#undef RPOW
+
+/* ----------------------------------------------------------------- helpers */
+
+void oracle_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}
+
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* exported scalar helpers so tests can pin the doctest known answers */
+float  oracle_safe_divide_f32(float x, float y)   { return sdiv_f32(x, y); }
+double oracle_safe_divide_f64(double x, double y) { return sdiv_f64(x, y); }
+float  oracle_safe_sqrt_f32(float x)              { return ssqrt_f32(x); }
+double oracle_safe_sqrt_f64(double x)             { return ssqrt_f64(x); }

@@ -1,0 +1,489 @@
+"""CPU oracle for the SG-MCMC update path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module. The product package ``pysgmcmc_amd`` never
+does (tests/test_boundary.py greps for it).
+
+Two independent restatements of the reference arithmetic live under oracle/:
+
+* ``sgmcmc_oracle.c`` -- fused, one pass per step (what a sane CPU port looks
+  like; also the ``"port"`` CPU baseline of bench.py). Loaded here via ctypes.
+* this file -- an **op-by-op numpy mirror of the reference's TensorFlow graph**:
+  one numpy call per TF op, every temporary materialised, in the order the
+  ``tf.control_dependencies`` chain forces. It is the closest executable proxy
+  of the TF-CPU sampler available in an image without TensorFlow ("baseline A"
+  of BASELINE.md section 3) and the cross-check that pins the fused C code.
+
+PARITY PINNING STATUS: sampler trajectories are *unpinned* against reference
+outputs (TensorFlow cannot be run here and the reference tests hold no golden
+trajectories -- pysgmcmc/tests/samplers/sampler_testing.py:55-59). Pinned:
+safe_divide/safe_sqrt doctests, the BNN prior golden constants, Philox KATs,
+C-vs-numpy bit equality. See sgmcmc_oracle.c header and DESIGN.md.
+
+Reference citations are relative to the pysgmcmc repository root.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsgmcmc_oracle.so")
+
+
+# --------------------------------------------------------------------------
+# C oracle loader
+# --------------------------------------------------------------------------
+
+def build_c(force=False):
+    """Compile oracle/libsgmcmc_oracle.so with gcc (no GPU needed)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < max(
+            os.path.getmtime(os.path.join(_HERE, f))
+            for f in ("sgmcmc_oracle.c", "sgmcmc_oracle_body.inc"))
+    ):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libsgmcmc_oracle.so"])
+    return _LIB_PATH
+
+
+_c_lib = None
+
+
+def load_c():
+    """ctypes handle to the fused C oracle with argtypes set."""
+    global _c_lib
+    if _c_lib is not None:
+        return _c_lib
+    lib = ctypes.CDLL(build_c())
+    u64, sz, ci = ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int
+    vp = ctypes.c_void_p
+    for sfx, real in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
+        f = getattr(lib, "oracle_sghmc_step_" + sfx)
+        f.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, real, real, real, ci, vp, u64, u64]
+        f.restype = ci
+        f = getattr(lib, "oracle_sgld_step_" + sfx)
+        f.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, real, real, real, ci, vp, u64, u64]
+        f.restype = ci
+        f = getattr(lib, "oracle_rsghmc_step_" + sfx)
+        f.argtypes = [vp, vp, vp, sz, real, real, real, real, real, vp, u64, u64]
+        f.restype = ci
+        f = getattr(lib, "oracle_moments_update_" + sfx)
+        f.argtypes = [vp, vp, vp, sz, u64]
+        f.restype = ci
+        f = getattr(lib, "oracle_philox_normal_" + sfx)
+        f.argtypes = [u64, u64, sz, vp]
+        f.restype = None
+        f = getattr(lib, "oracle_sghmc_consts_" + sfx)
+        f.argtypes = [real, real, real, vp]
+        f.restype = None
+        f = getattr(lib, "oracle_safe_divide_" + sfx)
+        f.argtypes = [real, real]
+        f.restype = real
+        f = getattr(lib, "oracle_safe_sqrt_" + sfx)
+        f.argtypes = [real]
+        f.restype = real
+    lib.oracle_philox4x32_10.argtypes = [vp, vp, vp]
+    lib.oracle_philox4x32_10.restype = None
+    lib.oracle_philox_uniform_bits.argtypes = [u64, u64, sz, vp]
+    lib.oracle_philox_uniform_bits.restype = None
+    lib.oracle_set_num_threads.argtypes = [ci]
+    lib.oracle_max_threads.restype = ci
+    _c_lib = lib
+    return lib
+
+
+def _sfx(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return "f32"
+    if dtype == np.float64:
+        return "f64"
+    raise TypeError(dtype)
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+class CState(object):
+    """Flat per-chain state for the C oracle (same arrays the HIP kernels use)."""
+
+    def __init__(self, theta0, dtype=np.float32):
+        dt = np.dtype(dtype)
+        self.dtype = dt
+        self.theta = np.ascontiguousarray(np.asarray(theta0, dtype=dt).ravel()).copy()
+        n = self.theta.size
+        self.n = n
+        # pysgmcmc/samplers/sghmc.py:126-155 initial values
+        self.V = np.zeros(n, dt)
+        self.tau = np.ones(n, dt)
+        self.g = np.ones(n, dt)
+        self.v_hat = np.ones(n, dt)
+        self.minv = np.ones(n, dt)
+        self.r = np.full(n, 0.5, dt)
+        self.p = np.zeros(n, dt)     # relativistic momentum
+
+
+def c_sghmc_step(st, grad, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step=0):
+    lib = load_c()
+    grad = np.ascontiguousarray(grad, dtype=st.dtype).ravel()
+    if xi is not None:
+        xi = np.ascontiguousarray(xi, dtype=st.dtype).ravel()
+    f = getattr(lib, "oracle_sghmc_step_" + _sfx(st.dtype))
+    rc = f(_p(st.theta), _p(st.V), _p(grad), _p(st.tau), _p(st.g), _p(st.v_hat),
+           _p(st.minv), _p(st.r), st.n, eps, scale_grad, mdecay, int(adapt),
+           _p(xi), seed, step)
+    assert rc == 0
+
+
+def c_sgld_step(st, grad, eps, A, scale_grad, adapt, xi=None, seed=0, step=0):
+    lib = load_c()
+    grad = np.ascontiguousarray(grad, dtype=st.dtype).ravel()
+    if xi is not None:
+        xi = np.ascontiguousarray(xi, dtype=st.dtype).ravel()
+    f = getattr(lib, "oracle_sgld_step_" + _sfx(st.dtype))
+    rc = f(_p(st.theta), _p(grad), _p(st.tau), _p(st.g), _p(st.v_hat),
+           _p(st.minv), _p(st.r), st.n, eps, A, scale_grad, int(adapt),
+           _p(xi), seed, step)
+    assert rc == 0
+
+
+def c_rsghmc_step(st, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, step=0):
+    lib = load_c()
+    grad_cost = np.ascontiguousarray(grad_cost, dtype=st.dtype).ravel()
+    if xi is not None:
+        xi = np.ascontiguousarray(xi, dtype=st.dtype).ravel()
+    f = getattr(lib, "oracle_rsghmc_step_" + _sfx(st.dtype))
+    rc = f(_p(st.theta), _p(st.p), _p(grad_cost), st.n, eps, mass, c, D, b_hat,
+           _p(xi), seed, step)
+    assert rc == 0
+
+
+def c_moments_update(theta, mean, m2, count):
+    lib = load_c()
+    f = getattr(lib, "oracle_moments_update_" + _sfx(theta.dtype))
+    rc = f(_p(theta), _p(mean), _p(m2), theta.size, count)
+    assert rc == 0
+
+
+def c_philox_normal(seed, step, n, dtype=np.float32):
+    lib = load_c()
+    out = np.empty(n, dtype)
+    getattr(lib, "oracle_philox_normal_" + _sfx(dtype))(seed, step, n, _p(out))
+    return out
+
+
+def c_philox_bits(seed, step, n):
+    lib = load_c()
+    out = np.empty(n, np.uint32)
+    lib.oracle_philox_uniform_bits(seed, step, n, _p(out))
+    return out
+
+
+def c_philox4x32_10(ctr, key):
+    lib = load_c()
+    c = np.asarray(ctr, np.uint32).copy()
+    k = np.asarray(key, np.uint32).copy()
+    out = np.empty(4, np.uint32)
+    lib.oracle_philox4x32_10(_p(c), _p(k), _p(out))
+    return out
+
+
+# --------------------------------------------------------------------------
+# Pure-Python Philox4x32-10 (third independent statement; small cases only)
+# --------------------------------------------------------------------------
+
+def py_philox4x32_10(ctr, key):
+    """Philox4x32-10 as published (Salmon, Moraes, Dror, Shaw, SC'11)."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c = [int(x) for x in ctr]
+    k = [int(x) for x in key]
+    for _ in range(10):
+        p0 = M0 * c[0]
+        p1 = M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k[0]) & 0xFFFFFFFF, p1 & 0xFFFFFFFF,
+             ((p0 >> 32) ^ c[3] ^ k[1]) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k = [(k[0] + W0) & 0xFFFFFFFF, (k[1] + W1) & 0xFFFFFFFF]
+    return c
+
+
+# --------------------------------------------------------------------------
+# Op-by-op numpy mirror of the reference TF graph
+# --------------------------------------------------------------------------
+
+def safe_divide(x, y, small_constant=1e-16):
+    """pysgmcmc/tensor_utils.py:269 (dtype follows the array operands)."""
+    dt = np.result_type(x, y) if isinstance(y, np.ndarray) or isinstance(x, np.ndarray) else np.float64
+    dt = np.dtype(dt).type
+    two, sc = dt(2.0), dt(small_constant)
+    t0 = two * np.sign(y)          # 2. * tf.sign(y)
+    t1 = t0 * sc                   #   * small_constant
+    t2 = t1 + sc                   #   + small_constant
+    t3 = y + t2                    # y + (...)
+    return np.divide(x, t3)        # tf.divide
+
+
+def safe_sqrt(x, clip_value_min=0.0, clip_value_max=float("inf")):
+    """pysgmcmc/tensor_utils.py:319-323."""
+    dt = np.asarray(x).dtype.type
+    t0 = np.maximum(x, dt(clip_value_min))
+    t1 = np.minimum(t0, dt(clip_value_max))
+    return np.sqrt(t1)
+
+
+class OpByOpState(object):
+    """Per-parameter-tensor state as the reference keeps it: one (n,1) column
+    per array (pysgmcmc/tensor_utils.py:87-98, samplers/sghmc.py:126-155)."""
+
+    def __init__(self, theta0, dtype=np.float32):
+        dt = np.dtype(dtype)
+        self.dtype = dt
+        self.theta = np.asarray(theta0, dtype=dt).reshape(-1, 1).copy()
+        ones = np.ones_like(self.theta)
+        self.tau = ones.copy()
+        self.r = (dt.type(1.0) / (self.tau + dt.type(1.0)))
+        self.g = ones.copy()
+        self.v_hat = ones.copy()
+        self.minv = np.divide(dt.type(1.0), np.sqrt(self.v_hat))
+        self.V = np.zeros_like(self.theta)
+        self.p = np.zeros_like(self.theta)
+
+
+def _burn_in_ops(st, grad):
+    """sghmc.py:168-196 / sgld.py:154-180. Returns minv_t; assigns r, tau, minv,
+    g, v_hat in the control-dependency order (all reads see OLD values)."""
+    T = st.dtype.type
+    tau0, g0, vh0 = st.tau, st.g, st.v_hat
+    r_t = T(1.0) / (tau0 + T(1.0))                       # tf.assign(r, 1./(tau+1))
+    a0 = -g0                                             # -g
+    a1 = a0 * g0                                         # -g * g
+    a2 = a1 * tau0                                       # -g * g * tau
+    a3 = safe_divide(a2, vh0)
+    a4 = a3 + T(1.0)
+    tau_t = tau0 + a4                                    # assign_add(tau, ...)
+    minv_t = safe_divide(T(1.0), safe_sqrt(vh0))         # assign(minv, ...)
+    b0 = (-r_t) * g0
+    b1 = r_t * grad
+    g_t = g0 + (b0 + b1)                                 # assign_add(g, ...)
+    c0 = (-r_t) * vh0
+    c1 = r_t * (grad * grad)                             # grad ** 2
+    v_hat_t = vh0 + (c0 + c1)                            # assign_add(v_hat, ...)
+    st.r, st.tau, st.minv, st.g, st.v_hat = r_t, tau_t, minv_t, g_t, v_hat_t
+    return minv_t
+
+
+def opbyop_sghmc_step(st, grad, eps, scale_grad, mdecay, xi, frozen_minv=None,
+                      update_stats_when_frozen=True):
+    """One `session.run` of the SGHMC graph, samplers/sghmc.py:165-251.
+
+    ``frozen_minv`` plays the role of the feed at base_classes.py:454: when
+    given, it replaces the *output tensor* of ``minv_t`` for everything
+    downstream. The statistics ops still execute in TF (they are control
+    dependencies of ``v_t``); ``update_stats_when_frozen`` keeps that side
+    effect, which no output ever observes.
+    """
+    T = st.dtype.type
+    grad = np.asarray(grad, st.dtype).reshape(-1, 1)
+    xi = np.asarray(xi, st.dtype).reshape(-1, 1)
+    eps = T(eps)
+    noise = T(0.0)                                       # :111
+    scale_grad = T(scale_grad)                           # :113
+    eps_s = eps / np.sqrt(scale_grad)                    # :115
+    mdecay = T(mdecay)                                   # :117
+    if frozen_minv is None:
+        minv_t = _burn_in_ops(st, grad)
+    else:
+        if update_stats_when_frozen:
+            _burn_in_ops(st, grad)
+        minv_t = np.asarray(frozen_minv, st.dtype).reshape(-1, 1)
+    # :211-217
+    n0 = T(2.0) * np.power(eps_s, T(2.0))
+    n1 = n0 * mdecay
+    n2 = n1 * minv_t
+    n3 = T(2.0) * np.power(eps_s, T(3.0))
+    n4 = n3 * np.square(minv_t)
+    n5 = n4 * noise
+    n6 = n2 - n5
+    n7 = np.power(eps_s, T(4.0))
+    noise_scale = n6 - n7
+    sigma = np.sqrt(np.maximum(noise_scale, T(1e-16)))   # :220
+    sample = sigma * xi                                  # base_classes.py:218
+    # :233-238
+    v0 = -np.power(eps, T(2.0))
+    v1 = v0 * minv_t
+    v2 = v1 * grad
+    v3 = mdecay * st.V
+    v4 = v2 - v3
+    v5 = v4 + sample
+    v_t = st.V + v5
+    st.V = v_t
+    st.theta = st.theta + v_t                            # :241-243
+    return st.theta
+
+
+def opbyop_sgld_step(st, grad, eps, A, scale_grad, xi, frozen_minv=None,
+                     update_stats_when_frozen=True):
+    """samplers/sgld.py:149-211."""
+    T = st.dtype.type
+    grad = np.asarray(grad, st.dtype).reshape(-1, 1)
+    xi = np.asarray(xi, st.dtype).reshape(-1, 1)
+    eps, A, scale_grad, noise = T(eps), T(A), T(scale_grad), T(0.0)
+    if frozen_minv is None:
+        minv_t = _burn_in_ops(st, grad)
+    else:
+        if update_stats_when_frozen:
+            _burn_in_ops(st, grad)
+        minv_t = np.asarray(frozen_minv, st.dtype).reshape(-1, 1)
+    s0 = T(2.0) * eps
+    s1 = minv_t * (A - noise)
+    s2 = safe_divide(s1, np.asarray(scale_grad))
+    sigma = safe_sqrt(s0 * s2)
+    sample = sigma * xi
+    u0 = (-eps) * minv_t
+    u1 = u0 * A
+    u2 = u1 * grad
+    st.theta = st.theta + (u2 + sample)
+    return st.theta
+
+
+def opbyop_rsghmc_step(st, grad_cost, eps, mass, c, D, b_hat, xi):
+    """samplers/relativistic_sghmc.py:100-140, elementwise."""
+    T = st.dtype.type
+    gl = -np.asarray(grad_cost, st.dtype).reshape(-1, 1)   # tf.gradients(-cost)
+    xi = np.asarray(xi, st.dtype).reshape(-1, 1)
+    eps, m, c, D, b_hat = T(eps), T(mass), T(c), T(D), T(b_hat)
+    m2c2 = np.square(m) * np.square(c)
+    p0 = st.p
+    pg = (eps * p0) / (m * np.sqrt((p0 * p0) / m2c2 + T(1.0)))
+    n = np.sqrt(eps * (T(2.0) * D - eps * b_hat)) * xi
+    p1 = p0 + (((eps * gl) + n) - (D * pg))
+    pg1 = (eps * p1) / (m * np.sqrt((p1 * p1) / m2c2 + T(1.0)))
+    st.p = p1
+    st.theta = st.theta + pg1
+    return st.theta
+
+
+# --------------------------------------------------------------------------
+# Toy targets (pysgmcmc/diagnostics/objective_functions.py:49-98), fp64 numpy
+# --------------------------------------------------------------------------
+
+def banana_log_likelihood(x):
+    return -0.5 * (0.01 * x[0] ** 2 + (x[1] + 0.1 * x[0] ** 2 - 10) ** 2)
+
+
+def banana_cost_grad(x):
+    """cost = -loglik; analytic gradient."""
+    x0, x1 = float(x[0]), float(x[1])
+    t = x1 + 0.1 * x0 ** 2 - 10
+    cost = 0.5 * (0.01 * x0 ** 2 + t ** 2)
+    return cost, np.array([0.01 * x0 + t * 0.2 * x0, t])
+
+
+def gmm_log_likelihood(x, mu=(-5, 0, 5), var=(1., 1., 1.), weights=(1 / 3., 1 / 3., 1 / 3.)):
+    x = float(np.asarray(x).ravel()[0])
+    terms = [np.log(w) - 0.5 * np.log(2.0 * np.pi * v) - 0.5 * ((x - m) ** 2) / v
+             for m, v, w in zip(mu, var, weights)]
+    mx = max(terms)
+    return mx + np.log(sum(np.exp(t - mx) for t in terms))
+
+
+def gmm_cost_grad(x, mu=(-5, 0, 5), var=(1., 1., 1.), weights=(1 / 3., 1 / 3., 1 / 3.)):
+    xv = float(np.asarray(x).ravel()[0])
+    terms = np.array([np.log(w) - 0.5 * np.log(2.0 * np.pi * v) - 0.5 * ((xv - m) ** 2) / v
+                      for m, v, w in zip(mu, var, weights)])
+    ll = gmm_log_likelihood(x, mu, var, weights)
+    resp = np.exp(terms - ll)
+    dll = sum(rk * (-(xv - m) / v) for rk, m, v in zip(resp, mu, var))
+    return -ll, np.array([-dll])
+
+
+# --------------------------------------------------------------------------
+# BNN cost path (pysgmcmc/models/bayesian_neural_network.py), numpy
+# --------------------------------------------------------------------------
+
+def log_variance_prior_log_like(log_var, mean=1e-6, var=0.01):
+    """bayesian_neural_network.py:102-107 (fp64)."""
+    log_var = np.asarray(log_var, np.float64)
+    mean, var = np.float64(mean), np.float64(var)
+    inner = safe_divide(-np.square(log_var - np.log(mean)), np.asarray(2.0 * var)) - 0.5 * np.log(var)
+    return np.mean(np.sum(inner, axis=1))
+
+
+def weight_prior_log_like(parameters, wdecay=1.0):
+    """bayesian_neural_network.py:131-141 (fp64)."""
+    log_like = np.float64(0.0)
+    n_params = np.float64(0.0)
+    for p in parameters:
+        p = np.asarray(p, np.float64)
+        log_like = log_like + np.sum(-wdecay * 0.5 * np.square(p))
+        n_params = n_params + np.float64(p.size)
+    return safe_divide(np.asarray(log_like), np.asarray(n_params))
+
+
+def bnn_forward(params, X):
+    """Default net, bayesian_neural_network.py:28-69. params = [W1,b1,W2,b2,W3,b3,W4,b4,output_bias]."""
+    W1, b1, W2, b2, W3, b3, W4, b4, ob = params
+    h = np.tanh(X @ W1 + b1)
+    h = np.tanh(h @ W2 + b2)
+    h = np.tanh(h @ W3 + b3)
+    mean = h @ W4 + b4
+    log_var = np.ones_like(mean) * ob
+    return np.concatenate([mean, log_var], axis=1)
+
+
+def bnn_negative_log_likelihood(params, X, Y, batch_size, n_examples):
+    """bayesian_neural_network.py:365-388. Returns (nll, mse)."""
+    out = bnn_forward(params, X)
+    f_mean = out[:, 0].reshape(-1, 1)
+    f_log_var = out[:, 1].reshape(-1, 1)
+    f_var_inv = 1.0 / (np.exp(f_log_var) + 1e-16)
+    mse = np.square(Y - f_mean)
+    log_like = np.sum(np.sum(-mse * (0.5 * f_var_inv) - 0.5 * f_log_var, axis=1))
+    log_like = log_like / batch_size
+    log_like = log_like + log_variance_prior_log_like(f_log_var) / n_examples
+    log_like = log_like + weight_prior_log_like(params) / n_examples
+    return -log_like, np.mean(mse)
+
+
+# --------------------------------------------------------------------------
+# Cross-chain diagnostics (formulas of pymc3 3.1, unpinned)
+# --------------------------------------------------------------------------
+
+def gelman_rubin(chains):
+    """chains: (m, n, P) -> R-hat (P,). B = n var_c(mean_c), W = mean_c(var_c),
+    Vhat = W (n-1)/n + B/n, Rhat = sqrt(Vhat / W)   (ddof=1 throughout)."""
+    x = np.asarray(chains, np.float64)
+    m, n = x.shape[0], x.shape[1]
+    B = n * np.var(x.mean(axis=1), axis=0, ddof=1)
+    W = np.mean(np.var(x, axis=1, ddof=1), axis=0)
+    Vhat = W * (n - 1) / n + B / n
+    return np.sqrt(Vhat / W)
+
+
+def effective_n(chains):
+    """chains: (m, n) scalar trace per chain -> n_eff
+    (pysgmcmc/diagnostics/sampler_diagnostics.py:76-82: n_eff = mn / (1 + 2 sum rho_t),
+    truncated at the first odd T with rho_{T+1} + rho_{T+2} < 0; variogram form)."""
+    x = np.asarray(chains, np.float64)
+    m, n = x.shape
+    B = n * np.var(x.mean(axis=1), ddof=1)
+    W = np.mean(np.var(x, axis=1, ddof=1))
+    Vhat = W * (n - 1) / n + B / n
+
+    def vario(t):
+        d = x[:, t:] - x[:, :n - t]
+        return np.sum(d * d) / (m * (n - t))
+
+    rho = np.ones(n)
+    negative_autocorr = False
+    t = 1
+    while not negative_autocorr and t < n:
+        rho[t] = 1.0 - vario(t) / (2.0 * Vhat)
+        if not t % 2:
+            negative_autocorr = (rho[t - 1] + rho[t]) < 0
+        t += 1
+    return int(m * n / (1.0 + 2.0 * rho[1:t].sum()))
