@@ -1,0 +1,148 @@
+/* sgmcmc_hip.h -- C ABI of libsgmcmc_hip.so, the MI355X (gfx950) SG-MCMC update path.
+ *
+ * This is the drop-in boundary for the per-parameter update executed by
+ * `next(sampler)` in MFreidank/pysgmcmc. The reference has no FFI: its boundary
+ * is `session.run([theta_t, cost])` (pysgmcmc/samplers/base_classes.py:298-300,
+ * :438-441), which executes ~25 TensorFlow elementwise ops per parameter tensor.
+ * Each entry point below replaces one such op chain with ONE fused HIP kernel
+ * launch over a flat array of all parameters.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types.
+ *   - Every function returns 0 on success, a positive hipError_t value if the
+ *     HIP runtime failed, or a negative SGMCMC_E* code. sgmcmc_last_error()
+ *     returns a thread-local message for the last failure on this thread.
+ *   - The library never allocates, frees or copies caller memory. All array
+ *     arguments are DEVICE pointers on the device that owns `stream`, n elements
+ *     long. 16-byte-aligned arrays take the vector path (one dwordx4 per lane per
+ *     array); any other alignment takes a slower scalar path with identical
+ *     results.
+ *   - Calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL =
+ *     the null stream) and are legal inside hipStreamBeginCapture.
+ *   - No global mutable state except the launch-geometry knobs of
+ *     sgmcmc_set_launch_config(), which never change results.
+ *   - Arithmetic: one IEEE rounding per reference op, in the reference's op order
+ *     (built with -ffp-contract=off; '/' and sqrt correctly rounded), so with
+ *     injected noise (`xi` != NULL) results are bit-identical to the CPU oracle
+ *     (oracle/sgmcmc_oracle.c) in both f32 and f64.
+ *   - Noise: `xi` == NULL draws xi[i] ~ N(0,1) in registers from Philox4x32-10 with
+ *     counter = (step_lo, step_hi, quad_lo, quad_hi), quad = i / 4, key = (seed_lo,
+ *     seed_hi), then Box-Muller: words (x0,x1) -> elements 4q (sin), 4q+1 (cos);
+ *     (x2,x3) -> 4q+2, 4q+3. Identical to rocRAND's philox4x32_10 stream with
+ *     subsequence = quad, offset = 4*step. The stream depends only on
+ *     (seed, step, i): never on launch geometry, alignment path or device.
+ */
+#ifndef SGMCMC_HIP_H
+#define SGMCMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGMCMC_ABI_VERSION 1
+
+#define SGMCMC_EINVAL   (-1)   /* null/invalid argument */
+#define SGMCMC_ENODEV   (-2)   /* no HIP device / not gfx950 code object */
+
+typedef void *sgmcmc_stream_t;     /* hipStream_t */
+
+int sgmcmc_abi_version(void);
+const char *sgmcmc_last_error(void);
+
+/* Number of HIP devices visible, or a negative code. Does not create a context. */
+int sgmcmc_device_count(void);
+
+/* Launch geometry knobs (performance only; results never depend on them).
+ *   block_threads: 64..1024, multiple of 64 (default 256)
+ *   quads_per_thread: 1, 2 or 4 float4 groups in flight per lane (default 2)
+ *   max_blocks: grid cap, the kernel grid-strides beyond it (default 256 CUs * 8)
+ *   nontemporal: 0/1 use nt loads+stores for streamed arrays (default 0)
+ * Pass 0 (or -1 for nontemporal) to keep the current value. */
+int sgmcmc_set_launch_config(int block_threads, int quads_per_thread, int max_blocks, int nontemporal);
+int sgmcmc_get_launch_config(int *block_threads, int *quads_per_thread, int *max_blocks, int *nontemporal);
+
+/* K1 -- fused SGHMC step. Replaces the op chain pysgmcmc/samplers/sghmc.py:165-251
+ * (+ constants :111-117) and the burn-in switch pysgmcmc/samplers/base_classes.py:432-456.
+ *   adapt = 1  burn-in step (is_burning_in): reads theta,V,grad,tau,g,v_hat; writes
+ *              theta,V,tau,g,v_hat,minv (and r if non-NULL).         48 B/param f32
+ *   adapt = 0  frozen step: reads theta,V,grad,minv; writes theta,V. 24 B/param f32
+ *              (tau,g,v_hat,r may be NULL)
+ *   eps, scale_grad, mdecay: the constructor/schedule scalars; eps_scaled and the
+ *              noise-scale constants are derived inside, in the dtype.
+ *   xi:   NULL -> Philox(seed, step); else injected N(0,1) draws, n elements.
+ *   step: the sampler's n_iterations at the time of the call.                      */
+int sgmcmc_sghmc_step_f32(float *theta, float *V, const float *grad,
+                          float *tau, float *g, float *v_hat, float *minv, float *r,
+                          size_t n, float eps, float scale_grad, float mdecay, int adapt,
+                          const float *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+int sgmcmc_sghmc_step_f64(double *theta, double *V, const double *grad,
+                          double *tau, double *g, double *v_hat, double *minv, double *r,
+                          size_t n, double eps, double scale_grad, double mdecay, int adapt,
+                          const double *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+
+/* K2 -- fused preconditioned SGLD step. Replaces pysgmcmc/samplers/sgld.py:149-211.
+ *   adapt = 1: R{theta,grad,tau,g,v_hat} W{theta,tau,g,v_hat,minv}   40 B/param f32
+ *   adapt = 0: R{theta,grad,minv} W{theta}                           16 B/param f32 */
+int sgmcmc_sgld_step_f32(float *theta, const float *grad,
+                         float *tau, float *g, float *v_hat, float *minv, float *r,
+                         size_t n, float eps, float A, float scale_grad, int adapt,
+                         const float *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+int sgmcmc_sgld_step_f64(double *theta, const double *grad,
+                         double *tau, double *g, double *v_hat, double *minv, double *r,
+                         size_t n, double eps, double A, double scale_grad, int adapt,
+                         const double *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+
+/* K3 -- fused relativistic SGHMC step, per element. Replaces
+ * pysgmcmc/samplers/relativistic_sghmc.py:120-140. grad_cost = d cost / d theta
+ * (the kernel negates it, as :100-103 differentiates -cost).
+ * R{theta,p,grad} W{theta,p}                                         20 B/param f32 */
+int sgmcmc_rsghmc_step_f32(float *theta, float *p, const float *grad_cost, size_t n,
+                           float eps, float mass, float c, float D, float b_hat,
+                           const float *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+int sgmcmc_rsghmc_step_f64(double *theta, double *p, const double *grad_cost, size_t n,
+                           double eps, double mass, double c, double D, double b_hat,
+                           const double *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+
+/* K5 -- write the N(0,1) stream itself: out[i] = xi(seed, step, i). Replaces
+ * tf.random_normal in pysgmcmc/samplers/base_classes.py:218-220 for callers that
+ * want the draws materialised (tests, relativistic momentum initialisation).      */
+int sgmcmc_philox_normal_f32(float *out, size_t n, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+int sgmcmc_philox_normal_f64(double *out, size_t n, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+/* raw Philox words: out[i] = x[i & 3] of quad i >> 2 (bit-exact integer check)     */
+int sgmcmc_philox_bits_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+
+/* K4 -- Welford running moments of one chain, for cross-chain R-hat. Replaces the
+ * per-chain mean/variance pass that pysgmcmc/diagnostics/sampler_diagnostics.py:118-194
+ * delegates to pymc3. count = samples folded in INCLUDING this one (>= 1).
+ * R{theta,mean,m2} W{mean,m2}                                        20 B/param f32 */
+int sgmcmc_moments_update_f32(const float *theta, float *mean, float *m2, size_t n,
+                              uint64_t count, sgmcmc_stream_t stream);
+int sgmcmc_moments_update_f64(const double *theta, double *mean, double *m2, size_t n,
+                              uint64_t count, sgmcmc_stream_t stream);
+
+/* R-hat exchange step. pack: out3[0:n] = mean, out3[n:2n] = mean^2,
+ * out3[2n:3n] = m2/(count-1). The caller all-reduces (SUM) out3 across the m chains
+ * over RCCL, then finish: rhat[i] = sqrt(((W (cnt-1)/cnt) + B/cnt) / W) with
+ * W = S_var/m, B = cnt * (S_sq - S_mean^2/m)/(m-1).                                */
+int sgmcmc_rhat_pack_f32(const float *mean, const float *m2, size_t n, uint64_t count,
+                         float *out3, sgmcmc_stream_t stream);
+int sgmcmc_rhat_finish_f32(const float *sum3, size_t n, int m_chains, uint64_t count,
+                           float *rhat, sgmcmc_stream_t stream);
+
+/* K6 -- deterministic summary of an array: out4 (device, 4 doubles) = {sum, sum of
+ * squares, min, max}. Wave-shuffle partial sums -> LDS -> per-block partials in
+ * `workspace` -> fixed-order final pass; bit-reproducible for a given n.
+ * workspace must hold sgmcmc_summary_workspace_bytes() bytes (device).
+ * Used for the adapted-preconditioner (minv) statistics at the end of burn-in and
+ * for max/mean R-hat.                                                               */
+size_t sgmcmc_summary_workspace_bytes(void);
+int sgmcmc_summary_f32(const float *x, size_t n, double *out4, void *workspace, sgmcmc_stream_t stream);
+int sgmcmc_summary_f64(const double *x, size_t n, double *out4, void *workspace, sgmcmc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGMCMC_HIP_H */

@@ -1,0 +1,105 @@
+"""ctypes binding of ``libsgmcmc_hip.so`` (C ABI in ``include/sgmcmc_hip.h``).
+
+This is the only way the package reaches the GPU update kernels. There is no
+CPU fallback: if the shared library is missing or a call fails, a
+``SgmcmcLibraryError`` is raised.
+"""
+import ctypes
+import os
+
+__all__ = ["SgmcmcLibraryError", "lib", "lib_path", "check", "build"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_LIB_PATH = os.path.join(_CSRC, "libsgmcmc_hip.so")
+
+
+class SgmcmcLibraryError(RuntimeError):
+    """libsgmcmc_hip.so is missing, failed to load, or a call into it failed."""
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def build(force=False):
+    """Compile ``csrc/libsgmcmc_hip.so`` for gfx950 with hipcc (no GPU needed)."""
+    import subprocess
+    src = os.path.join(_CSRC, "sgmcmc_kernels.hip")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "sgmcmc_hip.h")
+    stale = (not os.path.exists(_LIB_PATH)
+             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", _CSRC, "libsgmcmc_hip.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+_u64 = ctypes.c_uint64
+_sz = ctypes.c_size_t
+_ci = ctypes.c_int
+_vp = ctypes.c_void_p
+
+
+def _declare(lib):
+    lib.sgmcmc_abi_version.restype = _ci
+    lib.sgmcmc_last_error.restype = ctypes.c_char_p
+    lib.sgmcmc_device_count.restype = _ci
+    lib.sgmcmc_set_launch_config.argtypes = [_ci, _ci, _ci, _ci]
+    lib.sgmcmc_set_launch_config.restype = _ci
+    lib.sgmcmc_get_launch_config.argtypes = [ctypes.POINTER(_ci)] * 4
+    lib.sgmcmc_get_launch_config.restype = _ci
+    for sfx, real in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
+        f = getattr(lib, "sgmcmc_sghmc_step_" + sfx)
+        f.argtypes = [_vp] * 8 + [_sz, real, real, real, _ci, _vp, _u64, _u64, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_sgld_step_" + sfx)
+        f.argtypes = [_vp] * 7 + [_sz, real, real, real, _ci, _vp, _u64, _u64, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_rsghmc_step_" + sfx)
+        f.argtypes = [_vp] * 3 + [_sz, real, real, real, real, real, _vp, _u64, _u64, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_philox_normal_" + sfx)
+        f.argtypes = [_vp, _sz, _u64, _u64, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_moments_update_" + sfx)
+        f.argtypes = [_vp, _vp, _vp, _sz, _u64, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_summary_" + sfx)
+        f.argtypes = [_vp, _sz, _vp, _vp, _vp]
+        f.restype = _ci
+    lib.sgmcmc_philox_bits_u32.argtypes = [_vp, _sz, _u64, _u64, _vp]
+    lib.sgmcmc_philox_bits_u32.restype = _ci
+    lib.sgmcmc_rhat_pack_f32.argtypes = [_vp, _vp, _sz, _u64, _vp, _vp]
+    lib.sgmcmc_rhat_pack_f32.restype = _ci
+    lib.sgmcmc_rhat_finish_f32.argtypes = [_vp, _sz, _ci, _u64, _vp, _vp]
+    lib.sgmcmc_rhat_finish_f32.restype = _ci
+    lib.sgmcmc_summary_workspace_bytes.restype = _sz
+
+
+def lib():
+    """The loaded library (argtypes declared). Raises SgmcmcLibraryError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise SgmcmcLibraryError(
+            "pysgmcmc_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pysgmcmc_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % _LIB_PATH)
+    try:
+        handle = ctypes.CDLL(_LIB_PATH)
+    except OSError as exc:
+        raise SgmcmcLibraryError("pysgmcmc_amd: cannot load %s: %s" % (_LIB_PATH, exc))
+    _declare(handle)
+    if handle.sgmcmc_abi_version() != 1:
+        raise SgmcmcLibraryError("pysgmcmc_amd: ABI version mismatch in %s" % _LIB_PATH)
+    _lib = handle
+    return handle
+
+
+def check(rc, what):
+    """Turn a non-zero return code into an exception carrying sgmcmc_last_error()."""
+    if rc != 0:
+        msg = lib().sgmcmc_last_error()
+        raise SgmcmcLibraryError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))

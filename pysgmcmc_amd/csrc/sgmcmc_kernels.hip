@@ -1,0 +1,880 @@
+// sgmcmc_kernels.hip -- fused SG-MCMC update kernels for MI355X (gfx950, CDNA4)
+// and the C ABI declared in include/sgmcmc_hip.h.
+//
+// One launch per sampler step over a flat array of ALL parameters replaces the
+// ~25 TensorFlow elementwise ops per parameter tensor that the reference runs in
+// `session.run` (pysgmcmc/samplers/sghmc.py:165-251, sgld.py:149-211,
+// relativistic_sghmc.py:120-140; driver pysgmcmc/samplers/base_classes.py:298-300).
+//
+// Design:
+//   * HBM-bound elementwise pass, no contraction => no MFMA, no LDS staging of
+//     the streamed arrays. Work unit = one "quad" of 4 consecutive elements per
+//     lane: 16 B per lane per array (global_load/store_dwordx4, 1 KiB per wave
+//     instruction), and exactly one Philox4x32-10 call per quad.
+//   * QPT quads per lane are loaded before any is consumed (more bytes in
+//     flight per wave); grid-stride loop, grid capped at a few blocks per CU.
+//   * Noise lives in registers only: Philox counter = (step, quad), key = seed,
+//     Box-Muller on the hardware transcendental units (v_log_f32, v_sqrt_f32,
+//     v_sin_f32, v_cos_f32). 0 bytes of HBM traffic for xi.
+//   * All old state is read into registers before anything is written: that is
+//     the tf.control_dependencies contract of sghmc.py:170-200 made structural.
+//   * One IEEE rounding per reference op, reference op order
+//     (-ffp-contract=off, correctly rounded '/' and sqrt), so injected-noise
+//     results equal the CPU oracle bit for bit.
+//   * K6 (summary) is the only kernel with a reduction: wave shuffles ->
+//     LDS -> per-block partials -> fixed-order final pass.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "sgmcmc_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// --------------------------------------------------------------------------
+// vector types and quad memory access
+// --------------------------------------------------------------------------
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ void load_quad(const float *__restrict__ p, size_t q, float (&v)[4])
+{
+    const f32x4 *p4 = reinterpret_cast<const f32x4 *>(p) + q;
+    f32x4 t = NT ? __builtin_nontemporal_load(p4) : *p4;
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <bool NT>
+__device__ __forceinline__ void store_quad(float *__restrict__ p, size_t q, const float (&v)[4])
+{
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    f32x4 *p4 = reinterpret_cast<f32x4 *>(p) + q;
+    if (NT) __builtin_nontemporal_store(t, p4); else *p4 = t;
+}
+template <bool NT>
+__device__ __forceinline__ void load_quad(const double *__restrict__ p, size_t q, double (&v)[4])
+{
+    const f64x2 *p2 = reinterpret_cast<const f64x2 *>(p) + 2 * q;
+    f64x2 a = NT ? __builtin_nontemporal_load(p2) : p2[0];
+    f64x2 b = NT ? __builtin_nontemporal_load(p2 + 1) : p2[1];
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+template <bool NT>
+__device__ __forceinline__ void store_quad(double *__restrict__ p, size_t q, const double (&v)[4])
+{
+    f64x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    f64x2 *p2 = reinterpret_cast<f64x2 *>(p) + 2 * q;
+    if (NT) { __builtin_nontemporal_store(a, p2); __builtin_nontemporal_store(b, p2 + 1); }
+    else { p2[0] = a; p2[1] = b; }
+}
+// element-wise access for misaligned arrays and the ragged tail (cnt in 1..4)
+template <typename T>
+__device__ __forceinline__ void load_part(const T *__restrict__ p, size_t q, int cnt, T (&v)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (j < cnt) ? p[4 * q + j] : T(1);
+}
+template <typename T>
+__device__ __forceinline__ void store_part(T *__restrict__ p, size_t q, int cnt, const T (&v)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j < cnt) p[4 * q + j] = v[j];
+}
+
+// --------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11) + Box-Muller, all in registers
+// --------------------------------------------------------------------------
+
+struct NoiseKey { uint32_t k0, k1, s0, s1; };   // key = seed, (s0,s1) = step
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&x)[4])
+{
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    x[0] = c0; x[1] = c1; x[2] = c2; x[3] = c3;
+}
+
+__device__ __forceinline__ void philox_quad(const NoiseKey &nk, size_t q, uint32_t (&x)[4])
+{
+    philox4x32_10(nk.s0, nk.s1, (uint32_t)q, (uint32_t)((uint64_t)q >> 32), nk.k0, nk.k1, x);
+}
+
+// 4 standard normals for quad q. f32: hardware transcendentals
+// (v_log_f32 = log2, v_sin/cos_f32 take revolutions).
+__device__ __forceinline__ void normal_quad(const NoiseKey &nk, size_t q, float (&z)[4])
+{
+    uint32_t x[4];
+    philox_quad(nk, q, x);
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        float u = __builtin_fmaf((float)x[2 * pr], 0x1p-32f, 0x1p-33f);        // (0,1]
+        float rev = __builtin_fmaf((float)x[2 * pr + 1], 0x1p-32f, 0x1p-33f);  // (0,1]
+        float s = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));
+        z[2 * pr] = s * __builtin_amdgcn_sinf(rev);
+        z[2 * pr + 1] = s * __builtin_amdgcn_cosf(rev);
+    }
+}
+__device__ __forceinline__ void normal_quad(const NoiseKey &nk, size_t q, double (&z)[4])
+{
+    uint32_t x[4];
+    philox_quad(nk, q, x);
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        double u = ((double)x[2 * pr] + 0.5) * 0x1p-32;
+        double rev = ((double)x[2 * pr + 1] + 0.5) * 0x1p-32;
+        double s = sqrt(-2.0 * log(u));
+        double sn, cs;
+        sincospi(2.0 * rev, &sn, &cs);
+        z[2 * pr] = s * sn;
+        z[2 * pr + 1] = s * cs;
+    }
+}
+
+// --------------------------------------------------------------------------
+// reference scalar helpers (pysgmcmc/tensor_utils.py:269, :319-323)
+// --------------------------------------------------------------------------
+
+template <typename T> __device__ __forceinline__ T rsqrt_rn(T x);
+template <> __device__ __forceinline__ float rsqrt_rn<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ double rsqrt_rn<double>(double x) { return sqrt(x); }
+
+template <typename T>
+__device__ __forceinline__ T sdiv(T x, T y)
+{
+    const T sc = T(1e-16);
+    T sgn = (y > T(0)) ? T(1) : ((y < T(0)) ? T(-1) : T(0));
+    T delta = (T(2) * sgn) * sc + sc;
+    return x / (y + delta);
+}
+template <typename T>
+__device__ __forceinline__ T ssqrt(T x)
+{
+    T c = (x > T(0)) ? x : T(0);
+    c = (c < (T)INFINITY) ? c : (T)INFINITY;
+    return rsqrt_rn<T>(c);
+}
+
+// burn-in statistics, sghmc.py:168-196 == sgld.py:154-180 (all reads are of OLD state)
+template <typename T>
+__device__ __forceinline__ T adapt_stats(T grad, T &tau, T &g, T &vh, T &r_out)
+{
+    T tau0 = tau, g0 = g, vh0 = vh;
+    T r = T(1) / (tau0 + T(1));
+    T tau1 = tau0 + (sdiv<T>(((-g0) * g0) * tau0, vh0) + T(1));
+    T minv = sdiv<T>(T(1), ssqrt<T>(vh0));
+    T g1 = g0 + ((-r) * g0 + r * grad);
+    T vh1 = vh0 + ((-r) * vh0 + r * (grad * grad));
+    tau = tau1; g = g1; vh = vh1; r_out = r;
+    return minv;
+}
+
+// --------------------------------------------------------------------------
+// per-sampler quad operators
+// --------------------------------------------------------------------------
+
+template <typename T, bool ADAPT, bool INJECT>
+struct SghmcOp {
+    typedef T real;
+    T *theta, *V; const T *grad; T *tau, *g, *vh, *minv, *r; const T *xi;
+    T e2, c1, c3, e4, mdecay;      // host-derived scalars, sghmc.py:111-117,211-217,235
+    NoiseKey nk;
+    struct Regs { T th[4], v[4], gr[4], mi[4], tau[4], g[4], vh[4], rr[4], z[4]; };
+
+    template <bool NT> __device__ __forceinline__ void load_vec(size_t q, Regs &R) const
+    {
+        load_quad<NT>(theta, q, R.th); load_quad<NT>(V, q, R.v); load_quad<NT>(grad, q, R.gr);
+        if (ADAPT) { load_quad<NT>(tau, q, R.tau); load_quad<NT>(g, q, R.g); load_quad<NT>(vh, q, R.vh); }
+        else load_quad<NT>(minv, q, R.mi);
+        if (INJECT) load_quad<NT>(xi, q, R.z);
+    }
+    __device__ __forceinline__ void load_part_(size_t q, int cnt, Regs &R) const
+    {
+        load_part(theta, q, cnt, R.th); load_part(V, q, cnt, R.v); load_part(grad, q, cnt, R.gr);
+        if (ADAPT) { load_part(tau, q, cnt, R.tau); load_part(g, q, cnt, R.g); load_part(vh, q, cnt, R.vh); }
+        else load_part(minv, q, cnt, R.mi);
+        if (INJECT) load_part(xi, q, cnt, R.z);
+    }
+    __device__ __forceinline__ void compute(size_t q, Regs &R) const
+    {
+        if (!INJECT) normal_quad(nk, q, R.z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            T gr = R.gr[j];
+            T mi;
+            if constexpr (ADAPT) { mi = adapt_stats<T>(gr, R.tau[j], R.g[j], R.vh[j], R.rr[j]); R.mi[j] = mi; }
+            else mi = R.mi[j];
+            T noise_scale = (c1 * mi - (c3 * (mi * mi)) * T(0)) - e4;                    // :211-217
+            T sigma = rsqrt_rn<T>((noise_scale > T(1e-16)) ? noise_scale : T(1e-16));     // :220
+            T sample = sigma * R.z[j];
+            T v0 = R.v[j];
+            T v1 = v0 + (((((-e2) * mi) * gr) - mdecay * v0) + sample);                   // :233-238
+            R.v[j] = v1;
+            R.th[j] = R.th[j] + v1;                                                      // :241-243
+        }
+    }
+    template <bool NT> __device__ __forceinline__ void store_vec(size_t q, const Regs &R) const
+    {
+        store_quad<NT>(theta, q, R.th); store_quad<NT>(V, q, R.v);
+        if (ADAPT) {
+            store_quad<NT>(tau, q, R.tau); store_quad<NT>(g, q, R.g); store_quad<NT>(vh, q, R.vh);
+            store_quad<NT>(minv, q, R.mi);
+            if (r) store_quad<NT>(r, q, R.rr);
+        }
+    }
+    __device__ __forceinline__ void store_part_(size_t q, int cnt, const Regs &R) const
+    {
+        store_part(theta, q, cnt, R.th); store_part(V, q, cnt, R.v);
+        if (ADAPT) {
+            store_part(tau, q, cnt, R.tau); store_part(g, q, cnt, R.g); store_part(vh, q, cnt, R.vh);
+            store_part(minv, q, cnt, R.mi);
+            if (r) store_part(r, q, cnt, R.rr);
+        }
+    }
+};
+
+template <typename T, bool ADAPT, bool INJECT>
+struct SgldOp {
+    typedef T real;
+    T *theta; const T *grad; T *tau, *g, *vh, *minv, *r; const T *xi;
+    T eps, A, a_eff, two_eps, sg_den;     // sgld.py:106-108,186-191,201-204
+    NoiseKey nk;
+    struct Regs { T th[4], gr[4], mi[4], tau[4], g[4], vh[4], rr[4], z[4]; };
+
+    template <bool NT> __device__ __forceinline__ void load_vec(size_t q, Regs &R) const
+    {
+        load_quad<NT>(theta, q, R.th); load_quad<NT>(grad, q, R.gr);
+        if (ADAPT) { load_quad<NT>(tau, q, R.tau); load_quad<NT>(g, q, R.g); load_quad<NT>(vh, q, R.vh); }
+        else load_quad<NT>(minv, q, R.mi);
+        if (INJECT) load_quad<NT>(xi, q, R.z);
+    }
+    __device__ __forceinline__ void load_part_(size_t q, int cnt, Regs &R) const
+    {
+        load_part(theta, q, cnt, R.th); load_part(grad, q, cnt, R.gr);
+        if (ADAPT) { load_part(tau, q, cnt, R.tau); load_part(g, q, cnt, R.g); load_part(vh, q, cnt, R.vh); }
+        else load_part(minv, q, cnt, R.mi);
+        if (INJECT) load_part(xi, q, cnt, R.z);
+    }
+    __device__ __forceinline__ void compute(size_t q, Regs &R) const
+    {
+        if (!INJECT) normal_quad(nk, q, R.z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            T gr = R.gr[j];
+            T mi;
+            if constexpr (ADAPT) { mi = adapt_stats<T>(gr, R.tau[j], R.g[j], R.vh[j], R.rr[j]); R.mi[j] = mi; }
+            else mi = R.mi[j];
+            T sigma = ssqrt<T>(two_eps * ((mi * a_eff) / sg_den));                        // :186-191
+            T sample = sigma * R.z[j];
+            R.th[j] = R.th[j] + (((((-eps) * mi) * A) * gr) + sample);                    // :201-204
+        }
+    }
+    template <bool NT> __device__ __forceinline__ void store_vec(size_t q, const Regs &R) const
+    {
+        store_quad<NT>(theta, q, R.th);
+        if (ADAPT) {
+            store_quad<NT>(tau, q, R.tau); store_quad<NT>(g, q, R.g); store_quad<NT>(vh, q, R.vh);
+            store_quad<NT>(minv, q, R.mi);
+            if (r) store_quad<NT>(r, q, R.rr);
+        }
+    }
+    __device__ __forceinline__ void store_part_(size_t q, int cnt, const Regs &R) const
+    {
+        store_part(theta, q, cnt, R.th);
+        if (ADAPT) {
+            store_part(tau, q, cnt, R.tau); store_part(g, q, cnt, R.g); store_part(vh, q, cnt, R.vh);
+            store_part(minv, q, cnt, R.mi);
+            if (r) store_part(r, q, cnt, R.rr);
+        }
+    }
+};
+
+template <typename T, bool ADAPT_UNUSED, bool INJECT>
+struct RsghmcOp {
+    typedef T real;
+    T *theta, *p; const T *grad; const T *xi;
+    T eps, mass, D, m2c2, nscale;         // relativistic_sghmc.py:105-106,117-125
+    NoiseKey nk;
+    struct Regs { T th[4], p[4], gr[4], z[4]; };
+
+    template <bool NT> __device__ __forceinline__ void load_vec(size_t q, Regs &R) const
+    {
+        load_quad<NT>(theta, q, R.th); load_quad<NT>(p, q, R.p); load_quad<NT>(grad, q, R.gr);
+        if (INJECT) load_quad<NT>(xi, q, R.z);
+    }
+    __device__ __forceinline__ void load_part_(size_t q, int cnt, Regs &R) const
+    {
+        load_part(theta, q, cnt, R.th); load_part(p, q, cnt, R.p); load_part(grad, q, cnt, R.gr);
+        if (INJECT) load_part(xi, q, cnt, R.z);
+    }
+    __device__ __forceinline__ void compute(size_t q, Regs &R) const
+    {
+        if (!INJECT) normal_quad(nk, q, R.z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            T p0 = R.p[j];
+            T gl = -R.gr[j];                                                             // :100-103
+            T pg = (eps * p0) / (mass * rsqrt_rn<T>((p0 * p0) / m2c2 + T(1)));           // :123
+            T nz = nscale * R.z[j];                                                      // :125
+            T p1 = p0 + (((eps * gl) + nz) - (D * pg));                                  // :126-129
+            T pg1 = (eps * p1) / (mass * rsqrt_rn<T>((p1 * p1) / m2c2 + T(1)));          // :131
+            R.p[j] = p1;
+            R.th[j] = R.th[j] + pg1;                                                     // :132-135
+        }
+    }
+    template <bool NT> __device__ __forceinline__ void store_vec(size_t q, const Regs &R) const
+    {
+        store_quad<NT>(theta, q, R.th); store_quad<NT>(p, q, R.p);
+    }
+    __device__ __forceinline__ void store_part_(size_t q, int cnt, const Regs &R) const
+    {
+        store_part(theta, q, cnt, R.th); store_part(p, q, cnt, R.p);
+    }
+};
+
+template <typename T>
+struct NormalFillOp {
+    typedef T real;
+    T *out; NoiseKey nk;
+    struct Regs { T z[4]; };
+    template <bool NT> __device__ __forceinline__ void load_vec(size_t, Regs &) const {}
+    __device__ __forceinline__ void load_part_(size_t, int, Regs &) const {}
+    __device__ __forceinline__ void compute(size_t q, Regs &R) const { normal_quad(nk, q, R.z); }
+    template <bool NT> __device__ __forceinline__ void store_vec(size_t q, const Regs &R) const { store_quad<NT>(out, q, R.z); }
+    __device__ __forceinline__ void store_part_(size_t q, int cnt, const Regs &R) const { store_part(out, q, cnt, R.z); }
+};
+
+template <typename T>
+struct MomentsOp {
+    typedef T real;
+    const T *theta; T *mean, *m2; T inv;
+    struct Regs { T x[4], mu[4], m2[4]; };
+    template <bool NT> __device__ __forceinline__ void load_vec(size_t q, Regs &R) const
+    { load_quad<NT>(theta, q, R.x); load_quad<NT>(mean, q, R.mu); load_quad<NT>(m2, q, R.m2); }
+    __device__ __forceinline__ void load_part_(size_t q, int cnt, Regs &R) const
+    { load_part(theta, q, cnt, R.x); load_part(mean, q, cnt, R.mu); load_part(m2, q, cnt, R.m2); }
+    __device__ __forceinline__ void compute(size_t, Regs &R) const
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            T x = R.x[j];
+            T d = x - R.mu[j];
+            T mu = R.mu[j] + d * inv;
+            R.mu[j] = mu;
+            R.m2[j] = R.m2[j] + d * (x - mu);
+        }
+    }
+    template <bool NT> __device__ __forceinline__ void store_vec(size_t q, const Regs &R) const
+    { store_quad<NT>(mean, q, R.mu); store_quad<NT>(m2, q, R.m2); }
+    __device__ __forceinline__ void store_part_(size_t q, int cnt, const Regs &R) const
+    { store_part(mean, q, cnt, R.mu); store_part(m2, q, cnt, R.m2); }
+};
+
+// --------------------------------------------------------------------------
+// the one streaming kernel shape all operators share
+// --------------------------------------------------------------------------
+
+// VEC: arrays are 16-B aligned; quads [0, nq_full) go through dwordx4 accesses,
+//      QPT quads in flight per lane; the ragged tail (n % 4 elements) is done
+//      element-wise by one lane.
+template <typename Op, int QPT, bool NT>
+__global__ void __launch_bounds__(256) stream_quads_vec(const Op op, size_t nq_full, int tail_cnt)
+{
+    const size_t G = (size_t)gridDim.x * blockDim.x;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t base = gid; base < nq_full; base += G * QPT) {
+        typename Op::Regs R[QPT];
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+            size_t q = base + (size_t)u * G;
+            if (q < nq_full) op.template load_vec<NT>(q, R[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+            size_t q = base + (size_t)u * G;
+            if (q < nq_full) op.compute(q, R[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+            size_t q = base + (size_t)u * G;
+            if (q < nq_full) op.template store_vec<NT>(q, R[u]);
+        }
+    }
+    if (tail_cnt && gid == G - 1) {
+        typename Op::Regs R;
+        op.load_part_(nq_full, tail_cnt, R);
+        op.compute(nq_full, R);
+        op.store_part_(nq_full, tail_cnt, R);
+    }
+}
+
+// element-wise path for misaligned arrays: same quads, same results
+template <typename Op>
+__global__ void __launch_bounds__(256) stream_quads_scalar(const Op op, size_t n)
+{
+    const size_t G = (size_t)gridDim.x * blockDim.x;
+    const size_t nq = (n + 3) / 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += G) {
+        size_t left = n - 4 * q;
+        int cnt = left >= 4 ? 4 : (int)left;
+        typename Op::Regs R;
+        op.load_part_(q, cnt, R);
+        op.compute(q, R);
+        op.store_part_(q, cnt, R);
+    }
+}
+
+// --------------------------------------------------------------------------
+// K6 summary: wave shuffles -> LDS -> per-block partials -> fixed-order final
+// --------------------------------------------------------------------------
+
+constexpr int SUMMARY_BLOCKS = 1024;
+constexpr int SUMMARY_THREADS = 256;
+
+struct Summary { double s, ss, mn, mx; };
+
+__device__ __forceinline__ Summary summary_combine(Summary a, Summary b)
+{
+    Summary o;
+    o.s = a.s + b.s; o.ss = a.ss + b.ss;
+    o.mn = a.mn < b.mn ? a.mn : b.mn;
+    o.mx = a.mx > b.mx ? a.mx : b.mx;
+    return o;
+}
+__device__ __forceinline__ Summary summary_wave_reduce(Summary v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Summary o;
+        o.s = __shfl_down(v.s, off, 64);
+        o.ss = __shfl_down(v.ss, off, 64);
+        o.mn = __shfl_down(v.mn, off, 64);
+        o.mx = __shfl_down(v.mx, off, 64);
+        v = summary_combine(v, o);
+    }
+    return v;
+}
+__device__ __forceinline__ Summary summary_block_reduce(Summary v)
+{
+    __shared__ Summary lds[SUMMARY_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = summary_wave_reduce(v);
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    if (wave == 0) {
+        const int nw = blockDim.x >> 6;
+        Summary w = lds[lane < nw ? lane : 0];
+        if (lane >= nw) { w.s = 0; w.ss = 0; w.mn = INFINITY; w.mx = -INFINITY; }
+        v = summary_wave_reduce(w);
+    }
+    return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(SUMMARY_THREADS) summary_partial(const T *__restrict__ x, size_t n, Summary *__restrict__ part)
+{
+    Summary acc = {0.0, 0.0, INFINITY, -INFINITY};
+    const size_t G = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += G) {
+        double v = (double)x[i];
+        acc.s += v; acc.ss += v * v;
+        acc.mn = v < acc.mn ? v : acc.mn;
+        acc.mx = v > acc.mx ? v : acc.mx;
+    }
+    acc = summary_block_reduce(acc);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ void __launch_bounds__(SUMMARY_THREADS) summary_final(const Summary *__restrict__ part, int nparts, double *__restrict__ out4)
+{
+    Summary acc = {0.0, 0.0, INFINITY, -INFINITY};
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) acc = summary_combine(acc, part[i]);
+    acc = summary_block_reduce(acc);
+    if (threadIdx.x == 0) { out4[0] = acc.s; out4[1] = acc.ss; out4[2] = acc.mn; out4[3] = acc.mx; }
+}
+
+// --------------------------------------------------------------------------
+// R-hat pack / finish and raw Philox words (small elementwise kernels)
+// --------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) rhat_pack_kernel(const float *__restrict__ mean, const float *__restrict__ m2,
+                                                        size_t n, float inv_cm1, float *__restrict__ out3)
+{
+    const size_t G = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += G) {
+        float mu = mean[i];
+        out3[i] = mu;
+        out3[n + i] = mu * mu;
+        out3[2 * n + i] = m2[i] * inv_cm1;
+    }
+}
+__global__ void __launch_bounds__(256) rhat_finish_kernel(const float *__restrict__ sum3, size_t n, float m, float cnt,
+                                                          float *__restrict__ rhat)
+{
+    const size_t G = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += G) {
+        float s_mean = sum3[i], s_sq = sum3[n + i], s_var = sum3[2 * n + i];
+        float W = s_var / m;
+        float B = cnt * ((s_sq - (s_mean * s_mean) / m) / (m - 1.0f));
+        float Vhat = W * ((cnt - 1.0f) / cnt) + B / cnt;
+        rhat[i] = sqrtf(Vhat / W);
+    }
+}
+__global__ void __launch_bounds__(256) philox_bits_kernel(uint32_t *__restrict__ out, size_t n, NoiseKey nk)
+{
+    const size_t G = (size_t)gridDim.x * blockDim.x;
+    const size_t nq = (n + 3) / 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += G) {
+        uint32_t x[4];
+        philox_quad(nk, q, x);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * q + j < n) out[4 * q + j] = x[j];
+    }
+}
+
+// --------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int hip_fail(hipError_t e, const char *what)
+{
+    return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+}
+
+std::atomic<int> g_block_threads{256};
+std::atomic<int> g_qpt{2};
+std::atomic<int> g_max_blocks{256 * 8};
+std::atomic<int> g_nt{0};
+
+inline bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline NoiseKey make_key(uint64_t seed, uint64_t step)
+{
+    NoiseKey nk;
+    nk.k0 = (uint32_t)seed; nk.k1 = (uint32_t)(seed >> 32);
+    nk.s0 = (uint32_t)step; nk.s1 = (uint32_t)(step >> 32);
+    return nk;
+}
+
+template <typename Op, int QPT, bool NT>
+int launch_vec(const Op &op, size_t n, hipStream_t st)
+{
+    const int bt = g_block_threads.load();
+    const size_t nq_full = n / 4;
+    const int tail = (int)(n % 4);
+    size_t per_block = (size_t)bt * QPT;
+    size_t want = (nq_full + per_block - 1) / per_block;
+    if (want == 0) want = 1;
+    size_t cap = (size_t)g_max_blocks.load();
+    unsigned grid = (unsigned)(want < cap ? want : cap);
+    hipLaunchKernelGGL((stream_quads_vec<Op, QPT, NT>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch stream_quads_vec");
+}
+template <typename Op>
+int launch_scalar(const Op &op, size_t n, hipStream_t st)
+{
+    const int bt = g_block_threads.load();
+    size_t nq = (n + 3) / 4;
+    size_t want = (nq + bt - 1) / bt;
+    if (want == 0) want = 1;
+    size_t cap = (size_t)g_max_blocks.load();
+    unsigned grid = (unsigned)(want < cap ? want : cap);
+    hipLaunchKernelGGL((stream_quads_scalar<Op>), dim3(grid), dim3(bt), 0, st, op, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch stream_quads_scalar");
+}
+
+// f32 ops honour the (quads_per_thread, nontemporal) knobs; f64 ops (a quad is
+// already 32 B per lane per array) use one quad per lane.
+template <typename Op>
+int launch(const Op &op, size_t n, bool vec_ok, hipStream_t st)
+{
+    if (n == 0) return 0;
+    if (!vec_ok) return launch_scalar<Op>(op, n, st);
+    if (sizeof(typename Op::real) == 8) {
+        return g_nt.load() ? launch_vec<Op, 1, true>(op, n, st) : launch_vec<Op, 1, false>(op, n, st);
+    }
+    const int qpt = g_qpt.load();
+    if (g_nt.load()) {
+        if (qpt >= 4) return launch_vec<Op, 4, true>(op, n, st);
+        if (qpt == 2) return launch_vec<Op, 2, true>(op, n, st);
+        return launch_vec<Op, 1, true>(op, n, st);
+    }
+    if (qpt >= 4) return launch_vec<Op, 4, false>(op, n, st);
+    if (qpt == 2) return launch_vec<Op, 2, false>(op, n, st);
+    return launch_vec<Op, 1, false>(op, n, st);
+}
+
+template <typename T>
+int sghmc_step(T *theta, T *V, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, size_t n,
+               T eps, T scale_grad, T mdecay, int adapt, const T *xi, uint64_t seed, uint64_t step, hipStream_t st)
+{
+    if (n == 0) return 0;
+    if (!theta || !V || !grad || !minv) return fail(SGMCMC_EINVAL, "sghmc_step: theta, V, grad and minv must be non-NULL");
+    if (adapt && (!tau || !g || !v_hat)) return fail(SGMCMC_EINVAL, "sghmc_step: adapt=1 needs tau, g and v_hat");
+    // scalars of the reference graph, in the dtype, same op order (sghmc.py:111-117,211-217,235)
+    T eps_s = eps / std::sqrt(scale_grad);
+    T e2 = std::pow(eps, T(2));
+    T c1 = (T(2) * std::pow(eps_s, T(2))) * mdecay;
+    T c3 = T(2) * std::pow(eps_s, T(3));
+    T e4 = std::pow(eps_s, T(4));
+    NoiseKey nk = make_key(seed, step);
+    bool vec_ok = aligned16(theta) && aligned16(V) && aligned16(grad) && aligned16(minv) && aligned16(xi) &&
+                  (!adapt || (aligned16(tau) && aligned16(g) && aligned16(v_hat) && aligned16(r)));
+#define SGHMC_GO(AD, INJ)                                                                              \
+    {                                                                                                  \
+        SghmcOp<T, AD, INJ> op{theta, V, grad, tau, g, v_hat, minv, r, xi, e2, c1, c3, e4, mdecay, nk}; \
+        return launch(op, n, vec_ok, st);                                                              \
+    }
+    if (adapt) { if (xi) SGHMC_GO(true, true) else SGHMC_GO(true, false) }
+    else { if (xi) SGHMC_GO(false, true) else SGHMC_GO(false, false) }
+#undef SGHMC_GO
+}
+
+template <typename T>
+int sgld_step(T *theta, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, size_t n,
+              T eps, T A, T scale_grad, int adapt, const T *xi, uint64_t seed, uint64_t step, hipStream_t st)
+{
+    if (n == 0) return 0;
+    if (!theta || !grad || !minv) return fail(SGMCMC_EINVAL, "sgld_step: theta, grad and minv must be non-NULL");
+    if (adapt && (!tau || !g || !v_hat)) return fail(SGMCMC_EINVAL, "sgld_step: adapt=1 needs tau, g and v_hat");
+    T sgn = (scale_grad > T(0)) ? T(1) : ((scale_grad < T(0)) ? T(-1) : T(0));
+    T sg_den = scale_grad + ((T(2) * sgn) * T(1e-16) + T(1e-16));
+    T two_eps = T(2) * eps;
+    T a_eff = A - T(0);
+    NoiseKey nk = make_key(seed, step);
+    bool vec_ok = aligned16(theta) && aligned16(grad) && aligned16(minv) && aligned16(xi) &&
+                  (!adapt || (aligned16(tau) && aligned16(g) && aligned16(v_hat) && aligned16(r)));
+#define SGLD_GO(AD, INJ)                                                                            \
+    {                                                                                               \
+        SgldOp<T, AD, INJ> op{theta, grad, tau, g, v_hat, minv, r, xi, eps, A, a_eff, two_eps, sg_den, nk}; \
+        return launch(op, n, vec_ok, st);                                                           \
+    }
+    if (adapt) { if (xi) SGLD_GO(true, true) else SGLD_GO(true, false) }
+    else { if (xi) SGLD_GO(false, true) else SGLD_GO(false, false) }
+#undef SGLD_GO
+}
+
+template <typename T>
+int rsghmc_step(T *theta, T *p, const T *grad, size_t n, T eps, T mass, T c, T D, T b_hat,
+                const T *xi, uint64_t seed, uint64_t step, hipStream_t st)
+{
+    if (n == 0) return 0;
+    if (!theta || !p || !grad) return fail(SGMCMC_EINVAL, "rsghmc_step: theta, p and grad_cost must be non-NULL");
+    T m2c2 = (mass * mass) * (c * c);
+    T nscale = std::sqrt(eps * ((T(2) * D) - (eps * b_hat)));
+    NoiseKey nk = make_key(seed, step);
+    bool vec_ok = aligned16(theta) && aligned16(p) && aligned16(grad) && aligned16(xi);
+    if (xi) {
+        RsghmcOp<T, false, true> op{theta, p, grad, xi, eps, mass, D, m2c2, nscale, nk};
+        return launch(op, n, vec_ok, st);
+    }
+    RsghmcOp<T, false, false> op{theta, p, grad, xi, eps, mass, D, m2c2, nscale, nk};
+    return launch(op, n, vec_ok, st);
+}
+
+template <typename T>
+int summary(const T *x, size_t n, double *out4, void *ws, hipStream_t st)
+{
+    if (!x || !out4 || !ws) return fail(SGMCMC_EINVAL, "summary: NULL argument");
+    size_t want = (n + SUMMARY_THREADS - 1) / SUMMARY_THREADS;
+    int blocks = (int)(want < (size_t)SUMMARY_BLOCKS ? (want ? want : 1) : SUMMARY_BLOCKS);
+    Summary *part = static_cast<Summary *>(ws);
+    hipLaunchKernelGGL((summary_partial<T>), dim3(blocks), dim3(SUMMARY_THREADS), 0, st, x, n, part);
+    hipLaunchKernelGGL(summary_final, dim3(1), dim3(SUMMARY_THREADS), 0, st, part, blocks, out4);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch summary");
+}
+
+inline unsigned small_grid(size_t n)
+{
+    size_t want = (n + 255) / 256;
+    size_t cap = (size_t)g_max_blocks.load();
+    return (unsigned)(want < cap ? (want ? want : 1) : cap);
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------
+// C ABI
+// --------------------------------------------------------------------------
+
+extern "C" {
+
+int sgmcmc_abi_version(void) { return SGMCMC_ABI_VERSION; }
+const char *sgmcmc_last_error(void) { return g_err; }
+
+int sgmcmc_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(SGMCMC_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    return n;
+}
+
+int sgmcmc_set_launch_config(int block_threads, int quads_per_thread, int max_blocks, int nontemporal)
+{
+    if (block_threads != 0) {
+        if (block_threads < 64 || block_threads > 256 || (block_threads % 64) != 0)
+            return fail(SGMCMC_EINVAL, "block_threads must be 64, 128, 192 or 256");
+        g_block_threads.store(block_threads);
+    }
+    if (quads_per_thread != 0) {
+        if (quads_per_thread != 1 && quads_per_thread != 2 && quads_per_thread != 4)
+            return fail(SGMCMC_EINVAL, "quads_per_thread must be 1, 2 or 4");
+        g_qpt.store(quads_per_thread);
+    }
+    if (max_blocks != 0) {
+        if (max_blocks < 1) return fail(SGMCMC_EINVAL, "max_blocks must be >= 1");
+        g_max_blocks.store(max_blocks);
+    }
+    if (nontemporal >= 0) g_nt.store(nontemporal ? 1 : 0);
+    return 0;
+}
+int sgmcmc_get_launch_config(int *block_threads, int *quads_per_thread, int *max_blocks, int *nontemporal)
+{
+    if (block_threads) *block_threads = g_block_threads.load();
+    if (quads_per_thread) *quads_per_thread = g_qpt.load();
+    if (max_blocks) *max_blocks = g_max_blocks.load();
+    if (nontemporal) *nontemporal = g_nt.load();
+    return 0;
+}
+
+int sgmcmc_sghmc_step_f32(float *theta, float *V, const float *grad, float *tau, float *g, float *v_hat,
+                          float *minv, float *r, size_t n, float eps, float scale_grad, float mdecay, int adapt,
+                          const float *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream)
+{
+    return sghmc_step<float>(theta, V, grad, tau, g, v_hat, minv, r, n, eps, scale_grad, mdecay, adapt, xi, seed, step,
+                             static_cast<hipStream_t>(stream));
+}
+int sgmcmc_sghmc_step_f64(double *theta, double *V, const double *grad, double *tau, double *g, double *v_hat,
+                          double *minv, double *r, size_t n, double eps, double scale_grad, double mdecay, int adapt,
+                          const double *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream)
+{
+    return sghmc_step<double>(theta, V, grad, tau, g, v_hat, minv, r, n, eps, scale_grad, mdecay, adapt, xi, seed, step,
+                              static_cast<hipStream_t>(stream));
+}
+int sgmcmc_sgld_step_f32(float *theta, const float *grad, float *tau, float *g, float *v_hat, float *minv, float *r,
+                         size_t n, float eps, float A, float scale_grad, int adapt, const float *xi, uint64_t seed,
+                         uint64_t step, sgmcmc_stream_t stream)
+{
+    return sgld_step<float>(theta, grad, tau, g, v_hat, minv, r, n, eps, A, scale_grad, adapt, xi, seed, step,
+                            static_cast<hipStream_t>(stream));
+}
+int sgmcmc_sgld_step_f64(double *theta, const double *grad, double *tau, double *g, double *v_hat, double *minv,
+                         double *r, size_t n, double eps, double A, double scale_grad, int adapt, const double *xi,
+                         uint64_t seed, uint64_t step, sgmcmc_stream_t stream)
+{
+    return sgld_step<double>(theta, grad, tau, g, v_hat, minv, r, n, eps, A, scale_grad, adapt, xi, seed, step,
+                             static_cast<hipStream_t>(stream));
+}
+int sgmcmc_rsghmc_step_f32(float *theta, float *p, const float *grad_cost, size_t n, float eps, float mass, float c,
+                           float D, float b_hat, const float *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream)
+{
+    return rsghmc_step<float>(theta, p, grad_cost, n, eps, mass, c, D, b_hat, xi, seed, step,
+                              static_cast<hipStream_t>(stream));
+}
+int sgmcmc_rsghmc_step_f64(double *theta, double *p, const double *grad_cost, size_t n, double eps, double mass,
+                           double c, double D, double b_hat, const double *xi, uint64_t seed, uint64_t step,
+                           sgmcmc_stream_t stream)
+{
+    return rsghmc_step<double>(theta, p, grad_cost, n, eps, mass, c, D, b_hat, xi, seed, step,
+                               static_cast<hipStream_t>(stream));
+}
+
+int sgmcmc_philox_normal_f32(float *out, size_t n, uint64_t seed, uint64_t step, sgmcmc_stream_t stream)
+{
+    if (n == 0) return 0;
+    if (!out) return fail(SGMCMC_EINVAL, "philox_normal: out is NULL");
+    NormalFillOp<float> op{out, make_key(seed, step)};
+    return launch(op, n, aligned16(out), static_cast<hipStream_t>(stream));
+}
+int sgmcmc_philox_normal_f64(double *out, size_t n, uint64_t seed, uint64_t step, sgmcmc_stream_t stream)
+{
+    if (n == 0) return 0;
+    if (!out) return fail(SGMCMC_EINVAL, "philox_normal: out is NULL");
+    NormalFillOp<double> op{out, make_key(seed, step)};
+    return launch(op, n, aligned16(out), static_cast<hipStream_t>(stream));
+}
+int sgmcmc_philox_bits_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t step, sgmcmc_stream_t stream)
+{
+    if (n == 0) return 0;
+    if (!out) return fail(SGMCMC_EINVAL, "philox_bits: out is NULL");
+    hipLaunchKernelGGL(philox_bits_kernel, dim3(small_grid((n + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       out, n, make_key(seed, step));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch philox_bits");
+}
+
+int sgmcmc_moments_update_f32(const float *theta, float *mean, float *m2, size_t n, uint64_t count, sgmcmc_stream_t stream)
+{
+    if (n == 0) return 0;
+    if (!theta || !mean || !m2 || count == 0) return fail(SGMCMC_EINVAL, "moments_update: NULL argument or count == 0");
+    MomentsOp<float> op{theta, mean, m2, 1.0f / (float)count};
+    return launch(op, n, aligned16(theta) && aligned16(mean) && aligned16(m2), static_cast<hipStream_t>(stream));
+}
+int sgmcmc_moments_update_f64(const double *theta, double *mean, double *m2, size_t n, uint64_t count, sgmcmc_stream_t stream)
+{
+    if (n == 0) return 0;
+    if (!theta || !mean || !m2 || count == 0) return fail(SGMCMC_EINVAL, "moments_update: NULL argument or count == 0");
+    MomentsOp<double> op{theta, mean, m2, 1.0 / (double)count};
+    return launch(op, n, aligned16(theta) && aligned16(mean) && aligned16(m2), static_cast<hipStream_t>(stream));
+}
+
+int sgmcmc_rhat_pack_f32(const float *mean, const float *m2, size_t n, uint64_t count, float *out3, sgmcmc_stream_t stream)
+{
+    if (n == 0) return 0;
+    if (!mean || !m2 || !out3 || count < 2) return fail(SGMCMC_EINVAL, "rhat_pack: NULL argument or count < 2");
+    hipLaunchKernelGGL(rhat_pack_kernel, dim3(small_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), mean, m2, n,
+                       1.0f / (float)(count - 1), out3);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch rhat_pack");
+}
+int sgmcmc_rhat_finish_f32(const float *sum3, size_t n, int m_chains, uint64_t count, float *rhat, sgmcmc_stream_t stream)
+{
+    if (n == 0) return 0;
+    if (!sum3 || !rhat || m_chains < 2 || count < 2) return fail(SGMCMC_EINVAL, "rhat_finish: NULL argument, m_chains < 2 or count < 2");
+    hipLaunchKernelGGL(rhat_finish_kernel, dim3(small_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), sum3, n,
+                       (float)m_chains, (float)count, rhat);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch rhat_finish");
+}
+
+size_t sgmcmc_summary_workspace_bytes(void) { return sizeof(Summary) * SUMMARY_BLOCKS; }
+int sgmcmc_summary_f32(const float *x, size_t n, double *out4, void *workspace, sgmcmc_stream_t stream)
+{
+    return summary<float>(x, n, out4, workspace, static_cast<hipStream_t>(stream));
+}
+int sgmcmc_summary_f64(const double *x, size_t n, double *out4, void *workspace, sgmcmc_stream_t stream)
+{
+    return summary<double>(x, n, out4, workspace, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+"""Thin torch-tensor front end of the C ABI (``include/sgmcmc_hip.h``).
+
+Every function takes flat, contiguous device tensors, passes their raw
+pointers to ``libsgmcmc_hip.so`` and launches on torch's *current* HIP stream
+(so ``torch.cuda.Event`` timing, stream ordering with the autograd kernels and
+``torch.cuda.graph`` capture all see the launch). PyTorch is plumbing here:
+device memory and streams only.
+
+No CPU path exists: a CPU tensor raises ``SgmcmcLibraryError``.
+"""
+import torch
+
+from pysgmcmc_amd._lib import SgmcmcLibraryError, check, lib
+
+__all__ = [
+    "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
+    "moments_update", "rhat_pack", "rhat_finish", "summary",
+    "set_launch_config", "get_launch_config",
+]
+
+_SFX = {torch.float32: "f32", torch.float64: "f64"}
+
+
+def _sfx(t):
+    try:
+        return _SFX[t.dtype]
+    except KeyError:
+        raise TypeError("pysgmcmc_amd kernels support float32/float64, got %s" % t.dtype)
+
+
+def _ptr(t, like=None):
+    """Raw device pointer of a flat contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SgmcmcLibraryError(
+            "pysgmcmc_amd: tensor lives on %s; the SG-MCMC update path runs only as HIP kernels on an "
+            "AMD GPU (no CPU fallback)." % t.device)
+    if not t.is_contiguous():
+        raise ValueError("pysgmcmc_amd: kernel arguments must be contiguous")
+    if like is not None:
+        if t.dtype != like.dtype:
+            raise TypeError("pysgmcmc_amd: dtype mismatch %s vs %s" % (t.dtype, like.dtype))
+        if t.numel() != like.numel():
+            raise ValueError("pysgmcmc_amd: length mismatch %d vs %d" % (t.numel(), like.numel()))
+        if t.device != like.device:
+            raise ValueError("pysgmcmc_amd: device mismatch %s vs %s" % (t.device, like.device))
+    return t.data_ptr()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def set_launch_config(block_threads=0, quads_per_thread=0, max_blocks=0, nontemporal=-1):
+    check(lib().sgmcmc_set_launch_config(block_threads, quads_per_thread, max_blocks, nontemporal),
+          "sgmcmc_set_launch_config")
+
+
+def get_launch_config():
+    import ctypes
+    a, b, c, d = (ctypes.c_int() for _ in range(4))
+    check(lib().sgmcmc_get_launch_config(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)),
+          "sgmcmc_get_launch_config")
+    return {"block_threads": a.value, "quads_per_thread": b.value, "max_blocks": c.value, "nontemporal": d.value}
+
+
+def sghmc_step(theta, V, grad, tau, g, v_hat, minv, r, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step=0):
+    """K1, one fused SGHMC step in place (pysgmcmc/samplers/sghmc.py:165-251)."""
+    f = getattr(lib(), "sgmcmc_sghmc_step_" + _sfx(theta))
+    with torch.cuda.device(theta.device):
+        rc = f(_ptr(theta), _ptr(V, theta), _ptr(grad, theta), _ptr(tau, theta), _ptr(g, theta),
+               _ptr(v_hat, theta), _ptr(minv, theta), _ptr(r, theta), theta.numel(),
+               float(eps), float(scale_grad), float(mdecay), int(bool(adapt)), _ptr(xi, theta),
+               int(seed), int(step), _stream(theta))
+    check(rc, "sgmcmc_sghmc_step")
+
+
+def sgld_step(theta, grad, tau, g, v_hat, minv, r, eps, A, scale_grad, adapt, xi=None, seed=0, step=0):
+    """K2, one fused SGLD step in place (pysgmcmc/samplers/sgld.py:149-211)."""
+    f = getattr(lib(), "sgmcmc_sgld_step_" + _sfx(theta))
+    with torch.cuda.device(theta.device):
+        rc = f(_ptr(theta), _ptr(grad, theta), _ptr(tau, theta), _ptr(g, theta), _ptr(v_hat, theta),
+               _ptr(minv, theta), _ptr(r, theta), theta.numel(), float(eps), float(A), float(scale_grad),
+               int(bool(adapt)), _ptr(xi, theta), int(seed), int(step), _stream(theta))
+    check(rc, "sgmcmc_sgld_step")
+
+
+def rsghmc_step(theta, p, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, step=0):
+    """K3, one fused relativistic SGHMC step (pysgmcmc/samplers/relativistic_sghmc.py:120-140)."""
+    f = getattr(lib(), "sgmcmc_rsghmc_step_" + _sfx(theta))
+    with torch.cuda.device(theta.device):
+        rc = f(_ptr(theta), _ptr(p, theta), _ptr(grad_cost, theta), theta.numel(), float(eps), float(mass),
+               float(c), float(D), float(b_hat), _ptr(xi, theta), int(seed), int(step), _stream(theta))
+    check(rc, "sgmcmc_rsghmc_step")
+
+
+def philox_normal(out, seed, step):
+    """K5, out[i] = xi(seed, step, i)."""
+    f = getattr(lib(), "sgmcmc_philox_normal_" + _sfx(out))
+    with torch.cuda.device(out.device):
+        rc = f(_ptr(out), out.numel(), int(seed), int(step), _stream(out))
+    check(rc, "sgmcmc_philox_normal")
+    return out
+
+
+def philox_bits(out, seed, step):
+    if out.dtype not in (torch.int32, torch.uint32):
+        raise TypeError("philox_bits wants a 32-bit integer tensor")
+    with torch.cuda.device(out.device):
+        rc = lib().sgmcmc_philox_bits_u32(_ptr(out), out.numel(), int(seed), int(step), _stream(out))
+    check(rc, "sgmcmc_philox_bits_u32")
+    return out
+
+
+def moments_update(theta, mean, m2, count):
+    """K4, Welford update of (mean, m2) with the sample theta; count includes it."""
+    f = getattr(lib(), "sgmcmc_moments_update_" + _sfx(theta))
+    with torch.cuda.device(theta.device):
+        rc = f(_ptr(theta), _ptr(mean, theta), _ptr(m2, theta), theta.numel(), int(count), _stream(theta))
+    check(rc, "sgmcmc_moments_update")
+
+
+def rhat_pack(mean, m2, count, out3):
+    if mean.dtype != torch.float32:
+        raise TypeError("rhat_pack is float32-only")
+    if out3.numel() != 3 * mean.numel():
+        raise ValueError("out3 must hold 3*n elements")
+    with torch.cuda.device(mean.device):
+        rc = lib().sgmcmc_rhat_pack_f32(_ptr(mean), _ptr(m2, mean), mean.numel(), int(count), _ptr(out3),
+                                        _stream(mean))
+    check(rc, "sgmcmc_rhat_pack_f32")
+
+
+def rhat_finish(sum3, n, m_chains, count, rhat):
+    with torch.cuda.device(sum3.device):
+        rc = lib().sgmcmc_rhat_finish_f32(_ptr(sum3), int(n), int(m_chains), int(count), _ptr(rhat), _stream(sum3))
+    check(rc, "sgmcmc_rhat_finish_f32")
+
+
+def summary(x, out4=None, workspace=None):
+    """K6, deterministic {sum, sum of squares, min, max} of a flat array -> float64[4] device tensor."""
+    f = getattr(lib(), "sgmcmc_summary_" + _sfx(x))
+    if out4 is None:
+        out4 = torch.empty(4, dtype=torch.float64, device=x.device)
+    if workspace is None:
+        workspace = torch.empty(lib().sgmcmc_summary_workspace_bytes(), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = f(_ptr(x), x.numel(), _ptr(out4), _ptr(workspace), _stream(x))
+    check(rc, "sgmcmc_summary")
+    return out4

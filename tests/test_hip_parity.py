@@ -1,0 +1,296 @@
+"""GPU parity: the HIP kernels (through the C ABI) against the CPU oracle.
+
+Bar (DESIGN.md "Parity"):
+  * injected noise (xi given): BIT-EXACT in f32 and f64 -- every array, every step;
+  * Philox words: bit-exact integers;
+  * Philox normals: f32 |gpu - oracle| <= 4e-6 * max(1, |z|) except where u is within
+    2^-20 of 1 (|z| < 2e-3, hardware log2 is absolute- not relative-accurate there),
+    where the bound is 1e-4; f64 <= 1e-12;
+  * in-register noise step == injected step fed with the K5 stream (bit-exact).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [(np.float32, torch.float32), (np.float64, torch.float64)]
+# ragged sizes: < 1 quad, not a multiple of 4, not a multiple of the block, > 1 grid pass
+SIZES = [1, 3, 4, 5, 1023, 5252, 70001]
+
+
+def _dev(a, gpu):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+
+
+class GpuState(object):
+    def __init__(self, cst, gpu):
+        for name in ("theta", "V", "tau", "g", "v_hat", "minv", "r", "p"):
+            setattr(self, name, _dev(getattr(cst, name), gpu))
+
+
+def _assert_same(dev_t, host_a, what):
+    got = dev_t.cpu().numpy()
+    if not np.array_equal(got.view(np.uint32 if got.dtype == np.float32 else np.uint64),
+                          host_a.view(np.uint32 if host_a.dtype == np.float32 else np.uint64)):
+        idx = np.flatnonzero(got != host_a)
+        raise AssertionError("%s: %d/%d elements differ, first idx %d gpu=%r oracle=%r" % (
+            what, idx.size, got.size, idx[0] if idx.size else -1,
+            got[idx[0]] if idx.size else None, host_a[idx[0]] if idx.size else None))
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("npdt,thdt", DTYPES)
+def test_sghmc_injected_bit_exact(gpu, oracle, n, npdt, thdt):
+    from pysgmcmc_amd import kernels
+    rng = np.random.default_rng(1234 + n)
+    cst = oracle.CState(rng.normal(size=n), npdt)
+    gst = GpuState(cst, gpu)
+    burn = 7
+    for t in range(15):
+        grad = (rng.normal(size=n) * 3).astype(npdt)
+        if t == 3:
+            grad[:] = 0          # zero-gradient step
+        xi = rng.normal(size=n).astype(npdt)
+        adapt = t < burn
+        oracle.c_sghmc_step(cst, grad, 0.01, 100.0, 0.05, adapt, xi)
+        kernels.sghmc_step(gst.theta, gst.V, _dev(grad, gpu), gst.tau, gst.g, gst.v_hat, gst.minv, gst.r,
+                           0.01, 100.0, 0.05, adapt, xi=_dev(xi, gpu))
+        for name in ("theta", "V", "tau", "g", "v_hat", "minv", "r"):
+            _assert_same(getattr(gst, name), getattr(cst, name), "sghmc step %d %s" % (t, name))
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("npdt,thdt", DTYPES)
+def test_sgld_injected_bit_exact(gpu, oracle, n, npdt, thdt):
+    from pysgmcmc_amd import kernels
+    rng = np.random.default_rng(99 + n)
+    cst = oracle.CState(rng.normal(size=n), npdt)
+    gst = GpuState(cst, gpu)
+    for t in range(15):
+        grad = (rng.normal(size=n) * 3).astype(npdt)
+        xi = rng.normal(size=n).astype(npdt)
+        adapt = t < 7
+        oracle.c_sgld_step(cst, grad, 0.01, 1.0, 100.0, adapt, xi)
+        kernels.sgld_step(gst.theta, _dev(grad, gpu), gst.tau, gst.g, gst.v_hat, gst.minv, gst.r,
+                          0.01, 1.0, 100.0, adapt, xi=_dev(xi, gpu))
+        for name in ("theta", "tau", "g", "v_hat", "minv", "r"):
+            _assert_same(getattr(gst, name), getattr(cst, name), "sgld step %d %s" % (t, name))
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("npdt,thdt", DTYPES)
+def test_rsghmc_injected_bit_exact(gpu, oracle, n, npdt, thdt):
+    from pysgmcmc_amd import kernels
+    rng = np.random.default_rng(7 + n)
+    cst = oracle.CState(rng.normal(size=n), npdt)
+    cst.p[:] = rng.normal(size=n).astype(npdt)
+    gst = GpuState(cst, gpu)
+    for t in range(15):
+        grad = (rng.normal(size=n) * 3).astype(npdt)
+        xi = rng.normal(size=n).astype(npdt)
+        oracle.c_rsghmc_step(cst, grad, 0.001, 1.0, 1.0, 1.0, 0.0, xi)
+        kernels.rsghmc_step(gst.theta, gst.p, _dev(grad, gpu), 0.001, 1.0, 1.0, 1.0, 0.0, xi=_dev(xi, gpu))
+        for name in ("theta", "p"):
+            _assert_same(getattr(gst, name), getattr(cst, name), "rsghmc step %d %s" % (t, name))
+
+
+def test_edge_cases_bit_exact(gpu, oracle):
+    """v_hat -> 0 (safe_divide / safe_sqrt guards), negative v_hat, sigma clamp
+    (eps_s^4 > 2 eps_s^2 mdecay minv), huge gradients."""
+    from pysgmcmc_amd import kernels
+    n = 64
+    for npdt in (np.float32, np.float64):
+        cst = oracle.CState(np.linspace(-1, 1, n), npdt)
+        cst.v_hat[:16] = 0.0
+        cst.v_hat[16:24] = -1e-16
+        cst.v_hat[24:32] = 1e-30
+        cst.g[8:20] = 0.0
+        gst = GpuState(cst, gpu)
+        rng = np.random.default_rng(5)
+        for t, (eps, sg, md) in enumerate([(0.01, 1.0, 0.05), (2.0, 1.0, 1e-6), (0.1, 1e6, 0.05), (0.01, 1.0, 0.05)]):
+            grad = rng.normal(size=n).astype(npdt)
+            if t == 2:
+                grad *= npdt(1e18)
+            xi = rng.normal(size=n).astype(npdt)
+            adapt = t < 3
+            with np.errstate(all="ignore"):
+                oracle.c_sghmc_step(cst, grad, eps, sg, md, adapt, xi)
+            kernels.sghmc_step(gst.theta, gst.V, _dev(grad, gpu), gst.tau, gst.g, gst.v_hat, gst.minv, gst.r,
+                               eps, sg, md, adapt, xi=_dev(xi, gpu))
+            for name in ("theta", "V", "tau", "g", "v_hat", "minv"):
+                got = getattr(gst, name).cpu().numpy()
+                want = getattr(cst, name)
+                assert np.array_equal(got, want, equal_nan=True), (npdt, t, name)
+        assert np.isfinite(cst.minv).all()
+
+
+def test_misaligned_and_empty(gpu, oracle):
+    """Arrays that are not 16-B aligned take the element-wise path: same results. n = 0 is a no-op."""
+    from pysgmcmc_amd import kernels
+    n = 4099
+    rng = np.random.default_rng(3)
+    cst = oracle.CState(rng.normal(size=n), np.float32)
+    big = {k: torch.zeros(n + 1, dtype=torch.float32, device=gpu) for k in
+           ("theta", "V", "tau", "g", "v_hat", "minv", "grad", "xi")}
+    views = {k: v[1:] for k, v in big.items()}      # 4-byte offset -> misaligned
+    for k in ("theta", "V", "tau", "g", "v_hat", "minv"):
+        views[k].copy_(_dev(getattr(cst, k), gpu))
+    for t in range(4):
+        grad = rng.normal(size=n).astype(np.float32)
+        xi = rng.normal(size=n).astype(np.float32)
+        views["grad"].copy_(_dev(grad, gpu))
+        views["xi"].copy_(_dev(xi, gpu))
+        adapt = t < 2
+        oracle.c_sghmc_step(cst, grad, 0.01, 10.0, 0.05, adapt, xi)
+        kernels.sghmc_step(views["theta"], views["V"], views["grad"], views["tau"], views["g"], views["v_hat"],
+                           views["minv"], None, 0.01, 10.0, 0.05, adapt, xi=views["xi"])
+        for name in ("theta", "V", "tau", "g", "v_hat", "minv"):
+            _assert_same(views[name], getattr(cst, name), "misaligned step %d %s" % (t, name))
+    e = torch.empty(0, dtype=torch.float32, device=gpu)
+    kernels.sghmc_step(e, e, e, e, e, e, e, None, 0.01, 1.0, 0.05, True)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("seed,step", [(0, 0), (1, 0), (87654321, 12345), (2 ** 63 + 5, 2 ** 40 + 3)])
+def test_philox_bits_exact(gpu, oracle, seed, step):
+    from pysgmcmc_amd import kernels
+    n = 100003
+    out = torch.empty(n, dtype=torch.int32, device=gpu)
+    kernels.philox_bits(out, seed, step)
+    got = out.cpu().numpy().view(np.uint32)
+    want = oracle.c_philox_bits(seed, step, n)
+    assert np.array_equal(got, want)
+
+
+def test_philox_normal_f32_tolerance(gpu, oracle):
+    from pysgmcmc_amd import kernels
+    n = 1 << 22
+    out = torch.empty(n, dtype=torch.float32, device=gpu)
+    kernels.philox_normal(out, 42, 7)
+    got = out.cpu().numpy().astype(np.float64)
+    want = oracle.c_philox_normal(42, 7, n, np.float32).astype(np.float64)
+    err = np.abs(got - want)
+    bits = oracle.c_philox_bits(42, 7, n).reshape(-1, 2)
+    u_word = np.repeat(bits[:, 0], 2)               # the word that feeds log() for each pair
+    near_one = u_word > np.uint32(0xFFFFF000)       # u within 2^-20 of 1
+    scale = np.maximum(1.0, np.abs(want))
+    assert (err[~near_one] <= 4e-6 * scale[~near_one]).all(), err[~near_one].max()
+    assert (err[near_one] <= 1e-4).all()
+    # the stream is a standard normal: moments over 4M draws
+    assert abs(got.mean()) < 4 / np.sqrt(n)
+    assert abs(got.var() - 1.0) < 6 * np.sqrt(2.0 / n)
+    assert abs((got ** 4).mean() - 3.0) < 0.03
+
+
+def test_philox_normal_f64_tolerance(gpu, oracle):
+    from pysgmcmc_amd import kernels
+    n = 100001
+    out = torch.empty(n, dtype=torch.float64, device=gpu)
+    kernels.philox_normal(out, 9, 1)
+    want = oracle.c_philox_normal(9, 1, n, np.float64)
+    assert np.abs(out.cpu().numpy() - want).max() <= 1e-12
+
+
+@pytest.mark.parametrize("npdt,thdt", DTYPES)
+def test_register_noise_equals_injected_stream(gpu, oracle, npdt, thdt):
+    """xi == NULL path: the in-register Philox draw equals feeding the K5 stream as xi (bit-exact),
+    for the vector path, the ragged tail and every launch geometry."""
+    from pysgmcmc_amd import kernels
+    n = 70003
+    rng = np.random.default_rng(11)
+    th0 = rng.normal(size=n).astype(npdt)
+    grad = _dev(rng.normal(size=n).astype(npdt), gpu)
+    results = []
+    try:
+        for qpt, blocks, nt in [(1, 2048, 0), (2, 64, 0), (4, 2048, 1), (2, 7, 1)]:
+            kernels.set_launch_config(256, qpt, blocks, nt)
+            a = GpuState(oracle.CState(th0, npdt), gpu)
+            b = GpuState(oracle.CState(th0, npdt), gpu)
+            for t in range(3):
+                xi = torch.empty(n, dtype=thdt, device=gpu)
+                kernels.philox_normal(xi, 2024, t)
+                kernels.sghmc_step(a.theta, a.V, grad, a.tau, a.g, a.v_hat, a.minv, None, 0.01, 50.0, 0.05, t < 2,
+                                   xi=None, seed=2024, step=t)
+                kernels.sghmc_step(b.theta, b.V, grad, b.tau, b.g, b.v_hat, b.minv, None, 0.01, 50.0, 0.05, t < 2,
+                                   xi=xi)
+                assert torch.equal(a.theta, b.theta) and torch.equal(a.V, b.V)
+            results.append(a.theta.clone())
+    finally:
+        kernels.set_launch_config(256, 2, 2048, 0)
+    for r in results[1:]:
+        assert torch.equal(results[0], r)     # geometry never changes the samples
+
+
+def test_moments_and_summary(gpu, oracle):
+    from pysgmcmc_amd import kernels
+    n = 50001
+    rng = np.random.default_rng(0)
+    mean_h = np.zeros(n, np.float32)
+    m2_h = np.zeros(n, np.float32)
+    mean_d, m2_d = _dev(mean_h, gpu), _dev(m2_h, gpu)
+    for c in range(1, 6):
+        x = rng.normal(size=n).astype(np.float32)
+        oracle.c_moments_update(x, mean_h, m2_h, c)
+        kernels.moments_update(_dev(x, gpu), mean_d, m2_d, c)
+    _assert_same(mean_d, mean_h, "welford mean")
+    _assert_same(m2_d, m2_h, "welford m2")
+    x = rng.normal(size=n).astype(np.float32)
+    s = kernels.summary(_dev(x, gpu)).cpu().numpy()
+    x64 = x.astype(np.float64)
+    assert np.isclose(s[0], x64.sum(), rtol=1e-12, atol=1e-9)
+    assert np.isclose(s[1], (x64 * x64).sum(), rtol=1e-12)
+    assert s[2] == x64.min() and s[3] == x64.max()
+    s2 = kernels.summary(_dev(x, gpu)).cpu().numpy()
+    assert np.array_equal(s, s2)              # deterministic
+
+
+def test_rhat_pack_finish(gpu, oracle):
+    from pysgmcmc_amd import kernels
+    m, cnt, n = 4, 200, 1000
+    rng = np.random.default_rng(1)
+    chains = rng.normal(size=(m, cnt, n)).astype(np.float32) + rng.normal(size=(m, 1, n)).astype(np.float32) * 0.1
+    total = torch.zeros(3 * n, dtype=torch.float32, device=gpu)
+    for c in range(m):
+        mean = torch.zeros(n, dtype=torch.float32, device=gpu)
+        m2 = torch.zeros(n, dtype=torch.float32, device=gpu)
+        for t in range(cnt):
+            kernels.moments_update(_dev(chains[c, t], gpu), mean, m2, t + 1)
+        out3 = torch.empty(3 * n, dtype=torch.float32, device=gpu)
+        kernels.rhat_pack(mean, m2, cnt, out3)
+        total += out3                           # stands in for the RCCL all-reduce(SUM)
+    rhat = torch.empty(n, dtype=torch.float32, device=gpu)
+    kernels.rhat_finish(total, n, m, cnt, rhat)
+    want = oracle.gelman_rubin(chains)
+    assert np.allclose(rhat.cpu().numpy(), want, rtol=2e-4, atol=1e-5)
+
+
+def test_full_size_properties(gpu):
+    """10 M parameters (BASELINE.json configs[2]): size-independent properties.
+    (a) determinism: same (seed, step) -> identical arrays; (b) different step -> different noise;
+    (c) linearity in the noise-free limit: with sigma clamped to 1e-8 and V0 = 0 one frozen step
+        gives V' ~= -eps^2 * minv * grad; (d) sample moments of the injected noise."""
+    from pysgmcmc_amd import kernels
+    n = 10_002_434
+    g = torch.Generator(device=gpu).manual_seed(0)
+    theta0 = torch.randn(n, device=gpu, generator=g)
+    grad = torch.randn(n, device=gpu, generator=g) * 0.1
+    minv = torch.rand(n, device=gpu, generator=g) * 1.5 + 0.5
+
+    def run(seed, step):
+        th, V = theta0.clone(), torch.zeros_like(theta0)
+        kernels.sghmc_step(th, V, grad, None, None, None, minv, None, 0.01, 1e5, 0.05, False, seed=seed, step=step)
+        return th, V
+    th1, V1 = run(5, 9)
+    th2, V2 = run(5, 9)
+    assert torch.equal(th1, th2) and torch.equal(V1, V2)
+    th3, V3 = run(5, 10)
+    assert not torch.equal(V1, V3)
+    assert torch.equal(th1, theta0 + V1)
+    eps = 0.01
+    eps_s = eps / np.sqrt(1e5)
+    sigma = torch.sqrt(torch.clamp(2 * eps_s ** 2 * 0.05 * minv - eps_s ** 4, min=1e-16))
+    z = (V1 + eps ** 2 * minv * grad) / sigma
+    assert abs(z.mean().item()) < 5 / np.sqrt(n)
+    assert abs(z.var().item() - 1.0) < 0.01
+    assert z.abs().max().item() < 7.0
