@@ -56,9 +56,9 @@ const char *sgmcmc_last_error(void);
 int sgmcmc_device_count(void);
 
 /* Launch geometry knobs (performance only; results never depend on them).
- *   block_threads: 64..1024, multiple of 64 (default 256)
- *   quads_per_thread: 1, 2 or 4 float4 groups in flight per lane (default 2)
- *   max_blocks: grid cap, the kernel grid-strides beyond it (default 256 CUs * 8)
+ *   block_threads: 64, 128, 192 or 256 (default 256)
+ *   quads_per_thread: 1, 2 or 4 float4 groups in flight per lane (default 1)
+ *   max_blocks: grid cap, the kernel grid-strides beyond it (default 2^20 = uncapped)
  *   nontemporal: 0/1 use nt loads+stores for streamed arrays (default 0)
  * Pass 0 (or -1 for nontemporal) to keep the current value. */
 int sgmcmc_set_launch_config(int block_threads, int quads_per_thread, int max_blocks, int nontemporal);
@@ -73,15 +73,20 @@ int sgmcmc_get_launch_config(int *block_threads, int *quads_per_thread, int *max
  *   eps, scale_grad, mdecay: the constructor/schedule scalars; eps_scaled and the
  *              noise-scale constants are derived inside, in the dtype.
  *   xi:   NULL -> Philox(seed, step); else injected N(0,1) draws, n elements.
- *   step: the sampler's n_iterations at the time of the call.                      */
+ *   step: the sampler's n_iterations at the time of the call.
+ *   step_dev: NULL, or a DEVICE counter added to `step` when the kernel starts.
+ *              A hipGraph replays identical arguments; a graph-captured chain
+ *              advances its noise stream with sgmcmc_counter_add_u64 on it.        */
 int sgmcmc_sghmc_step_f32(float *theta, float *V, const float *grad,
                           float *tau, float *g, float *v_hat, float *minv, float *r,
                           size_t n, float eps, float scale_grad, float mdecay, int adapt,
-                          const float *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+                          const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+        sgmcmc_stream_t stream);
 int sgmcmc_sghmc_step_f64(double *theta, double *V, const double *grad,
                           double *tau, double *g, double *v_hat, double *minv, double *r,
                           size_t n, double eps, double scale_grad, double mdecay, int adapt,
-                          const double *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+                          const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+        sgmcmc_stream_t stream);
 
 /* K2 -- fused preconditioned SGLD step. Replaces pysgmcmc/samplers/sgld.py:149-211.
  *   adapt = 1: R{theta,grad,tau,g,v_hat} W{theta,tau,g,v_hat,minv}   40 B/param f32
@@ -89,11 +94,13 @@ int sgmcmc_sghmc_step_f64(double *theta, double *V, const double *grad,
 int sgmcmc_sgld_step_f32(float *theta, const float *grad,
                          float *tau, float *g, float *v_hat, float *minv, float *r,
                          size_t n, float eps, float A, float scale_grad, int adapt,
-                         const float *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+                         const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+        sgmcmc_stream_t stream);
 int sgmcmc_sgld_step_f64(double *theta, const double *grad,
                          double *tau, double *g, double *v_hat, double *minv, double *r,
                          size_t n, double eps, double A, double scale_grad, int adapt,
-                         const double *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+                         const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+        sgmcmc_stream_t stream);
 
 /* K3 -- fused relativistic SGHMC step, per element. Replaces
  * pysgmcmc/samplers/relativistic_sghmc.py:120-140. grad_cost = d cost / d theta
@@ -101,18 +108,26 @@ int sgmcmc_sgld_step_f64(double *theta, const double *grad,
  * R{theta,p,grad} W{theta,p}                                         20 B/param f32 */
 int sgmcmc_rsghmc_step_f32(float *theta, float *p, const float *grad_cost, size_t n,
                            float eps, float mass, float c, float D, float b_hat,
-                           const float *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+                           const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+        sgmcmc_stream_t stream);
 int sgmcmc_rsghmc_step_f64(double *theta, double *p, const double *grad_cost, size_t n,
                            double eps, double mass, double c, double D, double b_hat,
-                           const double *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+                           const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+        sgmcmc_stream_t stream);
 
 /* K5 -- write the N(0,1) stream itself: out[i] = xi(seed, step, i). Replaces
  * tf.random_normal in pysgmcmc/samplers/base_classes.py:218-220 for callers that
  * want the draws materialised (tests, relativistic momentum initialisation).      */
-int sgmcmc_philox_normal_f32(float *out, size_t n, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
-int sgmcmc_philox_normal_f64(double *out, size_t n, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+int sgmcmc_philox_normal_f32(float *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+        sgmcmc_stream_t stream);
+int sgmcmc_philox_normal_f64(double *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+        sgmcmc_stream_t stream);
 /* raw Philox words: out[i] = x[i & 3] of quad i >> 2 (bit-exact integer check)     */
-int sgmcmc_philox_bits_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t step, sgmcmc_stream_t stream);
+int sgmcmc_philox_bits_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+        sgmcmc_stream_t stream);
+
+/* *counter += inc on the stream (1-thread kernel; the graph-safe step counter).     */
+int sgmcmc_counter_add_u64(uint64_t *counter, uint64_t inc, sgmcmc_stream_t stream);
 
 /* K4 -- Welford running moments of one chain, for cross-chain R-hat. Replaces the
  * per-chain mean/variance pass that pysgmcmc/diagnostics/sampler_diagnostics.py:118-194

@@ -52,16 +52,16 @@ def _declare(lib):
     lib.sgmcmc_get_launch_config.restype = _ci
     for sfx, real in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
         f = getattr(lib, "sgmcmc_sghmc_step_" + sfx)
-        f.argtypes = [_vp] * 8 + [_sz, real, real, real, _ci, _vp, _u64, _u64, _vp]
+        f.argtypes = [_vp] * 8 + [_sz, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_sgld_step_" + sfx)
-        f.argtypes = [_vp] * 7 + [_sz, real, real, real, _ci, _vp, _u64, _u64, _vp]
+        f.argtypes = [_vp] * 7 + [_sz, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_rsghmc_step_" + sfx)
-        f.argtypes = [_vp] * 3 + [_sz, real, real, real, real, real, _vp, _u64, _u64, _vp]
+        f.argtypes = [_vp] * 3 + [_sz, real, real, real, real, real, _vp, _u64, _u64, _vp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_philox_normal_" + sfx)
-        f.argtypes = [_vp, _sz, _u64, _u64, _vp]
+        f.argtypes = [_vp, _sz, _u64, _u64, _vp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_moments_update_" + sfx)
         f.argtypes = [_vp, _vp, _vp, _sz, _u64, _vp]
@@ -69,7 +69,9 @@ def _declare(lib):
         f = getattr(lib, "sgmcmc_summary_" + sfx)
         f.argtypes = [_vp, _sz, _vp, _vp, _vp]
         f.restype = _ci
-    lib.sgmcmc_philox_bits_u32.argtypes = [_vp, _sz, _u64, _u64, _vp]
+    lib.sgmcmc_philox_bits_u32.argtypes = [_vp, _sz, _u64, _u64, _vp, _vp]
+    lib.sgmcmc_counter_add_u64.argtypes = [_vp, _u64, _vp]
+    lib.sgmcmc_counter_add_u64.restype = _ci
     lib.sgmcmc_philox_bits_u32.restype = _ci
     lib.sgmcmc_rhat_pack_f32.argtypes = [_vp, _vp, _sz, _u64, _vp, _vp]
     lib.sgmcmc_rhat_pack_f32.restype = _ci

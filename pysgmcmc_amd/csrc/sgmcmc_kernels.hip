@@ -11,8 +11,11 @@
 //     the streamed arrays. Work unit = one "quad" of 4 consecutive elements per
 //     lane: 16 B per lane per array (global_load/store_dwordx4, 1 KiB per wave
 //     instruction), and exactly one Philox4x32-10 call per quad.
-//   * QPT quads per lane are loaded before any is consumed (more bytes in
-//     flight per wave); grid-stride loop, grid capped at a few blocks per CU.
+//   * Launch geometry is a knob (quads in flight per lane, grid cap, nt hints);
+//     measured best on MI355X at 10 M params (gpurun tune, round 1): ONE quad per
+//     lane, uncapped grid (~9.8 k blocks of 256), plain (not nt) accesses --
+//     occupancy, not per-lane ILP, is what keeps HBM busy here. Those are the
+//     defaults.
 //   * Noise lives in registers only: Philox counter = (step, quad), key = seed,
 //     Box-Muller on the hardware transcendental units (v_log_f32, v_sqrt_f32,
 //     v_sin_f32, v_cos_f32). 0 bytes of HBM traffic for xi.
@@ -93,7 +96,20 @@ __device__ __forceinline__ void store_part(T *__restrict__ p, size_t q, int cnt,
 // Philox4x32-10 (Salmon et al., SC'11) + Box-Muller, all in registers
 // --------------------------------------------------------------------------
 
-struct NoiseKey { uint32_t k0, k1, s0, s1; };   // key = seed, (s0,s1) = step
+// key = seed, (s0,s1) = step. step_dev (nullable) is a device-resident counter added to
+// the by-value step when the kernel starts: a hipGraph replays identical kernel
+// arguments, so graph-captured chains advance their noise stream through it.
+struct NoiseKey {
+    uint32_t k0, k1, s0, s1;
+    const uint64_t *step_dev;
+    __device__ __forceinline__ void resolve()
+    {
+        if (step_dev) {
+            uint64_t st = (((uint64_t)s1 << 32) | s0) + *step_dev;
+            s0 = (uint32_t)st; s1 = (uint32_t)(st >> 32);
+        }
+    }
+};
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&x)[4])
@@ -196,6 +212,7 @@ struct SghmcOp {
     T *theta, *V; const T *grad; T *tau, *g, *vh, *minv, *r; const T *xi;
     T e2, c1, c3, e4, mdecay;      // host-derived scalars, sghmc.py:111-117,211-217,235
     NoiseKey nk;
+    __device__ __forceinline__ void prepare() { nk.resolve(); }
     struct Regs { T th[4], v[4], gr[4], mi[4], tau[4], g[4], vh[4], rr[4], z[4]; };
 
     template <bool NT> __device__ __forceinline__ void load_vec(size_t q, Regs &R) const
@@ -256,6 +273,7 @@ struct SgldOp {
     T *theta; const T *grad; T *tau, *g, *vh, *minv, *r; const T *xi;
     T eps, A, a_eff, two_eps, sg_den;     // sgld.py:106-108,186-191,201-204
     NoiseKey nk;
+    __device__ __forceinline__ void prepare() { nk.resolve(); }
     struct Regs { T th[4], gr[4], mi[4], tau[4], g[4], vh[4], rr[4], z[4]; };
 
     template <bool NT> __device__ __forceinline__ void load_vec(size_t q, Regs &R) const
@@ -312,6 +330,7 @@ struct RsghmcOp {
     T *theta, *p; const T *grad; const T *xi;
     T eps, mass, D, m2c2, nscale;         // relativistic_sghmc.py:105-106,117-125
     NoiseKey nk;
+    __device__ __forceinline__ void prepare() { nk.resolve(); }
     struct Regs { T th[4], p[4], gr[4], z[4]; };
 
     template <bool NT> __device__ __forceinline__ void load_vec(size_t q, Regs &R) const
@@ -353,6 +372,7 @@ template <typename T>
 struct NormalFillOp {
     typedef T real;
     T *out; NoiseKey nk;
+    __device__ __forceinline__ void prepare() { nk.resolve(); }
     struct Regs { T z[4]; };
     template <bool NT> __device__ __forceinline__ void load_vec(size_t, Regs &) const {}
     __device__ __forceinline__ void load_part_(size_t, int, Regs &) const {}
@@ -365,6 +385,7 @@ template <typename T>
 struct MomentsOp {
     typedef T real;
     const T *theta; T *mean, *m2; T inv;
+    __device__ __forceinline__ void prepare() {}
     struct Regs { T x[4], mu[4], m2[4]; };
     template <bool NT> __device__ __forceinline__ void load_vec(size_t q, Regs &R) const
     { load_quad<NT>(theta, q, R.x); load_quad<NT>(mean, q, R.mu); load_quad<NT>(m2, q, R.m2); }
@@ -395,8 +416,10 @@ struct MomentsOp {
 //      QPT quads in flight per lane; the ragged tail (n % 4 elements) is done
 //      element-wise by one lane.
 template <typename Op, int QPT, bool NT>
-__global__ void __launch_bounds__(256) stream_quads_vec(const Op op, size_t nq_full, int tail_cnt)
+__global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t nq_full, int tail_cnt)
 {
+    Op op = op_in;
+    op.prepare();
     const size_t G = (size_t)gridDim.x * blockDim.x;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (size_t base = gid; base < nq_full; base += G * QPT) {
@@ -427,8 +450,10 @@ __global__ void __launch_bounds__(256) stream_quads_vec(const Op op, size_t nq_f
 
 // element-wise path for misaligned arrays: same quads, same results
 template <typename Op>
-__global__ void __launch_bounds__(256) stream_quads_scalar(const Op op, size_t n)
+__global__ void __launch_bounds__(256) stream_quads_scalar(const Op op_in, size_t n)
 {
+    Op op = op_in;
+    op.prepare();
     const size_t G = (size_t)gridDim.x * blockDim.x;
     const size_t nq = (n + 3) / 4;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += G) {
@@ -538,6 +563,7 @@ __global__ void __launch_bounds__(256) rhat_finish_kernel(const float *__restric
 }
 __global__ void __launch_bounds__(256) philox_bits_kernel(uint32_t *__restrict__ out, size_t n, NoiseKey nk)
 {
+    nk.resolve();
     const size_t G = (size_t)gridDim.x * blockDim.x;
     const size_t nq = (n + 3) / 4;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += G) {
@@ -568,19 +594,22 @@ int hip_fail(hipError_t e, const char *what)
 }
 
 std::atomic<int> g_block_threads{256};
-std::atomic<int> g_qpt{2};
-std::atomic<int> g_max_blocks{256 * 8};
+std::atomic<int> g_qpt{1};
+std::atomic<int> g_max_blocks{1 << 20};
 std::atomic<int> g_nt{0};
 
 inline bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-inline NoiseKey make_key(uint64_t seed, uint64_t step)
+inline NoiseKey make_key(uint64_t seed, uint64_t step, const uint64_t *step_dev)
 {
     NoiseKey nk;
     nk.k0 = (uint32_t)seed; nk.k1 = (uint32_t)(seed >> 32);
     nk.s0 = (uint32_t)step; nk.s1 = (uint32_t)(step >> 32);
+    nk.step_dev = step_dev;
     return nk;
 }
+
+__global__ void counter_add_kernel(uint64_t *ctr, uint64_t inc) { *ctr += inc; }
 
 template <typename Op, int QPT, bool NT>
 int launch_vec(const Op &op, size_t n, hipStream_t st)
@@ -634,7 +663,7 @@ int launch(const Op &op, size_t n, bool vec_ok, hipStream_t st)
 
 template <typename T>
 int sghmc_step(T *theta, T *V, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, size_t n,
-               T eps, T scale_grad, T mdecay, int adapt, const T *xi, uint64_t seed, uint64_t step, hipStream_t st)
+               T eps, T scale_grad, T mdecay, int adapt, const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev, hipStream_t st)
 {
     if (n == 0) return 0;
     if (!theta || !V || !grad || !minv) return fail(SGMCMC_EINVAL, "sghmc_step: theta, V, grad and minv must be non-NULL");
@@ -645,7 +674,7 @@ int sghmc_step(T *theta, T *V, const T *grad, T *tau, T *g, T *v_hat, T *minv, T
     T c1 = (T(2) * std::pow(eps_s, T(2))) * mdecay;
     T c3 = T(2) * std::pow(eps_s, T(3));
     T e4 = std::pow(eps_s, T(4));
-    NoiseKey nk = make_key(seed, step);
+    NoiseKey nk = make_key(seed, step, step_dev);
     bool vec_ok = aligned16(theta) && aligned16(V) && aligned16(grad) && aligned16(minv) && aligned16(xi) &&
                   (!adapt || (aligned16(tau) && aligned16(g) && aligned16(v_hat) && aligned16(r)));
 #define SGHMC_GO(AD, INJ)                                                                              \
@@ -660,7 +689,7 @@ int sghmc_step(T *theta, T *V, const T *grad, T *tau, T *g, T *v_hat, T *minv, T
 
 template <typename T>
 int sgld_step(T *theta, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, size_t n,
-              T eps, T A, T scale_grad, int adapt, const T *xi, uint64_t seed, uint64_t step, hipStream_t st)
+              T eps, T A, T scale_grad, int adapt, const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev, hipStream_t st)
 {
     if (n == 0) return 0;
     if (!theta || !grad || !minv) return fail(SGMCMC_EINVAL, "sgld_step: theta, grad and minv must be non-NULL");
@@ -669,7 +698,7 @@ int sgld_step(T *theta, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, si
     T sg_den = scale_grad + ((T(2) * sgn) * T(1e-16) + T(1e-16));
     T two_eps = T(2) * eps;
     T a_eff = A - T(0);
-    NoiseKey nk = make_key(seed, step);
+    NoiseKey nk = make_key(seed, step, step_dev);
     bool vec_ok = aligned16(theta) && aligned16(grad) && aligned16(minv) && aligned16(xi) &&
                   (!adapt || (aligned16(tau) && aligned16(g) && aligned16(v_hat) && aligned16(r)));
 #define SGLD_GO(AD, INJ)                                                                            \
@@ -684,13 +713,13 @@ int sgld_step(T *theta, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, si
 
 template <typename T>
 int rsghmc_step(T *theta, T *p, const T *grad, size_t n, T eps, T mass, T c, T D, T b_hat,
-                const T *xi, uint64_t seed, uint64_t step, hipStream_t st)
+                const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev, hipStream_t st)
 {
     if (n == 0) return 0;
     if (!theta || !p || !grad) return fail(SGMCMC_EINVAL, "rsghmc_step: theta, p and grad_cost must be non-NULL");
     T m2c2 = (mass * mass) * (c * c);
     T nscale = std::sqrt(eps * ((T(2) * D) - (eps * b_hat)));
-    NoiseKey nk = make_key(seed, step);
+    NoiseKey nk = make_key(seed, step, step_dev);
     bool vec_ok = aligned16(theta) && aligned16(p) && aligned16(grad) && aligned16(xi);
     if (xi) {
         RsghmcOp<T, false, true> op{theta, p, grad, xi, eps, mass, D, m2c2, nscale, nk};
@@ -769,66 +798,66 @@ int sgmcmc_get_launch_config(int *block_threads, int *quads_per_thread, int *max
 
 int sgmcmc_sghmc_step_f32(float *theta, float *V, const float *grad, float *tau, float *g, float *v_hat,
                           float *minv, float *r, size_t n, float eps, float scale_grad, float mdecay, int adapt,
-                          const float *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream)
+                          const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
 {
-    return sghmc_step<float>(theta, V, grad, tau, g, v_hat, minv, r, n, eps, scale_grad, mdecay, adapt, xi, seed, step,
+    return sghmc_step<float>(theta, V, grad, tau, g, v_hat, minv, r, n, eps, scale_grad, mdecay, adapt, xi, seed, step, step_dev,
                              static_cast<hipStream_t>(stream));
 }
 int sgmcmc_sghmc_step_f64(double *theta, double *V, const double *grad, double *tau, double *g, double *v_hat,
                           double *minv, double *r, size_t n, double eps, double scale_grad, double mdecay, int adapt,
-                          const double *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream)
+                          const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
 {
-    return sghmc_step<double>(theta, V, grad, tau, g, v_hat, minv, r, n, eps, scale_grad, mdecay, adapt, xi, seed, step,
+    return sghmc_step<double>(theta, V, grad, tau, g, v_hat, minv, r, n, eps, scale_grad, mdecay, adapt, xi, seed, step, step_dev,
                               static_cast<hipStream_t>(stream));
 }
 int sgmcmc_sgld_step_f32(float *theta, const float *grad, float *tau, float *g, float *v_hat, float *minv, float *r,
                          size_t n, float eps, float A, float scale_grad, int adapt, const float *xi, uint64_t seed,
-                         uint64_t step, sgmcmc_stream_t stream)
+                         uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
 {
-    return sgld_step<float>(theta, grad, tau, g, v_hat, minv, r, n, eps, A, scale_grad, adapt, xi, seed, step,
+    return sgld_step<float>(theta, grad, tau, g, v_hat, minv, r, n, eps, A, scale_grad, adapt, xi, seed, step, step_dev,
                             static_cast<hipStream_t>(stream));
 }
 int sgmcmc_sgld_step_f64(double *theta, const double *grad, double *tau, double *g, double *v_hat, double *minv,
                          double *r, size_t n, double eps, double A, double scale_grad, int adapt, const double *xi,
-                         uint64_t seed, uint64_t step, sgmcmc_stream_t stream)
+                         uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
 {
-    return sgld_step<double>(theta, grad, tau, g, v_hat, minv, r, n, eps, A, scale_grad, adapt, xi, seed, step,
+    return sgld_step<double>(theta, grad, tau, g, v_hat, minv, r, n, eps, A, scale_grad, adapt, xi, seed, step, step_dev,
                              static_cast<hipStream_t>(stream));
 }
 int sgmcmc_rsghmc_step_f32(float *theta, float *p, const float *grad_cost, size_t n, float eps, float mass, float c,
-                           float D, float b_hat, const float *xi, uint64_t seed, uint64_t step, sgmcmc_stream_t stream)
+                           float D, float b_hat, const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
 {
-    return rsghmc_step<float>(theta, p, grad_cost, n, eps, mass, c, D, b_hat, xi, seed, step,
+    return rsghmc_step<float>(theta, p, grad_cost, n, eps, mass, c, D, b_hat, xi, seed, step, step_dev,
                               static_cast<hipStream_t>(stream));
 }
 int sgmcmc_rsghmc_step_f64(double *theta, double *p, const double *grad_cost, size_t n, double eps, double mass,
                            double c, double D, double b_hat, const double *xi, uint64_t seed, uint64_t step,
-                           sgmcmc_stream_t stream)
+                           const uint64_t *step_dev, sgmcmc_stream_t stream)
 {
-    return rsghmc_step<double>(theta, p, grad_cost, n, eps, mass, c, D, b_hat, xi, seed, step,
+    return rsghmc_step<double>(theta, p, grad_cost, n, eps, mass, c, D, b_hat, xi, seed, step, step_dev,
                                static_cast<hipStream_t>(stream));
 }
 
-int sgmcmc_philox_normal_f32(float *out, size_t n, uint64_t seed, uint64_t step, sgmcmc_stream_t stream)
+int sgmcmc_philox_normal_f32(float *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
 {
     if (n == 0) return 0;
     if (!out) return fail(SGMCMC_EINVAL, "philox_normal: out is NULL");
-    NormalFillOp<float> op{out, make_key(seed, step)};
+    NormalFillOp<float> op{out, make_key(seed, step, step_dev)};
     return launch(op, n, aligned16(out), static_cast<hipStream_t>(stream));
 }
-int sgmcmc_philox_normal_f64(double *out, size_t n, uint64_t seed, uint64_t step, sgmcmc_stream_t stream)
+int sgmcmc_philox_normal_f64(double *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
 {
     if (n == 0) return 0;
     if (!out) return fail(SGMCMC_EINVAL, "philox_normal: out is NULL");
-    NormalFillOp<double> op{out, make_key(seed, step)};
+    NormalFillOp<double> op{out, make_key(seed, step, step_dev)};
     return launch(op, n, aligned16(out), static_cast<hipStream_t>(stream));
 }
-int sgmcmc_philox_bits_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t step, sgmcmc_stream_t stream)
+int sgmcmc_philox_bits_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
 {
     if (n == 0) return 0;
     if (!out) return fail(SGMCMC_EINVAL, "philox_bits: out is NULL");
     hipLaunchKernelGGL(philox_bits_kernel, dim3(small_grid((n + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       out, n, make_key(seed, step));
+                       out, n, make_key(seed, step, step_dev));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch philox_bits");
 }
@@ -865,6 +894,14 @@ int sgmcmc_rhat_finish_f32(const float *sum3, size_t n, int m_chains, uint64_t c
                        (float)m_chains, (float)count, rhat);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch rhat_finish");
+}
+
+int sgmcmc_counter_add_u64(uint64_t *counter, uint64_t inc, sgmcmc_stream_t stream)
+{
+    if (!counter) return fail(SGMCMC_EINVAL, "counter_add: counter is NULL");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), counter, inc);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch counter_add");
 }
 
 size_t sgmcmc_summary_workspace_bytes(void) { return sizeof(Summary) * SUMMARY_BLOCKS; }

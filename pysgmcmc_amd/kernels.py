@@ -15,7 +15,7 @@ from pysgmcmc_amd._lib import SgmcmcLibraryError, check, lib
 __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
-    "set_launch_config", "get_launch_config",
+    "set_launch_config", "get_launch_config", "counter_add",
 ]
 
 _SFX = {torch.float32: "f32", torch.float64: "f64"}
@@ -52,6 +52,28 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _ctr(step_dev):
+    """Device step counter (int64 tensor with one element) -> pointer, or NULL."""
+    if step_dev is None:
+        return None
+    if step_dev.dtype != torch.int64 or step_dev.numel() != 1:
+        raise TypeError("step_dev must be a one-element int64 device tensor")
+    return _ptr(step_dev)
+
+
+def counter_add(counter, inc=1):
+    """counter += inc on the current stream (graph-capturable)."""
+    with _on(counter):
+        rc = lib().sgmcmc_counter_add_u64(_ctr(counter), int(inc), _stream(counter))
+    check(rc, "sgmcmc_counter_add_u64")
+
+
+def _on(t):
+    """Device guard for the launch; refuses CPU tensors (there is no CPU update path)."""
+    _ptr(t)
+    return torch.cuda.device(t.device)
+
+
 def set_launch_config(block_threads=0, quads_per_thread=0, max_blocks=0, nontemporal=-1):
     check(lib().sgmcmc_set_launch_config(block_threads, quads_per_thread, max_blocks, nontemporal),
           "sgmcmc_set_launch_config")
@@ -65,50 +87,50 @@ def get_launch_config():
     return {"block_threads": a.value, "quads_per_thread": b.value, "max_blocks": c.value, "nontemporal": d.value}
 
 
-def sghmc_step(theta, V, grad, tau, g, v_hat, minv, r, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step=0):
+def sghmc_step(theta, V, grad, tau, g, v_hat, minv, r, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step=0, step_dev=None):
     """K1, one fused SGHMC step in place (pysgmcmc/samplers/sghmc.py:165-251)."""
     f = getattr(lib(), "sgmcmc_sghmc_step_" + _sfx(theta))
-    with torch.cuda.device(theta.device):
+    with _on(theta):
         rc = f(_ptr(theta), _ptr(V, theta), _ptr(grad, theta), _ptr(tau, theta), _ptr(g, theta),
                _ptr(v_hat, theta), _ptr(minv, theta), _ptr(r, theta), theta.numel(),
                float(eps), float(scale_grad), float(mdecay), int(bool(adapt)), _ptr(xi, theta),
-               int(seed), int(step), _stream(theta))
+               int(seed), int(step), _ctr(step_dev), _stream(theta))
     check(rc, "sgmcmc_sghmc_step")
 
 
-def sgld_step(theta, grad, tau, g, v_hat, minv, r, eps, A, scale_grad, adapt, xi=None, seed=0, step=0):
+def sgld_step(theta, grad, tau, g, v_hat, minv, r, eps, A, scale_grad, adapt, xi=None, seed=0, step=0, step_dev=None):
     """K2, one fused SGLD step in place (pysgmcmc/samplers/sgld.py:149-211)."""
     f = getattr(lib(), "sgmcmc_sgld_step_" + _sfx(theta))
-    with torch.cuda.device(theta.device):
+    with _on(theta):
         rc = f(_ptr(theta), _ptr(grad, theta), _ptr(tau, theta), _ptr(g, theta), _ptr(v_hat, theta),
                _ptr(minv, theta), _ptr(r, theta), theta.numel(), float(eps), float(A), float(scale_grad),
-               int(bool(adapt)), _ptr(xi, theta), int(seed), int(step), _stream(theta))
+               int(bool(adapt)), _ptr(xi, theta), int(seed), int(step), _ctr(step_dev), _stream(theta))
     check(rc, "sgmcmc_sgld_step")
 
 
-def rsghmc_step(theta, p, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, step=0):
+def rsghmc_step(theta, p, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, step=0, step_dev=None):
     """K3, one fused relativistic SGHMC step (pysgmcmc/samplers/relativistic_sghmc.py:120-140)."""
     f = getattr(lib(), "sgmcmc_rsghmc_step_" + _sfx(theta))
-    with torch.cuda.device(theta.device):
+    with _on(theta):
         rc = f(_ptr(theta), _ptr(p, theta), _ptr(grad_cost, theta), theta.numel(), float(eps), float(mass),
-               float(c), float(D), float(b_hat), _ptr(xi, theta), int(seed), int(step), _stream(theta))
+               float(c), float(D), float(b_hat), _ptr(xi, theta), int(seed), int(step), _ctr(step_dev), _stream(theta))
     check(rc, "sgmcmc_rsghmc_step")
 
 
-def philox_normal(out, seed, step):
+def philox_normal(out, seed, step, step_dev=None):
     """K5, out[i] = xi(seed, step, i)."""
     f = getattr(lib(), "sgmcmc_philox_normal_" + _sfx(out))
-    with torch.cuda.device(out.device):
-        rc = f(_ptr(out), out.numel(), int(seed), int(step), _stream(out))
+    with _on(out):
+        rc = f(_ptr(out), out.numel(), int(seed), int(step), _ctr(step_dev), _stream(out))
     check(rc, "sgmcmc_philox_normal")
     return out
 
 
-def philox_bits(out, seed, step):
+def philox_bits(out, seed, step, step_dev=None):
     if out.dtype not in (torch.int32, torch.uint32):
         raise TypeError("philox_bits wants a 32-bit integer tensor")
-    with torch.cuda.device(out.device):
-        rc = lib().sgmcmc_philox_bits_u32(_ptr(out), out.numel(), int(seed), int(step), _stream(out))
+    with _on(out):
+        rc = lib().sgmcmc_philox_bits_u32(_ptr(out), out.numel(), int(seed), int(step), _ctr(step_dev), _stream(out))
     check(rc, "sgmcmc_philox_bits_u32")
     return out
 
@@ -116,7 +138,7 @@ def philox_bits(out, seed, step):
 def moments_update(theta, mean, m2, count):
     """K4, Welford update of (mean, m2) with the sample theta; count includes it."""
     f = getattr(lib(), "sgmcmc_moments_update_" + _sfx(theta))
-    with torch.cuda.device(theta.device):
+    with _on(theta):
         rc = f(_ptr(theta), _ptr(mean, theta), _ptr(m2, theta), theta.numel(), int(count), _stream(theta))
     check(rc, "sgmcmc_moments_update")
 
@@ -126,14 +148,14 @@ def rhat_pack(mean, m2, count, out3):
         raise TypeError("rhat_pack is float32-only")
     if out3.numel() != 3 * mean.numel():
         raise ValueError("out3 must hold 3*n elements")
-    with torch.cuda.device(mean.device):
+    with _on(mean):
         rc = lib().sgmcmc_rhat_pack_f32(_ptr(mean), _ptr(m2, mean), mean.numel(), int(count), _ptr(out3),
                                         _stream(mean))
     check(rc, "sgmcmc_rhat_pack_f32")
 
 
 def rhat_finish(sum3, n, m_chains, count, rhat):
-    with torch.cuda.device(sum3.device):
+    with _on(sum3):
         rc = lib().sgmcmc_rhat_finish_f32(_ptr(sum3), int(n), int(m_chains), int(count), _ptr(rhat), _stream(sum3))
     check(rc, "sgmcmc_rhat_finish_f32")
 
@@ -145,7 +167,7 @@ def summary(x, out4=None, workspace=None):
         out4 = torch.empty(4, dtype=torch.float64, device=x.device)
     if workspace is None:
         workspace = torch.empty(lib().sgmcmc_summary_workspace_bytes(), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x):
         rc = f(_ptr(x), x.numel(), _ptr(out4), _ptr(workspace), _stream(x))
     check(rc, "sgmcmc_summary")
     return out4

@@ -1,0 +1,292 @@
+"""Sampler base classes: the per-step driver behind ``next(sampler)``.
+
+Mirror of ``pysgmcmc/samplers/base_classes.py`` (``MCMCSampler`` :17-310,
+``BurnInMCMCSampler`` :313-456): same constructor keywords, same iterator
+protocol, same return convention -- ``next(sampler) -> (sample, cost)`` where
+``sample`` is theta AFTER the step (a list of arrays in the parameters' shapes, or
+the bare array for a single parameter, :302-304) and ``cost`` is the cost at the
+parameters BEFORE the step (the same ``cost`` tensor feeds ``tf.gradients`` and
+is fetched next to the assign ops, :298-300).
+
+What differs, by design:
+  * ``params`` are torch tensors; the sampler re-points them to views of one flat
+    device arena (``pysgmcmc_amd.arena.FlatArena``) and the whole update of all
+    parameters is ONE fused HIP kernel launch (``pysgmcmc_amd.kernels``) instead
+    of ~25 TF ops per tensor.
+  * ``cost_fun(params)`` is evaluated every step with PyTorch-ROCm autograd (or,
+    if it provides ``cost_and_grad(params, grad_views)``, writes gradients
+    straight into the arena).
+  * ``session`` is accepted for signature compatibility; a ``torch.device`` (or
+    device string) there selects the GPU, anything else is ignored.
+  * ``sample_format`` (attribute, not a constructor keyword so that the
+    ``get_sampler`` keyword reflection stays identical to the reference):
+    ``"numpy"`` (default, reference behaviour: one D2H copy of theta per step),
+    ``"device"`` (cloned device tensors) or ``"view"`` (zero-copy views of the
+    live arena; they change at the next step).
+"""
+import os
+
+import numpy as np
+import torch
+
+from pysgmcmc_amd import kernels
+from pysgmcmc_amd.arena import FlatArena
+from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+
+__all__ = ("MCMCSampler", "BurnInMCMCSampler")
+
+_DTYPES = {
+    torch.float32: torch.float32, torch.float64: torch.float64,
+    "float32": torch.float32, "float64": torch.float64,
+    np.float32: torch.float32, np.float64: torch.float64,
+    np.dtype("float32"): torch.float32, np.dtype("float64"): torch.float64,
+    float: torch.float64,
+}
+
+
+def as_torch_dtype(dtype):
+    try:
+        return _DTYPES[dtype]
+    except (KeyError, TypeError):
+        pass
+    name = getattr(dtype, "name", None)          # e.g. a tf.DType
+    if name in ("float32", "float64"):
+        return _DTYPES[name]
+    raise AssertionError("unsupported sampler dtype: %r (float32 / float64)" % (dtype,))
+
+
+def _pick_device(session, params):
+    if isinstance(session, (torch.device, str, int)):
+        return torch.device(session) if not isinstance(session, int) else torch.device("cuda", session)
+    for p in params:
+        if isinstance(p, torch.Tensor) and p.is_cuda:
+            return p.device
+    if torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
+    # No GPU: construction still works (host logic is testable); stepping raises
+    # SgmcmcLibraryError in pysgmcmc_amd.kernels -- there is no CPU update path.
+    return torch.device("cpu")
+
+
+class MCMCSampler(object):
+    """Generic base class of all MCMC samplers (iterator protocol + step driver)."""
+
+    # state rows (besides theta and grad) the subclass's kernel needs
+    _STATE_ROWS = ()
+
+    def __init__(self, params, cost_fun, batch_generator=None,
+                 stepsize_schedule=ConstantStepsizeSchedule(0.01),
+                 session=None, dtype=torch.float64, seed=None):
+        # same checks as pysgmcmc/samplers/base_classes.py:73-89
+        assert batch_generator is None or hasattr(batch_generator, "__next__")
+        assert seed is None or isinstance(seed, int)
+        assert callable(cost_fun)
+        assert hasattr(stepsize_schedule, "update")
+        assert hasattr(stepsize_schedule, "__next__")
+        assert hasattr(stepsize_schedule, "initial_value")
+
+        self.dtype = dtype
+        self._torch_dtype = as_torch_dtype(dtype)
+        self.n_iterations = 0
+        self.seed = seed
+        # Philox key: the user's seed, or fresh entropy when seed is None
+        self._philox_seed = (int(seed) if seed is not None
+                             else int.from_bytes(os.urandom(8), "little")) & 0xFFFFFFFFFFFFFFFF
+        self.stepsize_schedule = stepsize_schedule
+        self.batch_generator = batch_generator
+        self.session = session
+        self.sample_format = "numpy"
+
+        params = list(params)
+        for p in params:
+            assert isinstance(p, torch.Tensor), "params must be torch tensors"
+        self.params = params
+        self.device = _pick_device(session, params)
+        self.arena = FlatArena(params, self._STATE_ROWS, self._torch_dtype, self.device)
+        for p in self.params:
+            p.requires_grad_(True)
+
+        self.cost_fun = cost_fun
+        self.cost = None                      # last evaluated cost (device tensor)
+        self.epsilon = self.stepsize_schedule.initial_value
+        # flat (n_i, 1) views of theta, the role of `vectorize` (tensor_utils.py:92-95)
+        self.vectorized_params = [v.view(-1, 1) for v in self.arena.views("theta")]
+        self.theta_t = self.arena.views("theta")
+        # injected-noise hook (tests / reproducing a trajectory): callable(step, n) -> flat tensor or None
+        self.noise_source = None
+
+    # ------------------------------------------------------------------ feeds
+    def _next_batch(self):
+        """Next ``{placeholder: value}`` dict, or ``{}`` without a generator."""
+        if self.batch_generator is not None:
+            return next(self.batch_generator)
+        return dict()
+
+    def _next_stepsize(self):
+        self.epsilon = next(self.stepsize_schedule)
+        return self.epsilon
+
+    @staticmethod
+    def _feed(feed_dict):
+        for placeholder, value in feed_dict.items():
+            if hasattr(placeholder, "feed"):
+                placeholder.feed(value)
+
+    # ------------------------------------------------------------------ cost
+    def _cost_and_grad(self):
+        """Evaluate cost at the current theta and leave d cost/d theta in the arena's grad row."""
+        fused = getattr(self.cost_fun, "cost_and_grad", None)
+        if fused is not None:
+            cost = fused(self.params, self.arena.grad_views)
+            return cost.detach() if isinstance(cost, torch.Tensor) else torch.as_tensor(cost)
+        with torch.enable_grad():
+            cost = self.cost_fun(self.params)
+            if not isinstance(cost, torch.Tensor) or not cost.requires_grad:
+                raise ValueError("cost_fun(params) must return a torch tensor that depends on params")
+            grads = torch.autograd.grad(cost, self.params, grad_outputs=torch.ones_like(cost),
+                                        allow_unused=True)
+        with torch.no_grad():
+            dst, src = [], []
+            for view, g in zip(self.arena.grad_views, grads):
+                if g is None:
+                    view.zero_()
+                else:
+                    dst.append(view)
+                    src.append(g.reshape(view.shape).to(view.dtype))
+            if dst:
+                torch._foreach_copy_(dst, src)
+        return cost.detach()
+
+    def _draw_noise(self):
+        """Injected xi for this step, or None for the in-register Philox stream."""
+        if self.noise_source is None:
+            return None
+        xi = self.noise_source(self.n_iterations, self.arena.n)
+        if xi is None:
+            return None
+        xi = torch.as_tensor(xi, dtype=self._torch_dtype, device=self.device).reshape(-1).contiguous()
+        assert xi.numel() == self.arena.n
+        return xi
+
+    # ------------------------------------------------------------------ output
+    def _format_sample(self):
+        fmt = self.sample_format
+        if fmt == "numpy":
+            flat = self.arena.row("theta").detach().cpu().numpy()
+            out = [flat[o:o + s].reshape(shp).copy()
+                   for o, s, shp in zip(self.arena.offsets, self.arena.sizes, self.arena.shapes)]
+        elif fmt == "device":
+            out = [v.detach().clone() for v in self.arena.views("theta")]
+        elif fmt == "view":
+            out = [v.detach() for v in self.arena.views("theta")]
+        else:
+            raise ValueError("sample_format must be 'numpy', 'device' or 'view'")
+        if len(out) == 1:
+            out = out[0]                     # base_classes.py:302-304
+        return out
+
+    def _format_cost(self, cost):
+        if self.sample_format == "numpy":
+            return cost.detach().cpu().numpy()
+        return cost
+
+    # ------------------------------------------------------------------ step
+    def _kernel_step(self, eps, xi):
+        raise NotImplementedError
+
+    def _step(self, feed_dict):
+        assert (feed_dict is None or hasattr(feed_dict, "update"))
+        if feed_dict is None:
+            feed_dict = dict()
+        feed_dict.update(self._next_batch())
+        eps = self._next_stepsize()
+        self._feed(feed_dict)
+        cost = self._cost_and_grad()          # U(theta_{t-1}) and its gradient
+        self.cost = cost
+        with torch.no_grad():
+            self._kernel_step(eps, self._draw_noise())
+        sample = self._format_sample()        # theta_t
+        cost_out = self._format_cost(cost)
+        self.stepsize_schedule.update(sample, cost_out)
+        self.n_iterations += 1
+        return sample, cost_out
+
+    # iterator protocol, base_classes.py:226-310
+    def __iter__(self):
+        return self
+
+    def __next__(self, feed_dict=None):
+        return self._step(feed_dict)
+
+    # ------------------------------------------------------------------ state
+    def state_dict(self):
+        """Everything needed to resume the chain bit-exactly (the reference cannot checkpoint)."""
+        return {"arena": self.arena.state_dict(), "n_iterations": self.n_iterations,
+                "philox_seed": self._philox_seed, "epsilon": self.epsilon}
+
+    def load_state_dict(self, state):
+        self.arena.load_state_dict(state["arena"])
+        self.n_iterations = int(state["n_iterations"])
+        self._philox_seed = int(state["philox_seed"])
+        self.epsilon = state["epsilon"]
+
+
+class BurnInMCMCSampler(MCMCSampler):
+    """Base class of samplers that adapt a diagonal preconditioner (``minv``)
+    during the first ``burn_in_steps`` steps and freeze it afterwards.
+
+    Burn-in switch, pysgmcmc/samplers/base_classes.py:432-456: steps
+    ``0 .. burn_in_steps-1`` adapt; from step ``burn_in_steps`` on the captured
+    ``minv`` is used unchanged. ``burn_in_steps <= 0`` never freezes (nothing is
+    ever captured to feed, :449) => perpetual adaptation, replicated here.
+    """
+
+    _STATE_ROWS = ("tau", "g", "v_hat", "minv")
+
+    def __init__(self, params, cost_fun, batch_generator=None,
+                 stepsize_schedule=ConstantStepsizeSchedule(0.01),
+                 burn_in_steps=3000,
+                 session=None, dtype=torch.float64, seed=None):
+        assert isinstance(burn_in_steps, int)
+        super().__init__(params=params, cost_fun=cost_fun,
+                         stepsize_schedule=stepsize_schedule,
+                         batch_generator=batch_generator,
+                         seed=seed, dtype=dtype, session=session)
+        self.burn_in_steps = burn_in_steps
+        # initial statistics, sghmc.py:126-149 / sgld.py:117-141
+        for name in ("tau", "g", "v_hat", "minv"):
+            self.arena.fill(name, 1.0)
+        self.minv_t = self.arena.views("minv")
+        # Set True to also materialise r = 1/(tau+1) like the reference's R_i variable
+        # (+4 B/param of traffic; r is derivable from tau).
+        self.materialize_r = False
+        self._minv_summary = None
+
+    @property
+    def is_burning_in(self):
+        return self.n_iterations < self.burn_in_steps
+
+    @property
+    def _adapting(self):
+        return self.is_burning_in or self.burn_in_steps <= 0
+
+    @property
+    def minv(self):
+        """Adapted inverse mass, one ``(n_i, 1)`` ndarray per parameter (base_classes.py:438-441)."""
+        return [v.detach().reshape(-1, 1).cpu().numpy() for v in self.arena.views("minv")]
+
+    @property
+    def minv_summary(self):
+        """``{"mean","std","min","max"}`` of the preconditioner, by the K6 reduction kernel."""
+        s = kernels.summary(self.arena.row("minv")).cpu().numpy()
+        n = float(self.arena.n)
+        mean = s[0] / n
+        var = max(s[1] / n - mean * mean, 0.0)
+        return {"mean": mean, "std": var ** 0.5, "min": s[2], "max": s[3]}
+
+    def _r_row(self):
+        if not self.materialize_r:
+            return None
+        if "r" not in self.arena._rows:
+            self.arena._rows["r"] = torch.full((self.arena.n,), 0.5, dtype=self._torch_dtype, device=self.device)
+        return self.arena._rows["r"]

@@ -1,0 +1,43 @@
+"""SGHMC with scale-adapted burn-in (mirror of ``pysgmcmc/samplers/sghmc.py``).
+
+The whole per-step op chain of the reference (``sghmc.py:165-251``: r, tau, minv,
+g, v_hat, noise scale, momentum, theta) is kernel K1,
+``sgmcmc_sghmc_step_{f32,f64}`` -- one launch for all parameters.
+"""
+import torch
+
+from pysgmcmc_amd import kernels
+from pysgmcmc_amd.samplers.base_classes import BurnInMCMCSampler
+from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+
+__all__ = ("SGHMCSampler",)
+
+
+class SGHMCSampler(BurnInMCMCSampler):
+    """Stochastic Gradient Hamiltonian Monte-Carlo sampler with the burn-in
+    adaptation of Springenberg et al. 2016 (same keywords and defaults as the
+    reference constructor, ``sghmc.py:31-34``)."""
+
+    _STATE_ROWS = ("V", "tau", "g", "v_hat", "minv")
+
+    def __init__(self, params, cost_fun, batch_generator=None,
+                 stepsize_schedule=ConstantStepsizeSchedule(0.01),
+                 burn_in_steps=3000, mdecay=0.05, scale_grad=1.0,
+                 session=None, dtype=torch.float64, seed=None):
+        super().__init__(
+            params=params, cost_fun=cost_fun, burn_in_steps=burn_in_steps,
+            batch_generator=batch_generator,
+            seed=seed, dtype=dtype, session=session,
+            stepsize_schedule=stepsize_schedule
+        )
+        self.mdecay = float(mdecay)
+        self.scale_grad = float(scale_grad)
+        # momentum starts at zero (sghmc.py:152-155); tau = g = v_hat = minv = 1 set by the base
+
+    def _kernel_step(self, eps, xi):
+        a = self.arena
+        kernels.sghmc_step(
+            a.row("theta"), a.row("V"), a.row("grad"),
+            a.row("tau"), a.row("g"), a.row("v_hat"), a.row("minv"), self._r_row(),
+            eps, self.scale_grad, self.mdecay, self._adapting,
+            xi=xi, seed=self._philox_seed, step=self.n_iterations)

@@ -1,0 +1,65 @@
+"""CPU stand-in for ``pysgmcmc_amd.kernels`` used ONLY by the ``-m "not gpu"`` tests
+to exercise the host-side sampler logic (iterator protocol, burn-in switch,
+schedule/batch feeding) on a machine without a GPU. Each function has the
+signature of its ``kernels`` counterpart and runs the C oracle on the CPU
+tensors' memory. The product never imports this (tests/test_boundary.py checks).
+"""
+import numpy as np
+import torch
+
+from oracle import sgmcmc_oracle as O
+
+
+class _St(object):
+    pass
+
+
+def _np(t):
+    return None if t is None else t.detach().numpy()
+
+
+def _sfx(t):
+    return "f32" if t.dtype == torch.float32 else "f64"
+
+
+def sghmc_step(theta, V, grad, tau, g, v_hat, minv, r, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step=0, step_dev=None):
+    lib = O.load_c()
+    f = getattr(lib, "oracle_sghmc_step_" + _sfx(theta))
+    p = lambda t: None if t is None else t.data_ptr()
+    rc = f(p(theta), p(V), p(grad), p(tau), p(g), p(v_hat), p(minv), p(r), theta.numel(),
+           float(eps), float(scale_grad), float(mdecay), int(bool(adapt)), p(xi), int(seed), int(step))
+    assert rc == 0
+    calls.append(("sghmc", bool(adapt), float(eps), int(step)))
+
+
+def sgld_step(theta, grad, tau, g, v_hat, minv, r, eps, A, scale_grad, adapt, xi=None, seed=0, step=0, step_dev=None):
+    lib = O.load_c()
+    f = getattr(lib, "oracle_sgld_step_" + _sfx(theta))
+    p = lambda t: None if t is None else t.data_ptr()
+    rc = f(p(theta), p(grad), p(tau), p(g), p(v_hat), p(minv), p(r), theta.numel(),
+           float(eps), float(A), float(scale_grad), int(bool(adapt)), p(xi), int(seed), int(step))
+    assert rc == 0
+    calls.append(("sgld", bool(adapt), float(eps), int(step)))
+
+
+def rsghmc_step(theta, p_, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, step=0, step_dev=None):
+    lib = O.load_c()
+    f = getattr(lib, "oracle_rsghmc_step_" + _sfx(theta))
+    p = lambda t: None if t is None else t.data_ptr()
+    rc = f(p(theta), p(p_), p(grad_cost), theta.numel(), float(eps), float(mass), float(c), float(D),
+           float(b_hat), p(xi), int(seed), int(step))
+    assert rc == 0
+    calls.append(("rsghmc", False, float(eps), int(step)))
+
+
+calls = []
+
+
+def install(monkeypatch):
+    """Route pysgmcmc_amd.kernels.*_step to the oracle for the duration of a test."""
+    from pysgmcmc_amd import kernels
+    del calls[:]
+    monkeypatch.setattr(kernels, "sghmc_step", sghmc_step)
+    monkeypatch.setattr(kernels, "sgld_step", sgld_step)
+    monkeypatch.setattr(kernels, "rsghmc_step", rsghmc_step)
+    return calls
