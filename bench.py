@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Benchmark of the SG-MCMC update path on MI355X (contract: see DESIGN.md "Measurement").
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]): SGHMC on a 4-layer tanh MLP BNN
+784-2048-2048-2048-1 + scalar log-variance = 10 002 434 parameters, fp32, synthetic
+data (N = 100 000 rows ~ N(0,1), minibatch windows of 256), post-burn-in (frozen
+preconditioner) phase. One "step" = one complete ``next(sampler)``: feed the minibatch,
+BNN forward + analytic backward writing gradients into the flat arena (rocBLAS GEMMs),
+then the fused SGHMC update kernel (in-register Philox noise). Nothing is skipped.
+
+N > 1: independent chains, one per GPU (weak scaling, no collective on the data path);
+every --rhat-every steps the chains exchange Welford moments with one RCCL all-reduce
+to compute R-hat (the only communication the path has).
+
+Output: ONE JSON line on rank 0. ``value`` = whole-job samples/s. ``roofline`` = the
+fused update kernel measured live with HIP events inside the timed region.
+``cpu_baseline`` (N = 1 only) = the fused C oracle timed on the host cores on the same
+10 M-parameter update.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:35
+BYTES_PER_PARAM = {"sghmc_frozen": 24, "sghmc_adapt": 48}
+LAYERS = (784, 2048, 2048, 2048)
+BATCH = 256
+N_DATA = 100_000
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rhat-every", type=int, default=100, help="R-hat exchange cadence (steps), N > 1")
+    ap.add_argument("--moments-every", type=int, default=10, help="Welford moments cadence (steps)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline leg")
+    return ap.parse_args()
+
+
+def build_chain(dev, rank):
+    from pysgmcmc_amd.data_batches import Placeholder, generate_batches
+    from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
+    from pysgmcmc_amd.samplers import SGHMCSampler
+    from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+
+    g = torch.Generator(device=dev).manual_seed(0)             # same synthetic dataset on every rank
+    X = torch.randn(N_DATA, LAYERS[0], device=dev, generator=g)
+    y = torch.randn(N_DATA, device=dev, generator=g)
+    xp = Placeholder(dtype=torch.float32, device=dev, name="X_Minibatch")
+    yp = Placeholder(dtype=torch.float32, device=dev, name="Y_Minibatch")
+    params = init_mlp_params(LAYERS[0], hidden=LAYERS[1:], seed=1000 + rank, dtype=torch.float32, device=dev)
+    cost = BNNCost(xp, yp, batch_size=BATCH, n_examples=N_DATA)
+    return SGHMCSampler(
+        params=params, cost_fun=cost,
+        batch_generator=generate_batches(X, y, xp, yp, batch_size=BATCH, seed=rank),
+        stepsize_schedule=ConstantStepsizeSchedule(0.01), mdecay=0.05, scale_grad=float(N_DATA),
+        burn_in_steps=8,                                       # adapted during warmup; timed steps are frozen
+        session=dev, dtype=torch.float32, seed=1234 + rank)
+
+
+class KernelTimer(object):
+    """HIP-event timing of the fused update launch, on the stream it is launched on."""
+
+    def __init__(self, sampler):
+        self.pairs = []
+        self.enabled = False
+        inner = sampler._kernel_step
+
+        def timed(eps, xi):
+            if not self.enabled:
+                return inner(eps, xi)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            inner(eps, xi)
+            b.record()
+            self.pairs.append((a, b))
+        sampler._kernel_step = timed
+
+    def mean_us(self):
+        return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) * 1e3 if self.pairs else None
+
+    def median_us(self):
+        return float(np.median([a.elapsed_time(b) for a, b in self.pairs])) * 1e3 if self.pairs else None
+
+
+def update_only(sampler, iters=200):
+    """Back-to-back launches of the fused kernel alone on the chain's own arrays (no gradient work)."""
+    from pysgmcmc_amd import kernels
+    a = sampler.arena
+    out = {}
+    for name, adapt in (("sghmc_frozen", False), ("sghmc_adapt", True)):
+        state = a.state_dict()
+        for _ in range(10):
+            kernels.sghmc_step(a.row("theta"), a.row("V"), a.row("grad"), a.row("tau"), a.row("g"), a.row("v_hat"),
+                               a.row("minv"), None, 0.01, float(N_DATA), 0.05, adapt, seed=1, step=0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(iters):
+            kernels.sghmc_step(a.row("theta"), a.row("V"), a.row("grad"), a.row("tau"), a.row("g"), a.row("v_hat"),
+                               a.row("minv"), None, 0.01, float(N_DATA), 0.05, adapt, seed=1, step=i + 1)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / iters * 1e3
+        a.load_state_dict(state)
+        out[name] = {"us_per_launch": round(us, 2), "steps_per_s": round(1e6 / us, 1),
+                     "GBps": round(BYTES_PER_PARAM[name] * a.n / us / 1e3, 1)}
+    return out
+
+
+def cpu_baseline(n, budget_s):
+    """The fused C oracle (kind "port") on the host cores: frozen SGHMC update, Philox noise, same n."""
+    from oracle import sgmcmc_oracle as O
+    lib = O.load_c()
+    cores = os.cpu_count() or 1
+    lib.oracle_set_num_threads(cores)
+    rng = np.random.default_rng(0)
+    st = O.CState(rng.standard_normal(n, dtype=np.float32) * 0.02, np.float32)
+    st.minv[:] = rng.random(n, dtype=np.float32) * 1.5 + 0.5
+    grad = rng.standard_normal(n, dtype=np.float32) * 0.1
+    O.c_sghmc_step(st, grad, 0.01, float(N_DATA), 0.05, False, None, seed=1, step=0)     # warm
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 50 and (time.perf_counter() - t0) < budget_s:
+        O.c_sghmc_step(st, grad, 0.01, float(N_DATA), 0.05, False, None, seed=1, step=steps + 1)
+        steps += 1
+    dt = time.perf_counter() - t0
+    # baseline A: op-by-op numpy mirror of the reference's unfused TF graph (injected noise drawn
+    # by numpy, temporaries materialised, + the per-step copy-out of all parameters)
+    ns = O.OpByOpState(st.theta, np.float32)
+    frozen = st.minv.reshape(-1, 1)
+    t1 = time.perf_counter()
+    asteps = 0
+    while asteps < 10 and (time.perf_counter() - t1) < budget_s / 2:
+        xi = rng.standard_normal(n, dtype=np.float32)
+        O.opbyop_sghmc_step(ns, grad, 0.01, float(N_DATA), 0.05, xi, frozen_minv=frozen)
+        _ = ns.theta.copy()
+        asteps += 1
+    adt = time.perf_counter() - t1
+    return {"value": round(steps / dt, 3), "unit": "update-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d frozen SGHMC update steps (update kernel only, no BNN gradient) of %d fp32 params, "
+                      "fused C oracle + OpenMP, Philox noise, %.1f s" % (steps, n, dt),
+            "opbyop_numpy_steps_per_s": round(asteps / adt, 3) if asteps else None}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback exists for the update path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)         # RCCL over xGMI
+
+    from pysgmcmc_amd import kernels
+    sampler = build_chain(dev, rank)
+    sampler.sample_format = "view"                             # no D2H copy of 40 MB per sample
+    n = sampler.arena.n
+    timer = KernelTimer(sampler)
+    mean = torch.zeros(n, dtype=torch.float32, device=dev)
+    m2 = torch.zeros(n, dtype=torch.float32, device=dev)
+    pack = torch.empty(3 * n, dtype=torch.float32, device=dev)
+    rhat = torch.empty(n, dtype=torch.float32, device=dev)
+    n_moments = [0]
+    rhat_summary = [None]
+
+    def one_step(i):
+        next(sampler)
+        if (i + 1) % args.moments_every == 0:
+            n_moments[0] += 1
+            kernels.moments_update(sampler.arena.row("theta"), mean, m2, n_moments[0])
+        if world > 1 and (i + 1) % args.rhat_every == 0 and n_moments[0] >= 2:
+            kernels.rhat_pack(mean, m2, n_moments[0], pack)
+            dist.all_reduce(pack)
+            kernels.rhat_finish(pack, n, world, n_moments[0], rhat)
+            rhat_summary[0] = kernels.summary(rhat)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    assert args.warmup < 8 or not sampler.is_burning_in
+    frozen_phase = not sampler._adapting
+    n_moments[0] = 0
+    mean.zero_()
+    m2.zero_()
+    timer.enabled = True
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(sampler.arena.row("theta")).all()
+
+    if rank == 0:
+        mode = "sghmc_frozen" if frozen_phase else "sghmc_adapt"
+        k_us = timer.mean_us()
+        alg_bytes = BYTES_PER_PARAM[mode] * n
+        achieved = alg_bytes / (k_us * 1e-6) / 1e9
+        line = {
+            "metric": "MCMC samples/sec + fused-update HBM GB/s (% roofline), BNN 10M params",
+            "value": round(world * args.steps / elapsed, 2),
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SGHMC (frozen preconditioner) full next(sampler) step: BNN fwd+bwd + fused update; "
+                                   "4-layer tanh MLP BNN 784-2048-2048-2048-1, %d params, batch %d, "
+                                   "1 chain per GPU" % (n, BATCH),
+                       "params": n, "batch": BATCH, "chains": world,
+                       "rhat_every": args.rhat_every if world > 1 else None,
+                       "moments_every": args.moments_every, "launch": kernels.get_launch_config()},
+            "roofline": {"bound": "hbm", "kernel": "stream_quads_vec<SghmcOp<float,%s,false>>" %
+                         ("false" if frozen_phase else "true"),
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "us_per_launch_mean": round(k_us, 2), "us_per_launch_median": round(timer.median_us(), 2),
+                         "launches_timed": len(timer.pairs), "timing": "hipEvent pairs around each launch, in-pipeline"},
+        }
+        if rhat_summary[0] is not None:
+            s = rhat_summary[0].cpu().numpy()
+            line["rhat"] = {"mean": round(float(s[0] / n), 4), "max": round(float(s[3]), 4)}
+        if world == 1:
+            line["update_only"] = update_only(sampler)
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
+        print(json.dumps(line))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

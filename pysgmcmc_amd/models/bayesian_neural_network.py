@@ -1,0 +1,430 @@
+"""Bayesian neural network on the SG-MCMC update path (mirror of
+``pysgmcmc/models/bayesian_neural_network.py``): the cost path that produces the
+gradients the fused kernels consume, and the ``train`` / ``predict`` driver.
+
+Cost (``bayesian_neural_network.py:365-388``), for a tanh MLP with a learnable scalar
+log-variance ``output_bias`` (``:28-69``):
+
+    NLL = -[ sum_i( -(y_i-mu_i)^2 * 0.5/(exp(s)+1e-16) - 0.5 s ) / batch_size
+             + LVP(s)/N + WP(theta)/N ]
+    LVP = mean_rows sum_cols[ sdiv(-(s - ln 1e-6)^2, 2*0.01) - 0.5 ln 0.01 ]   (:102-107)
+    WP  = sdiv( sum_tensors sum -0.5*wdecay*w^2, n_params )                    (:131-141)
+
+``batch_size`` is the CONFIGURED size, ``N`` the dataset size; WP runs over every
+trainable tensor including biases and ``output_bias`` (``:386``).
+
+:class:`BNNCost` evaluates this two ways:
+  * ``cost_fun(params)`` -- plain torch ops, differentiable by autograd (any
+    ``get_net``-style network works this way);
+  * ``cost_and_grad(params, grad_views)`` -- the MI355X path for MLPs: analytic
+    backward whose GEMMs (rocBLAS/hipBLASLt via ``torch.addmm(out=...)``) write
+    d cost/d W straight into the sampler's flat gradient arena with the weight-prior
+    term folded into the GEMM epilogue (``beta * W``), so no gradient tensor is ever
+    allocated, gathered or copied between the backward pass and the fused update.
+"""
+import itertools
+import logging
+import math
+from collections import deque
+from time import time
+
+import numpy as np
+import torch
+
+from pysgmcmc_amd.data_batches import Placeholder, generate_batches
+from pysgmcmc_amd.sampling import Sampler
+from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+from pysgmcmc_amd.tensor_utils import safe_divide
+
+__all__ = [
+    "get_default_net", "init_mlp_params", "mlp_forward", "log_variance_prior_log_like",
+    "weight_prior_log_like", "BNNCost", "BayesianNeuralNetwork",
+    "zero_mean_unit_var_normalization", "zero_mean_unit_var_unnormalization",
+]
+
+
+# ------------------------------------------------------------------ normalisation
+# pysgmcmc/models/base_model.py:125-137
+
+def zero_mean_unit_var_normalization(X, mean=None, std=None):
+    if mean is None:
+        mean = np.mean(X, axis=0)
+    if std is None:
+        std = np.std(X, axis=0)
+    return (X - mean) / std, mean, std
+
+
+def zero_mean_unit_var_unnormalization(X_normalized, mean, std):
+    return X_normalized * std + mean
+
+
+# ------------------------------------------------------------------ network
+
+def init_mlp_params(n_inputs, hidden=(50, 50, 50), seed=None, dtype=torch.float64, device="cpu"):
+    """Parameters of the default net in TF ``trainable_variables`` order:
+    ``[W1, b1, ..., W_L, b_L, output_bias]`` (``bayesian_neural_network.py:28-69``).
+
+    Kernels: ``variance_scaling_initializer(factor=1.0)`` = truncated normal with
+    variance 1/fan_in (:29-55); here N(0, 1/fan_in) truncated at 2 sd, drawn from
+    ``torch.Generator(seed)`` (TF's RNG stream itself is not reproducible here).
+    Biases zero; ``output_bias = log(1e-3)`` as a (1, 1) tensor (:58-61)."""
+    gen = torch.Generator(device="cpu")
+    if seed is not None:
+        gen.manual_seed(int(seed))
+    sizes = [int(n_inputs)] + [int(h) for h in hidden] + [1]
+    params = []
+    for fan_in, fan_out in zip(sizes[:-1], sizes[1:]):
+        w = torch.empty(fan_in, fan_out, dtype=torch.float64)
+        torch.nn.init.trunc_normal_(w, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=gen)
+        # rescale so the truncated draw has variance 1/fan_in (tf.contrib's initializer widens the
+        # pre-truncation stddev to sqrt(1.3/fan_in) for the same purpose)
+        w.mul_(math.sqrt(1.0 / fan_in) / 0.87962566103423978)
+        params.append(w.to(dtype=dtype, device=device))
+        params.append(torch.zeros(fan_out, dtype=dtype, device=device))
+    params.append(torch.full((1, 1), math.log(1e-3), dtype=dtype, device=device))
+    return params
+
+
+def mlp_forward(params, X):
+    """Network output ``(B, 2)`` = [mean, log_var] (``:63-67``)."""
+    h = X
+    n_layers = (len(params) - 1) // 2
+    for l in range(n_layers):
+        a = torch.addmm(params[2 * l + 1], h, params[2 * l])
+        h = torch.tanh(a) if l < n_layers - 1 else a
+    return torch.cat([h, torch.ones_like(h) * params[-1]], dim=1)
+
+
+def get_default_net(inputs, seed=None, dtype=torch.float64, params=None):
+    """Functional stand-in for the reference's ``get_default_net``: with ``params`` it
+    evaluates the 3x50 tanh net; without, it creates them first (returns (output, params))."""
+    if params is None:
+        params = init_mlp_params(inputs.shape[1], seed=seed, dtype=dtype, device=inputs.device)
+        return mlp_forward(params, inputs), params
+    return mlp_forward(params, inputs)
+
+
+# ------------------------------------------------------------------ priors
+
+def log_variance_prior_log_like(log_var, mean=1e-6, var=0.01, dtype=torch.float64):
+    """Prior on the predicted log variance (``:77-107``)."""
+    log_var = torch.as_tensor(log_var, dtype=dtype)
+    mean_t = torch.tensor(mean, dtype=dtype, device=log_var.device)
+    var_t = torch.tensor(var, dtype=dtype, device=log_var.device)
+    inner = safe_divide(-torch.square(log_var - torch.log(mean_t)), 2.0 * var_t) - 0.5 * torch.log(var_t)
+    return torch.mean(torch.sum(inner, dim=1))
+
+
+def weight_prior_log_like(parameters, wdecay=1.0, dtype=torch.float64):
+    """Gaussian prior on all parameters, normalised by their count (``:110-141``)."""
+    first = torch.as_tensor(parameters[0])
+    log_like = torch.zeros((), dtype=dtype, device=first.device)
+    n_params = 0.0
+    for p in parameters:
+        p = torch.as_tensor(p).to(dtype)
+        log_like = log_like + torch.sum(-wdecay * 0.5 * torch.square(p))
+        n_params += float(p.numel())
+    return safe_divide(log_like, torch.tensor(n_params, dtype=dtype, device=first.device))
+
+
+# ------------------------------------------------------------------ cost path
+
+class BNNCost(object):
+    """Negative log likelihood of the MLP BNN as a sampler ``cost_fun``.
+
+    ``x_placeholder`` / ``y_placeholder`` are fed by the batch generator; ``batch_size``
+    and ``n_examples`` are the configured constants of ``:377,380``.
+    """
+
+    __name__ = "negative_log_likelihood"
+
+    def __init__(self, x_placeholder, y_placeholder, batch_size, n_examples, wdecay=1.0,
+                 prior_mean=1e-6, prior_var=0.01):
+        self.x_placeholder = x_placeholder
+        self.y_placeholder = y_placeholder
+        self.batch_size = int(batch_size)
+        self.n_examples = int(n_examples)
+        self.wdecay = float(wdecay)
+        self.prior_mean = float(prior_mean)
+        self.prior_var = float(prior_var)
+        self.last_mse = None
+        self._ws = {}
+
+    # -- autograd path (any differentiable network) --
+    def __call__(self, params, *_):
+        X, Y = self.x_placeholder.value, self.y_placeholder.value
+        nll, mse = self.negative_log_likelihood(params, X, Y)
+        self.last_mse = mse.detach()
+        return nll
+
+    def negative_log_likelihood(self, params, X, Y):
+        dtype = params[0].dtype
+        out = mlp_forward(params, X)
+        f_mean = out[:, 0].reshape(-1, 1)
+        f_log_var = out[:, 1].reshape(-1, 1)
+        f_var_inv = 1.0 / (torch.exp(f_log_var) + 1e-16)
+        mse = torch.square(Y - f_mean)
+        log_like = torch.sum(torch.sum(-mse * (0.5 * f_var_inv) - 0.5 * f_log_var, dim=1))
+        log_like = log_like / self.batch_size
+        log_like = log_like + log_variance_prior_log_like(
+            f_log_var, mean=self.prior_mean, var=self.prior_var, dtype=dtype) / self.n_examples
+        log_like = log_like + weight_prior_log_like(params, wdecay=self.wdecay, dtype=dtype) / self.n_examples
+        return -log_like, torch.mean(mse)
+
+    # -- fused analytic path (MLP): gradients land in the arena --
+    def _buffers(self, params, B):
+        key = (B, params[0].dtype, params[0].device)
+        ws = self._ws.get(key)
+        if ws is None:
+            n_layers = (len(params) - 1) // 2
+            widths = [params[2 * l].shape[1] for l in range(n_layers)]
+            mk = lambda w: torch.empty(B, w, dtype=params[0].dtype, device=params[0].device)
+            ws = {"h": [mk(w) for w in widths], "d": [mk(w) for w in widths]}
+            self._ws = {key: ws}
+        return ws
+
+    @torch.no_grad()
+    def cost_and_grad(self, params, grad_views):
+        X, Y = self.x_placeholder.value, self.y_placeholder.value
+        B = X.shape[0]
+        n_layers = (len(params) - 1) // 2
+        ws = self._buffers(params, B)
+        hs, ds = ws["h"], ws["d"]
+        # forward, activations kept for the backward pass
+        h = X
+        for l in range(n_layers):
+            torch.addmm(params[2 * l + 1], h, params[2 * l], out=hs[l])
+            if l < n_layers - 1:
+                torch.tanh_(hs[l])
+            h = hs[l]
+        mean = hs[-1]
+        s = params[-1].reshape(())
+        es = torch.exp(s)
+        inv = 1.0 / (es + 1e-16)
+        resid = Y - mean
+        sq = resid * resid
+        sse = sq.sum()
+        n_params = float(sum(p.numel() for p in params))
+        wp_den = n_params + (2e-16 + 1e-16)                      # safe_divide, n_params > 0
+        lvp_den = 2.0 * self.prior_var + (2e-16 + 1e-16)
+        ln_mean = math.log(self.prior_mean)
+        sumsq = torch.zeros((), dtype=params[0].dtype, device=params[0].device)
+        for p in params:
+            sumsq = sumsq + (p * p).sum()
+        log_like = (-(sse * (0.5 * inv)) - 0.5 * s * B) / self.batch_size
+        lvp = -(s - ln_mean) ** 2 / lvp_den - 0.5 * math.log(self.prior_var)
+        wp = (-0.5 * self.wdecay) * sumsq / wp_den
+        cost = -(log_like + lvp / self.n_examples + wp / self.n_examples)
+        self.last_mse = sse / sq.numel()
+        # backward
+        prior_coef = self.wdecay / (wp_den * self.n_examples)    # d cost/d theta_j of the weight prior = coef * theta_j
+        # d cost / d s
+        ds_ = -((sse * (0.5 * es * inv * inv) - 0.5 * B) / self.batch_size
+                + (-2.0 * (s - ln_mean) / lvp_den) / self.n_examples) + prior_coef * s
+        grad_views[-1].copy_(ds_.reshape(grad_views[-1].shape))
+        # d cost / d mean
+        torch.mul(resid, -(inv / self.batch_size), out=ds[-1])
+        for l in range(n_layers - 1, -1, -1):
+            h_in = X if l == 0 else hs[l - 1]
+            W, b = params[2 * l], params[2 * l + 1]
+            # gW = h_in^T delta + coef * W   (prior folded into the GEMM epilogue)
+            torch.addmm(W, h_in.t(), ds[l], beta=prior_coef, alpha=1.0, out=grad_views[2 * l])
+            torch.sum(ds[l], dim=0, out=grad_views[2 * l + 1])
+            grad_views[2 * l + 1].add_(b, alpha=prior_coef)
+            if l > 0:
+                torch.mm(ds[l], W.t(), out=ds[l - 1])
+                # tanh': (1 - h^2)
+                ds[l - 1].addcmul_(ds[l - 1] * hs[l - 1], hs[l - 1], value=-1.0)
+        return cost
+
+
+# ------------------------------------------------------------------ model driver
+
+class BayesianNeuralNetwork(object):
+    """BNN whose weights are sampled with SG-MCMC (constructor keywords and
+    defaults as ``bayesian_neural_network.py:147-156``; ``session`` selects the
+    device or is ignored; ``get_net`` is replaced by ``hidden`` widths of a tanh MLP,
+    default 3x50)."""
+
+    def __init__(self, session=None, sampling_method=Sampler.SGHMC,
+                 get_net=get_default_net,
+                 batch_generator=generate_batches,
+                 batch_size=20,
+                 stepsize_schedule=ConstantStepsizeSchedule(np.sqrt(1e-4)),
+                 n_nets=100, n_iters=50000,
+                 burn_in_steps=1000, sample_steps=100,
+                 normalize_input=True, normalize_output=True,
+                 seed=None, dtype=torch.float64, hidden=(50, 50, 50), **sampler_kwargs):
+        # same sanity checks as :241-262
+        assert isinstance(n_nets, int)
+        assert isinstance(n_iters, int)
+        assert isinstance(burn_in_steps, int)
+        assert isinstance(sample_steps, int)
+        assert isinstance(batch_size, int)
+        from pysgmcmc_amd.samplers.base_classes import as_torch_dtype
+        self._torch_dtype = as_torch_dtype(dtype)
+        assert n_nets > 0
+        assert n_iters > 0
+        assert burn_in_steps >= 0
+        assert sample_steps > 0
+        assert batch_size > 0
+        assert callable(get_net)
+        assert callable(batch_generator)
+        assert hasattr(stepsize_schedule, "update")
+        assert hasattr(stepsize_schedule, "__next__")
+        if not Sampler.is_supported(sampling_method):
+            raise ValueError(
+                "'BayesianNeuralNetwork.__init__' received unsupported input "
+                "for parameter 'sampling_method'. Input was: {input}.\n"
+                "Supported sampling methods are enumerated in "
+                "'Sampler' enum type.".format(input=sampling_method)
+            )
+        self.sampling_method = sampling_method
+        self.stepsize_schedule = stepsize_schedule
+        self.get_net = get_net
+        self.batch_generator = batch_generator
+        self.normalize_input = normalize_input
+        self.normalize_output = normalize_output
+        self.n_nets = n_nets
+        self.n_iters = n_iters
+        self.batch_size = batch_size
+        self.sampler_kwargs = sampler_kwargs
+        self.burn_in_steps = burn_in_steps
+        self.sample_steps = sample_steps
+        self.samples = deque(maxlen=n_nets)
+        self.seed = seed
+        self.dtype = dtype
+        self.session = session
+        self.hidden = tuple(hidden)
+        self.is_trained = False
+        # use the analytic-backward cost path (gradients straight into the arena)
+        self.fused_cost = True
+
+    def _device(self):
+        if isinstance(self.session, (torch.device, str)):
+            return torch.device(self.session)
+        return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+    def train(self, X, y, *args, **kwargs):
+        """Sample ``n_nets`` networks from the posterior given data ``X (N, D)``, ``y (N,)``
+        (loop semantics of ``bayesian_neural_network.py:391-533``, including the
+        ``iteration_index <= burn_in_steps`` off-by-one at :514)."""
+        assert X.ndim == 2 and X.shape[0] == y.shape[0]
+        start_time = time()
+        self.X, self.y = X, y
+        if self.normalize_input:
+            self.X, self.x_mean, self.x_std = zero_mean_unit_var_normalization(self.X)
+        if self.normalize_output:
+            self.y, self.y_mean, self.y_std = zero_mean_unit_var_normalization(self.y)
+        n_datapoints, n_inputs = X.shape
+        device = self._device()
+        self.X_Minibatch = Placeholder(dtype=self._torch_dtype, shape=(None, n_inputs), name="X_Minibatch", device=device)
+        self.Y_Minibatch = Placeholder(dtype=self._torch_dtype, name="Y_Minibatch", device=device)
+
+        self.network_params = init_mlp_params(n_inputs, hidden=self.hidden, seed=self.seed,
+                                              dtype=self._torch_dtype, device=device)
+        names = []
+        for l in range(len(self.hidden) + 1):
+            names += ["fc_layer_%d/kernel:0" % (l + 1), "fc_layer_%d/bias:0" % (l + 1)]
+        names.append("output_bias:0")
+        for p, name in zip(self.network_params, names):
+            p.name = name
+        self.cost = BNNCost(self.X_Minibatch, self.Y_Minibatch, self.batch_size, n_datapoints)
+        cost_fun = self.cost
+        if not self.fused_cost:
+            cost_fun = lambda params, *_: self.cost(params)   # hides cost_and_grad -> autograd path
+        self.samples.clear()
+
+        self.sampler_kwargs.update({
+            "params": self.network_params,
+            "cost_fun": cost_fun,
+            "batch_generator": self.batch_generator(
+                x=self.X, x_placeholder=self.X_Minibatch,
+                y=self.y, y_placeholder=self.Y_Minibatch,
+                batch_size=self.batch_size,
+                seed=self.seed
+            ),
+            "session": device,
+            "seed": self.seed,
+            "dtype": self.dtype,
+            "stepsize_schedule": self.stepsize_schedule,
+        })
+        if Sampler.is_burn_in_mcmc(self.sampling_method):
+            self.sampler_kwargs.update({
+                "scale_grad": n_datapoints,
+                "burn_in_steps": self.burn_in_steps,
+            })
+        self.sampler = Sampler.get_sampler(self.sampling_method, **self.sampler_kwargs)
+        # samples are kept on the device; no per-step D2H copy of all parameters
+        self.sampler.sample_format = "view"
+        X_full = torch.as_tensor(self.X, dtype=self._torch_dtype, device=device)
+        Y_full = torch.as_tensor(self.y, dtype=self._torch_dtype, device=device).reshape(-1, 1)
+
+        logging.info("Starting sampling")
+
+        def log_full_training_error(iteration_index, is_sampling):
+            with torch.no_grad():
+                total_nll, total_mse = self.cost.negative_log_likelihood(self.network_params, X_full, Y_full)
+            seconds_elapsed = time() - start_time
+            if is_sampling:
+                logging.info("Iter {:8d} : NLL = {:.4e} MSE = {:.4e} "
+                             "Time = {:5.2f}".format(iteration_index, float(total_nll), float(total_mse),
+                                                     seconds_elapsed))
+            else:
+                logging.info("Iter {:8d} : NLL = {:.4e} MSE = {:.4e} "
+                             "Samples = {} Time = {:5.2f}".format(iteration_index, float(total_nll),
+                                                                  float(total_mse), len(self.samples),
+                                                                  seconds_elapsed))
+
+        logging_intervals = {"burn-in": 512, "sampling": self.sample_steps}
+        sample_chain = itertools.islice(self.sampler, self.n_iters)
+        for iteration_index, (parameter_values, _) in enumerate(sample_chain):
+            burning_in = iteration_index <= self.burn_in_steps
+            if burning_in and iteration_index % logging_intervals["burn-in"] == 0:
+                log_full_training_error(iteration_index=iteration_index, is_sampling=False)
+            if not burning_in and iteration_index % logging_intervals["sampling"] == 0:
+                log_full_training_error(iteration_index=iteration_index, is_sampling=True)
+                self.samples.append([v.clone() for v in parameter_values])
+                if len(self.samples) == self.n_nets:
+                    break
+        self.is_trained = True
+
+    def compute_network_output(self, params, input_data):
+        """Network output ``(N, 2)`` for one set of sampled weights (``:535-557``)."""
+        dev = params[0].device if isinstance(params[0], torch.Tensor) else self._device()
+        x = torch.as_tensor(input_data, dtype=self._torch_dtype, device=dev)
+        ps = [torch.as_tensor(p, dtype=self._torch_dtype, device=dev) for p in params]
+        with torch.no_grad():
+            return mlp_forward(ps, x).cpu().numpy()
+
+    def predict(self, X_test, return_individual_predictions=False, *args, **kwargs):
+        """Predictive mean and variance at ``X_test (N, D)`` (``:560-630``)."""
+        assert X_test.ndim == 2
+        if not self.is_trained:
+            raise ValueError(
+                "Calling `bnn.predict()` on an untrained "
+                "Bayesian Neural Network 'bnn' is not supported! "
+                "Please call `bnn.train()` before calling `bnn.predict()`"
+            )
+        if self.normalize_input:
+            X_, _, _ = zero_mean_unit_var_normalization(X_test, self.x_mean, self.x_std)
+        else:
+            X_ = X_test
+        f_out, theta_noise = [], []
+        for sample in self.samples:
+            out = self.compute_network_output(params=sample, input_data=X_)
+            f_out.append(out[:, 0])
+            theta_noise.append(np.exp(out[:, 1]))
+        f_out = np.asarray(f_out)
+        theta_noise = np.asarray(theta_noise)
+        if return_individual_predictions:
+            if self.normalize_output:
+                f_out = zero_mean_unit_var_unnormalization(f_out, self.y_mean, self.y_std)
+                theta_noise *= self.y_std ** 2
+            return f_out, theta_noise
+        mean_prediction = np.mean(f_out, axis=0)
+        variance_prediction = np.mean((f_out - mean_prediction) ** 2, axis=0)
+        if self.normalize_output:
+            mean_prediction = zero_mean_unit_var_unnormalization(mean_prediction, self.y_mean, self.y_std)
+            variance_prediction *= self.y_std ** 2
+        return mean_prediction, variance_prediction
