@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--rhat-every", type=int, default=100, help="R-hat exchange cadence (steps), N > 1")
     ap.add_argument("--moments-every", type=int, default=10, help="Welford moments cadence (steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-update-only", action="store_true", help="skip the kernel-only loops (for rocprof runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline leg")
     return ap.parse_args()
 
@@ -182,23 +183,19 @@ def main():
     sampler.sample_format = "view"                             # no D2H copy of 40 MB per sample
     n = sampler.arena.n
     timer = KernelTimer(sampler)
-    mean = torch.zeros(n, dtype=torch.float32, device=dev)
-    m2 = torch.zeros(n, dtype=torch.float32, device=dev)
+    from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, cross_chain_rhat
+    moments = ChainMoments(n, dev)
     pack = torch.empty(3 * n, dtype=torch.float32, device=dev)
     rhat = torch.empty(n, dtype=torch.float32, device=dev)
-    n_moments = [0]
     rhat_summary = [None]
 
     def one_step(i):
         next(sampler)
         if (i + 1) % args.moments_every == 0:
-            n_moments[0] += 1
-            kernels.moments_update(sampler.arena.row("theta"), mean, m2, n_moments[0])
-        if world > 1 and (i + 1) % args.rhat_every == 0 and n_moments[0] >= 2:
-            kernels.rhat_pack(mean, m2, n_moments[0], pack)
-            dist.all_reduce(pack)
-            kernels.rhat_finish(pack, n, world, n_moments[0], rhat)
-            rhat_summary[0] = kernels.summary(rhat)
+            moments.update(sampler.arena.row("theta"))                 # K4 Welford, every chain
+        if world > 1 and (i + 1) % args.rhat_every == 0 and moments.count >= 2:
+            # the only exchange on the path: ONE all-reduce of 3P floats over RCCL/xGMI
+            _, rhat_summary[0] = cross_chain_rhat(moments, pack=pack, rhat=rhat)
 
     def fence():
         torch.cuda.synchronize()
@@ -210,9 +207,7 @@ def main():
         one_step(i)
     assert args.warmup < 8 or not sampler.is_burning_in
     frozen_phase = not sampler._adapting
-    n_moments[0] = 0
-    mean.zero_()
-    m2.zero_()
+    moments.reset()
     timer.enabled = True
     fence()
     t0 = time.perf_counter()
@@ -255,10 +250,10 @@ def main():
                          "launches_timed": len(timer.pairs), "timing": "hipEvent pairs around each launch, in-pipeline"},
         }
         if rhat_summary[0] is not None:
-            s = rhat_summary[0].cpu().numpy()
-            line["rhat"] = {"mean": round(float(s[0] / n), 4), "max": round(float(s[3]), 4)}
+            line["rhat"] = {k: round(v, 4) for k, v in rhat_summary[0].items()}
         if world == 1:
-            line["update_only"] = update_only(sampler)
+            if not args.no_update_only:
+                line["update_only"] = update_only(sampler)
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(line))

@@ -596,7 +596,12 @@ int hip_fail(hipError_t e, const char *what)
 std::atomic<int> g_block_threads{256};
 std::atomic<int> g_qpt{1};
 std::atomic<int> g_max_blocks{1 << 20};
-std::atomic<int> g_nt{0};
+std::atomic<int> g_nt{2};                 // 0 = plain, 1 = nt, 2 = auto by working-set size
+// Above this many bytes touched per launch the arrays cannot stay in the 256 MiB
+// Infinity Cache between steps and nt accesses win (+6..7 % at 1.2 GB); below it
+// plain accesses win (the cache holds part of the working set across steps:
+// -5..-12 % with nt at 240 MB and 480 MB). Measured on MI355X, gpurun_out/tune_*.txt.
+constexpr size_t NT_AUTO_BYTES = (size_t)768 << 20;
 
 inline bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -643,15 +648,17 @@ int launch_scalar(const Op &op, size_t n, hipStream_t st)
 // f32 ops honour the (quads_per_thread, nontemporal) knobs; f64 ops (a quad is
 // already 32 B per lane per array) use one quad per lane.
 template <typename Op>
-int launch(const Op &op, size_t n, bool vec_ok, hipStream_t st)
+int launch(const Op &op, size_t n, bool vec_ok, size_t bytes_per_elem, hipStream_t st)
 {
     if (n == 0) return 0;
     if (!vec_ok) return launch_scalar<Op>(op, n, st);
+    const int nt_cfg = g_nt.load();
+    const bool nt = nt_cfg == 2 ? (n * bytes_per_elem > NT_AUTO_BYTES) : (nt_cfg != 0);
     if (sizeof(typename Op::real) == 8) {
-        return g_nt.load() ? launch_vec<Op, 1, true>(op, n, st) : launch_vec<Op, 1, false>(op, n, st);
+        return nt ? launch_vec<Op, 1, true>(op, n, st) : launch_vec<Op, 1, false>(op, n, st);
     }
     const int qpt = g_qpt.load();
-    if (g_nt.load()) {
+    if (nt) {
         if (qpt >= 4) return launch_vec<Op, 4, true>(op, n, st);
         if (qpt == 2) return launch_vec<Op, 2, true>(op, n, st);
         return launch_vec<Op, 1, true>(op, n, st);
@@ -680,7 +687,7 @@ int sghmc_step(T *theta, T *V, const T *grad, T *tau, T *g, T *v_hat, T *minv, T
 #define SGHMC_GO(AD, INJ)                                                                              \
     {                                                                                                  \
         SghmcOp<T, AD, INJ> op{theta, V, grad, tau, g, v_hat, minv, r, xi, e2, c1, c3, e4, mdecay, nk}; \
-        return launch(op, n, vec_ok, st);                                                              \
+        return launch(op, n, vec_ok, sizeof(T) * ((AD ? 12 : 6) + (INJ ? 1 : 0)), st);                 \
     }
     if (adapt) { if (xi) SGHMC_GO(true, true) else SGHMC_GO(true, false) }
     else { if (xi) SGHMC_GO(false, true) else SGHMC_GO(false, false) }
@@ -704,7 +711,7 @@ int sgld_step(T *theta, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, si
 #define SGLD_GO(AD, INJ)                                                                            \
     {                                                                                               \
         SgldOp<T, AD, INJ> op{theta, grad, tau, g, v_hat, minv, r, xi, eps, A, a_eff, two_eps, sg_den, nk}; \
-        return launch(op, n, vec_ok, st);                                                           \
+        return launch(op, n, vec_ok, sizeof(T) * ((AD ? 10 : 4) + (INJ ? 1 : 0)), st);              \
     }
     if (adapt) { if (xi) SGLD_GO(true, true) else SGLD_GO(true, false) }
     else { if (xi) SGLD_GO(false, true) else SGLD_GO(false, false) }
@@ -723,10 +730,10 @@ int rsghmc_step(T *theta, T *p, const T *grad, size_t n, T eps, T mass, T c, T D
     bool vec_ok = aligned16(theta) && aligned16(p) && aligned16(grad) && aligned16(xi);
     if (xi) {
         RsghmcOp<T, false, true> op{theta, p, grad, xi, eps, mass, D, m2c2, nscale, nk};
-        return launch(op, n, vec_ok, st);
+        return launch(op, n, vec_ok, sizeof(T) * 6, st);
     }
     RsghmcOp<T, false, false> op{theta, p, grad, xi, eps, mass, D, m2c2, nscale, nk};
-    return launch(op, n, vec_ok, st);
+    return launch(op, n, vec_ok, sizeof(T) * 5, st);
 }
 
 template <typename T>
@@ -784,7 +791,10 @@ int sgmcmc_set_launch_config(int block_threads, int quads_per_thread, int max_bl
         if (max_blocks < 1) return fail(SGMCMC_EINVAL, "max_blocks must be >= 1");
         g_max_blocks.store(max_blocks);
     }
-    if (nontemporal >= 0) g_nt.store(nontemporal ? 1 : 0);
+    if (nontemporal >= 0) {
+        if (nontemporal > 2) return fail(SGMCMC_EINVAL, "nontemporal must be 0 (off), 1 (on) or 2 (auto)");
+        g_nt.store(nontemporal);
+    }
     return 0;
 }
 int sgmcmc_get_launch_config(int *block_threads, int *quads_per_thread, int *max_blocks, int *nontemporal)
@@ -843,14 +853,14 @@ int sgmcmc_philox_normal_f32(float *out, size_t n, uint64_t seed, uint64_t step,
     if (n == 0) return 0;
     if (!out) return fail(SGMCMC_EINVAL, "philox_normal: out is NULL");
     NormalFillOp<float> op{out, make_key(seed, step, step_dev)};
-    return launch(op, n, aligned16(out), static_cast<hipStream_t>(stream));
+    return launch(op, n, aligned16(out), sizeof(*out), static_cast<hipStream_t>(stream));
 }
 int sgmcmc_philox_normal_f64(double *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
 {
     if (n == 0) return 0;
     if (!out) return fail(SGMCMC_EINVAL, "philox_normal: out is NULL");
     NormalFillOp<double> op{out, make_key(seed, step, step_dev)};
-    return launch(op, n, aligned16(out), static_cast<hipStream_t>(stream));
+    return launch(op, n, aligned16(out), sizeof(*out), static_cast<hipStream_t>(stream));
 }
 int sgmcmc_philox_bits_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
 {
@@ -867,14 +877,14 @@ int sgmcmc_moments_update_f32(const float *theta, float *mean, float *m2, size_t
     if (n == 0) return 0;
     if (!theta || !mean || !m2 || count == 0) return fail(SGMCMC_EINVAL, "moments_update: NULL argument or count == 0");
     MomentsOp<float> op{theta, mean, m2, 1.0f / (float)count};
-    return launch(op, n, aligned16(theta) && aligned16(mean) && aligned16(m2), static_cast<hipStream_t>(stream));
+    return launch(op, n, aligned16(theta) && aligned16(mean) && aligned16(m2), 5 * sizeof(*theta), static_cast<hipStream_t>(stream));
 }
 int sgmcmc_moments_update_f64(const double *theta, double *mean, double *m2, size_t n, uint64_t count, sgmcmc_stream_t stream)
 {
     if (n == 0) return 0;
     if (!theta || !mean || !m2 || count == 0) return fail(SGMCMC_EINVAL, "moments_update: NULL argument or count == 0");
     MomentsOp<double> op{theta, mean, m2, 1.0 / (double)count};
-    return launch(op, n, aligned16(theta) && aligned16(mean) && aligned16(m2), static_cast<hipStream_t>(stream));
+    return launch(op, n, aligned16(theta) && aligned16(mean) && aligned16(m2), 5 * sizeof(*theta), static_cast<hipStream_t>(stream));
 }
 
 int sgmcmc_rhat_pack_f32(const float *mean, const float *m2, size_t n, uint64_t count, float *out3, sgmcmc_stream_t stream)

@@ -63,3 +63,42 @@ def install(monkeypatch):
     monkeypatch.setattr(kernels, "sgld_step", sgld_step)
     monkeypatch.setattr(kernels, "rsghmc_step", rsghmc_step)
     return calls
+
+
+# ---- diagnostics kernels (numpy stand-ins for K4 / R-hat pack+finish / K6) ----
+
+def moments_update(theta, mean, m2, count):
+    O.c_moments_update(theta.detach().numpy(), mean.numpy(), m2.numpy(), int(count))
+
+
+def rhat_pack(mean, m2, count, out3):
+    n = mean.numel()
+    o = out3.numpy()
+    mu = mean.numpy()
+    o[:n] = mu
+    o[n:2 * n] = mu * mu
+    o[2 * n:] = m2.numpy() * np.float32(1.0 / (count - 1))
+
+
+def rhat_finish(sum3, n, m_chains, count, rhat):
+    s = sum3.numpy().astype(np.float64)
+    s_mean, s_sq, s_var = s[:n], s[n:2 * n], s[2 * n:]
+    m, cnt = float(m_chains), float(count)
+    W = s_var / m
+    B = cnt * ((s_sq - s_mean * s_mean / m) / (m - 1.0))
+    rhat.numpy()[:] = np.sqrt((W * ((cnt - 1.0) / cnt) + B / cnt) / W).astype(np.float32)
+
+
+def summary(x, out4=None, workspace=None):
+    a = x.detach().numpy().astype(np.float64)
+    return torch.tensor([a.sum(), (a * a).sum(), a.min(), a.max()], dtype=torch.float64)
+
+
+def install_diagnostics(monkeypatch=None):
+    from pysgmcmc_amd import kernels
+    for name, fn in (("moments_update", moments_update), ("rhat_pack", rhat_pack),
+                     ("rhat_finish", rhat_finish), ("summary", summary)):
+        if monkeypatch is not None:
+            monkeypatch.setattr(kernels, name, fn)
+        else:
+            setattr(kernels, name, fn)

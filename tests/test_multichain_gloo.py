@@ -1,0 +1,96 @@
+"""The N > 1 path on CPU: world_size-2 `gloo` process group, one chain per rank, no
+collective on the data path, ONE all-reduce for R-hat and one all-gather for ESS.
+The HIP kernels are replaced by the oracle shim in each rank (no GPU here); what is
+tested is the sharding, the exchange protocol and the formulas."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_shim
+    from pysgmcmc_amd import kernels
+    kernels.sghmc_step = oracle_shim.sghmc_step
+    oracle_shim.install_diagnostics()
+    from itertools import islice
+    from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, cross_chain_rhat, effective_sample_sizes
+    from pysgmcmc_amd.samplers import SGHMCSampler
+    from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+
+    n = 37
+    # independent chains: same target, seed = base + rank, over-dispersed start per chain
+    x = torch.full((n,), 3.0 * (rank - 0.5), dtype=torch.float32)
+    s = SGHMCSampler(params=[x], cost_fun=lambda p: 0.5 * (p[0] ** 2).sum(), burn_in_steps=50, session="cpu",
+                     stepsize_schedule=ConstantStepsizeSchedule(0.1), dtype=torch.float32, seed=100 + rank)
+    s.sample_format = "view"
+    mom = ChainMoments(n, "cpu")
+    kept, trace = [], []
+    for t, (sample, cost) in enumerate(islice(s, 650)):
+        if t >= 50 and t % 3 == 0:
+            mom.update(s.arena.row("theta"))
+            kept.append(sample.clone().numpy())
+            trace.append([float(cost), float(sample[0]), float(sample[1])])
+    rhat, summ = cross_chain_rhat(mom)
+    ess = effective_sample_sizes(torch.tensor(trace, dtype=torch.float32))
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), kept=np.array(kept), rhat=rhat.numpy(),
+             rhat_mean=summ["mean"], rhat_max=summ["max"], ess=np.array(ess), trace=np.array(trace),
+             final=s.arena.row("theta").numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_chains_rhat_and_ess_over_gloo(tmp_path, oracle):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(world)]
+    # chains are independent (different seeds and starts) ...
+    assert not np.array_equal(r[0]["final"], r[1]["final"])
+    # ... every rank ends with the same R-hat, equal to the oracle's on the gathered chains
+    assert np.array_equal(r[0]["rhat"], r[1]["rhat"])
+    chains = np.stack([r[0]["kept"], r[1]["kept"]])                    # (m, n_samples, P)
+    want = oracle.gelman_rubin(chains)
+    assert np.allclose(r[0]["rhat"], want, rtol=2e-3, atol=1e-4)
+    assert np.isclose(r[0]["rhat_mean"], want.mean(), rtol=2e-3) and np.isclose(r[0]["rhat_max"], want.max(), rtol=2e-3)
+    assert 0.9 < want.mean() < 1.3
+    # ESS: identical on both ranks, equal to the oracle's variogram estimate
+    assert np.array_equal(r[0]["ess"], r[1]["ess"])
+    traces = np.stack([r[0]["trace"], r[1]["trace"]])                   # (m, n, K)
+    for k in range(traces.shape[2]):
+        want_ess = oracle.effective_n(traces[:, :, k])
+        assert abs(int(r[0]["ess"][k]) - want_ess) <= max(2, 0.01 * want_ess), (k, r[0]["ess"][k], want_ess)
+
+
+def test_effective_n_and_gelman_rubin_match_oracle(oracle):
+    from pysgmcmc_amd.diagnostics.sampler_diagnostics import effective_n, gelman_rubin
+    rng = np.random.default_rng(0)
+    iid = rng.normal(size=(4, 1500))
+    ar = np.zeros((3, 1500))
+    for t in range(1, 1500):
+        ar[:, t] = 0.8 * ar[:, t - 1] + rng.normal(size=3)
+    for x in (iid, ar):
+        assert abs(effective_n(torch.tensor(x)) - oracle.effective_n(x)) <= 1
+    assert 50 < effective_n(torch.tensor(ar[:1])) < 600           # one chain: B = 0, still defined
+    ch = rng.normal(size=(3, 200, 11)) + rng.normal(size=(3, 1, 11)) * 0.3
+    assert np.allclose(gelman_rubin(torch.tensor(ch)).numpy(), oracle.gelman_rubin(ch), rtol=1e-12)
