@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rhat-every", type=int, default=100, help="R-hat exchange cadence (steps), N > 1")
     ap.add_argument("--moments-every", type=int, default=10, help="Welford moments cadence (steps)")
+    ap.add_argument("--eager", action="store_true", help="step eagerly instead of replaying one hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-update-only", action="store_true", help="skip the kernel-only loops (for rocprof runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline leg")
@@ -79,19 +80,34 @@ class KernelTimer(object):
     """HIP-event timing of the fused update launch, on the stream it is launched on."""
 
     def __init__(self, sampler):
+        from pysgmcmc_amd import kernels
         self.pairs = []
         self.enabled = False
-        inner = sampler._kernel_step
+        inner = kernels.sghmc_step                 # ONE launch: the fused update kernel (K1)
 
-        def timed(eps, xi):
+        def timed(*a, **kw):
             if not self.enabled:
-                return inner(eps, xi)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            inner(eps, xi)
-            b.record()
-            self.pairs.append((a, b))
-        sampler._kernel_step = timed
+                return inner(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            inner(*a, **kw)
+            e1.record()
+            self.pairs.append((e0, e1))
+        kernels.sghmc_step = timed
+
+    @staticmethod
+    def event_pair_overhead_us(reps=200):
+        """Elapsed time of an EMPTY event pair on the same stream: the fixed cost every bracketed
+        launch carries (barrier packets + dispatch latency). Reported next to the raw numbers."""
+        torch.cuda.synchronize()
+        pairs = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        return float(np.median([a.elapsed_time(b) for a, b in pairs])) * 1e3
 
     def mean_us(self):
         return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) * 1e3 if self.pairs else None
@@ -181,6 +197,7 @@ def main():
     from pysgmcmc_amd import kernels
     sampler = build_chain(dev, rank)
     sampler.sample_format = "view"                             # no D2H copy of 40 MB per sample
+    sampler.use_hip_graph = not args.eager
     n = sampler.arena.n
     timer = KernelTimer(sampler)
     from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, cross_chain_rhat
@@ -224,9 +241,10 @@ def main():
 
     if rank == 0:
         mode = "sghmc_frozen" if frozen_phase else "sghmc_adapt"
-        k_us = timer.mean_us()
+        k_us = timer.mean_us()                      # raw hipEvent bracket, includes the event-pair overhead
+        ev_us = timer.event_pair_overhead_us()
         alg_bytes = BYTES_PER_PARAM[mode] * n
-        achieved = alg_bytes / (k_us * 1e-6) / 1e9
+        achieved = alg_bytes / (k_us * 1e-6) / 1e9  # conservative: computed from the RAW bracket
         line = {
             "metric": "MCMC samples/sec + fused-update HBM GB/s (% roofline), BNN 10M params",
             "value": round(world * args.steps / elapsed, 2),
@@ -240,14 +258,20 @@ def main():
                                    "1 chain per GPU" % (n, BATCH),
                        "params": n, "batch": BATCH, "chains": world,
                        "rhat_every": args.rhat_every if world > 1 else None,
-                       "moments_every": args.moments_every, "launch": kernels.get_launch_config()},
+                       "moments_every": args.moments_every, "hip_graph": bool(sampler.use_hip_graph),
+                       "launch": kernels.get_launch_config()},
             "roofline": {"bound": "hbm", "kernel": "stream_quads_vec<SghmcOp<float,%s,false>>" %
                          ("false" if frozen_phase else "true"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "us_per_launch_mean": round(k_us, 2), "us_per_launch_median": round(timer.median_us(), 2),
-                         "launches_timed": len(timer.pairs), "timing": "hipEvent pairs around each launch, in-pipeline"},
+                         "launches_timed": len(timer.pairs),
+                         "us_event_pair_overhead": round(ev_us, 2),
+                         "achieved_minus_event_overhead": round(alg_bytes / ((k_us - ev_us) * 1e-6) / 1e9, 1),
+                         "timing": "hipEvent pair around every launch of the timed region, in-pipeline (after the "
+                                   "GEMMs evicted part of the state from the Infinity Cache); rocprofv3 kernel-only "
+                                   "durations are in profiles/"},
         }
         if rhat_summary[0] is not None:
             line["rhat"] = {k: round(v, 4) for k, v in rhat_summary[0].items()}

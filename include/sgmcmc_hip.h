@@ -73,48 +73,63 @@ int sgmcmc_get_launch_config(int *block_threads, int *quads_per_thread, int *max
  *              (tau,g,v_hat,r may be NULL)
  *   eps, scale_grad, mdecay: the constructor/schedule scalars; eps_scaled and the
  *              noise-scale constants are derived inside, in the dtype.
+ *   grad_decay: the kernel uses grad[i] + grad_decay * theta[i] as the gradient (formed in
+ *              registers from values it already loads): a Gaussian weight-prior / weight-decay
+ *              term of the cost need not be added by the gradient producer. 0 = off (exactly
+ *              the reference's update).
  *   xi:   NULL -> Philox(seed, step); else injected N(0,1) draws, n elements.
  *   step: the sampler's n_iterations at the time of the call.
+ *   stats_ws:  NULL, or a device workspace of sgmcmc_step_stats_workspace_bytes(n) bytes: the
+ *              kernel also reduces, from the values it already holds in registers (wave shuffles
+ *              -> LDS -> ONE 32-byte partial per block in stats_ws), the sums {theta'^2, V'^2
+ *              (p'^2; 0 for SGLD), minv, minv^2}. sgmcmc_step_stats_finish() then adds the
+ *              partials in a fixed order into 4 doubles. Bit-reproducible for a given launch
+ *              geometry; costs no extra pass over HBM.
  *   step_dev: NULL, or a DEVICE counter added to `step` when the kernel starts.
  *              A hipGraph replays identical arguments; a graph-captured chain
  *              advances its noise stream with sgmcmc_counter_add_u64 on it.        */
 int sgmcmc_sghmc_step_f32(float *theta, float *V, const float *grad,
                           float *tau, float *g, float *v_hat, float *minv, float *r,
-                          size_t n, float eps, float scale_grad, float mdecay, int adapt,
+                          size_t n, float eps, float scale_grad, float mdecay, float grad_decay, int adapt,
                           const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        sgmcmc_stream_t stream);
+        void *stats_ws, sgmcmc_stream_t stream);
 int sgmcmc_sghmc_step_f64(double *theta, double *V, const double *grad,
                           double *tau, double *g, double *v_hat, double *minv, double *r,
-                          size_t n, double eps, double scale_grad, double mdecay, int adapt,
+                          size_t n, double eps, double scale_grad, double mdecay, double grad_decay, int adapt,
                           const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        sgmcmc_stream_t stream);
+        void *stats_ws, sgmcmc_stream_t stream);
+
+size_t sgmcmc_step_stats_workspace_bytes(size_t n);
+/* K7 -- stats_out[0..3] (device doubles) = fixed-order sum of the per-block partials a step kernel left
+ * in stats_ws. One 1024-lane block.                                                               */
+int sgmcmc_step_stats_finish(const void *stats_ws, double *stats_out, sgmcmc_stream_t stream);
 
 /* K2 -- fused preconditioned SGLD step. Replaces pysgmcmc/samplers/sgld.py:149-211.
  *   adapt = 1: R{theta,grad,tau,g,v_hat} W{theta,tau,g,v_hat,minv}   40 B/param f32
  *   adapt = 0: R{theta,grad,minv} W{theta}                           16 B/param f32 */
 int sgmcmc_sgld_step_f32(float *theta, const float *grad,
                          float *tau, float *g, float *v_hat, float *minv, float *r,
-                         size_t n, float eps, float A, float scale_grad, int adapt,
+                         size_t n, float eps, float A, float scale_grad, float grad_decay, int adapt,
                          const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        sgmcmc_stream_t stream);
+        void *stats_ws, sgmcmc_stream_t stream);
 int sgmcmc_sgld_step_f64(double *theta, const double *grad,
                          double *tau, double *g, double *v_hat, double *minv, double *r,
-                         size_t n, double eps, double A, double scale_grad, int adapt,
+                         size_t n, double eps, double A, double scale_grad, double grad_decay, int adapt,
                          const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        sgmcmc_stream_t stream);
+        void *stats_ws, sgmcmc_stream_t stream);
 
 /* K3 -- fused relativistic SGHMC step, per element. Replaces
  * pysgmcmc/samplers/relativistic_sghmc.py:120-140. grad_cost = d cost / d theta
  * (the kernel negates it, as :100-103 differentiates -cost).
  * R{theta,p,grad} W{theta,p}                                         20 B/param f32 */
 int sgmcmc_rsghmc_step_f32(float *theta, float *p, const float *grad_cost, size_t n,
-                           float eps, float mass, float c, float D, float b_hat,
+                           float eps, float mass, float c, float D, float b_hat, float grad_decay,
                            const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        sgmcmc_stream_t stream);
+        void *stats_ws, sgmcmc_stream_t stream);
 int sgmcmc_rsghmc_step_f64(double *theta, double *p, const double *grad_cost, size_t n,
-                           double eps, double mass, double c, double D, double b_hat,
+                           double eps, double mass, double c, double D, double b_hat, double grad_decay,
                            const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        sgmcmc_stream_t stream);
+        void *stats_ws, sgmcmc_stream_t stream);
 
 /* K5 -- write the N(0,1) stream itself: out[i] = xi(seed, step, i). Replaces
  * tf.random_normal in pysgmcmc/samplers/base_classes.py:218-220 for callers that
@@ -157,6 +172,27 @@ int sgmcmc_rhat_finish_f32(const float *sum3, size_t n, int m_chains, uint64_t c
 size_t sgmcmc_summary_workspace_bytes(void);
 int sgmcmc_summary_f32(const float *x, size_t n, double *out4, void *workspace, sgmcmc_stream_t stream);
 int sgmcmc_summary_f64(const double *x, size_t n, double *out4, void *workspace, sgmcmc_stream_t stream);
+
+/* BNN cost path helpers (the gradient producer of the update path; replaces the TF graph of
+ * pysgmcmc/models/bayesian_neural_network.py:365-388 after the network's last GEMM).
+ * bnn_head: from the network mean output `mean[B]`, targets `y[B]`, the scalar log-variance
+ * parameter `log_var` and sum(theta^2) over all parameters (`theta_sumsq`, a device double, e.g.
+ * stats_out[0] of the previous step), computes in one launch: delta[B] = d NLL / d mean,
+ * cost_out = NLL (likelihood / batch_size + both priors / n_examples), grad_log_var_out = d NLL /
+ * d log_var and mse_out. All scalar outputs are device pointers. fold_prior_grad = 1 leaves the
+ * weight-prior gradient term (wdecay / (n_params * n_examples)) * theta out of grad_log_var_out
+ * because the caller passes it to the update kernel as grad_decay.
+ * tanh_backward: delta[i] *= 1 - h[i]^2.                                                       */
+int sgmcmc_bnn_head_f32(const float *mean, const float *y, const float *log_var, const double *theta_sumsq, size_t B,
+                        double batch_size, double n_examples, double n_params, double wdecay, double prior_mean,
+                        double prior_var, int fold_prior_grad, float *delta, float *cost_out, float *grad_log_var_out,
+                        float *mse_out, sgmcmc_stream_t stream);
+int sgmcmc_bnn_head_f64(const double *mean, const double *y, const double *log_var, const double *theta_sumsq, size_t B,
+                        double batch_size, double n_examples, double n_params, double wdecay, double prior_mean,
+                        double prior_var, int fold_prior_grad, double *delta, double *cost_out, double *grad_log_var_out,
+                        double *mse_out, sgmcmc_stream_t stream);
+int sgmcmc_tanh_backward_f32(float *delta, const float *h, size_t n, sgmcmc_stream_t stream);
+int sgmcmc_tanh_backward_f64(double *delta, const double *h, size_t n, sgmcmc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -60,13 +60,13 @@ def load_c():
     vp = ctypes.c_void_p
     for sfx, real in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
         f = getattr(lib, "oracle_sghmc_step_" + sfx)
-        f.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, real, real, real, ci, vp, u64, u64]
+        f.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, real, real, real, real, ci, vp, u64, u64]
         f.restype = ci
         f = getattr(lib, "oracle_sgld_step_" + sfx)
-        f.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, real, real, real, ci, vp, u64, u64]
+        f.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, real, real, real, real, ci, vp, u64, u64]
         f.restype = ci
         f = getattr(lib, "oracle_rsghmc_step_" + sfx)
-        f.argtypes = [vp, vp, vp, sz, real, real, real, real, real, vp, u64, u64]
+        f.argtypes = [vp, vp, vp, sz, real, real, real, real, real, real, vp, u64, u64]
         f.restype = ci
         f = getattr(lib, "oracle_moments_update_" + sfx)
         f.argtypes = [vp, vp, vp, sz, u64]
@@ -128,37 +128,37 @@ class CState(object):
         self.p = np.zeros(n, dt)     # relativistic momentum
 
 
-def c_sghmc_step(st, grad, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step=0):
+def c_sghmc_step(st, grad, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step=0, grad_decay=0.0):
     lib = load_c()
     grad = np.ascontiguousarray(grad, dtype=st.dtype).ravel()
     if xi is not None:
         xi = np.ascontiguousarray(xi, dtype=st.dtype).ravel()
     f = getattr(lib, "oracle_sghmc_step_" + _sfx(st.dtype))
     rc = f(_p(st.theta), _p(st.V), _p(grad), _p(st.tau), _p(st.g), _p(st.v_hat),
-           _p(st.minv), _p(st.r), st.n, eps, scale_grad, mdecay, int(adapt),
+           _p(st.minv), _p(st.r), st.n, eps, scale_grad, mdecay, grad_decay, int(adapt),
            _p(xi), seed, step)
     assert rc == 0
 
 
-def c_sgld_step(st, grad, eps, A, scale_grad, adapt, xi=None, seed=0, step=0):
+def c_sgld_step(st, grad, eps, A, scale_grad, adapt, xi=None, seed=0, step=0, grad_decay=0.0):
     lib = load_c()
     grad = np.ascontiguousarray(grad, dtype=st.dtype).ravel()
     if xi is not None:
         xi = np.ascontiguousarray(xi, dtype=st.dtype).ravel()
     f = getattr(lib, "oracle_sgld_step_" + _sfx(st.dtype))
     rc = f(_p(st.theta), _p(grad), _p(st.tau), _p(st.g), _p(st.v_hat),
-           _p(st.minv), _p(st.r), st.n, eps, A, scale_grad, int(adapt),
+           _p(st.minv), _p(st.r), st.n, eps, A, scale_grad, grad_decay, int(adapt),
            _p(xi), seed, step)
     assert rc == 0
 
 
-def c_rsghmc_step(st, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, step=0):
+def c_rsghmc_step(st, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, step=0, grad_decay=0.0):
     lib = load_c()
     grad_cost = np.ascontiguousarray(grad_cost, dtype=st.dtype).ravel()
     if xi is not None:
         xi = np.ascontiguousarray(xi, dtype=st.dtype).ravel()
     f = getattr(lib, "oracle_rsghmc_step_" + _sfx(st.dtype))
-    rc = f(_p(st.theta), _p(st.p), _p(grad_cost), st.n, eps, mass, c, D, b_hat,
+    rc = f(_p(st.theta), _p(st.p), _p(grad_cost), st.n, eps, mass, c, D, b_hat, grad_decay,
            _p(xi), seed, step)
     assert rc == 0
 

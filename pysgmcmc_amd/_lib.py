@@ -52,19 +52,25 @@ def _declare(lib):
     lib.sgmcmc_get_launch_config.restype = _ci
     for sfx, real in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
         f = getattr(lib, "sgmcmc_sghmc_step_" + sfx)
-        f.argtypes = [_vp] * 8 + [_sz, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp]
+        f.argtypes = [_vp] * 8 + [_sz, real, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_sgld_step_" + sfx)
-        f.argtypes = [_vp] * 7 + [_sz, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp]
+        f.argtypes = [_vp] * 7 + [_sz, real, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_rsghmc_step_" + sfx)
-        f.argtypes = [_vp] * 3 + [_sz, real, real, real, real, real, _vp, _u64, _u64, _vp, _vp]
+        f.argtypes = [_vp] * 3 + [_sz, real, real, real, real, real, real, _vp, _u64, _u64, _vp, _vp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_philox_normal_" + sfx)
         f.argtypes = [_vp, _sz, _u64, _u64, _vp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_moments_update_" + sfx)
         f.argtypes = [_vp, _vp, _vp, _sz, _u64, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_bnn_head_" + sfx)
+        f.argtypes = [_vp, _vp, _vp, _vp, _sz] + [ctypes.c_double] * 6 + [_ci, _vp, _vp, _vp, _vp, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_tanh_backward_" + sfx)
+        f.argtypes = [_vp, _vp, _sz, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_summary_" + sfx)
         f.argtypes = [_vp, _sz, _vp, _vp, _vp]
@@ -78,6 +84,10 @@ def _declare(lib):
     lib.sgmcmc_rhat_finish_f32.argtypes = [_vp, _sz, _ci, _u64, _vp, _vp]
     lib.sgmcmc_rhat_finish_f32.restype = _ci
     lib.sgmcmc_summary_workspace_bytes.restype = _sz
+    lib.sgmcmc_step_stats_workspace_bytes.argtypes = [_sz]
+    lib.sgmcmc_step_stats_workspace_bytes.restype = _sz
+    lib.sgmcmc_step_stats_finish.argtypes = [_vp, _vp, _vp]
+    lib.sgmcmc_step_stats_finish.restype = _ci
 
 
 def lib():

@@ -211,8 +211,19 @@ struct SghmcOp {
     typedef T real;
     T *theta, *V; const T *grad; T *tau, *g, *vh, *minv, *r; const T *xi;
     T e2, c1, c3, e4, mdecay;      // host-derived scalars, sghmc.py:111-117,211-217,235
+    T grad_decay;                  // gradient term grad_decay * theta added in registers (0 = off)
     NoiseKey nk;
+    double *stats_part;            // nullable: per-block partials of {sum theta'^2, sum V'^2, sum minv, sum minv^2}
     __device__ __forceinline__ void prepare() { nk.resolve(); }
+    template <typename RegsT>
+    __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < cnt) {
+            double th = (double)R.th[j], v = (double)R.v[j], mi = (double)R.mi[j];
+            acc[0] += th * th; acc[1] += v * v; acc[2] += mi; acc[3] += mi * mi;
+        }
+    }
     struct Regs { T th[4], v[4], gr[4], mi[4], tau[4], g[4], vh[4], rr[4], z[4]; };
 
     template <bool NT> __device__ __forceinline__ void load_vec(size_t q, Regs &R) const
@@ -234,7 +245,7 @@ struct SghmcOp {
         if (!INJECT) normal_quad(nk, q, R.z);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            T gr = R.gr[j];
+            T gr = (grad_decay != T(0)) ? R.gr[j] + grad_decay * R.th[j] : R.gr[j];
             T mi;
             if constexpr (ADAPT) { mi = adapt_stats<T>(gr, R.tau[j], R.g[j], R.vh[j], R.rr[j]); R.mi[j] = mi; }
             else mi = R.mi[j];
@@ -272,8 +283,19 @@ struct SgldOp {
     typedef T real;
     T *theta; const T *grad; T *tau, *g, *vh, *minv, *r; const T *xi;
     T eps, A, a_eff, two_eps, sg_den;     // sgld.py:106-108,186-191,201-204
+    T grad_decay;
     NoiseKey nk;
+    double *stats_part;
     __device__ __forceinline__ void prepare() { nk.resolve(); }
+    template <typename RegsT>
+    __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < cnt) {
+            double th = (double)R.th[j], mi = (double)R.mi[j];
+            acc[0] += th * th; acc[2] += mi; acc[3] += mi * mi;
+        }
+    }
     struct Regs { T th[4], gr[4], mi[4], tau[4], g[4], vh[4], rr[4], z[4]; };
 
     template <bool NT> __device__ __forceinline__ void load_vec(size_t q, Regs &R) const
@@ -295,7 +317,7 @@ struct SgldOp {
         if (!INJECT) normal_quad(nk, q, R.z);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            T gr = R.gr[j];
+            T gr = (grad_decay != T(0)) ? R.gr[j] + grad_decay * R.th[j] : R.gr[j];
             T mi;
             if constexpr (ADAPT) { mi = adapt_stats<T>(gr, R.tau[j], R.g[j], R.vh[j], R.rr[j]); R.mi[j] = mi; }
             else mi = R.mi[j];
@@ -329,8 +351,19 @@ struct RsghmcOp {
     typedef T real;
     T *theta, *p; const T *grad; const T *xi;
     T eps, mass, D, m2c2, nscale;         // relativistic_sghmc.py:105-106,117-125
+    T grad_decay;
     NoiseKey nk;
+    double *stats_part;
     __device__ __forceinline__ void prepare() { nk.resolve(); }
+    template <typename RegsT>
+    __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < cnt) {
+            double th = (double)R.th[j], pp = (double)R.p[j];
+            acc[0] += th * th; acc[1] += pp * pp;
+        }
+    }
     struct Regs { T th[4], p[4], gr[4], z[4]; };
 
     template <bool NT> __device__ __forceinline__ void load_vec(size_t q, Regs &R) const
@@ -349,7 +382,7 @@ struct RsghmcOp {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             T p0 = R.p[j];
-            T gl = -R.gr[j];                                                             // :100-103
+            T gl = -((grad_decay != T(0)) ? R.gr[j] + grad_decay * R.th[j] : R.gr[j]);           // :100-103
             T pg = (eps * p0) / (mass * rsqrt_rn<T>((p0 * p0) / m2c2 + T(1)));           // :123
             T nz = nscale * R.z[j];                                                      // :125
             T p1 = p0 + (((eps * gl) + nz) - (D * pg));                                  // :126-129
@@ -372,8 +405,10 @@ template <typename T>
 struct NormalFillOp {
     typedef T real;
     T *out; NoiseKey nk;
+    static constexpr double *stats_part = nullptr;
     __device__ __forceinline__ void prepare() { nk.resolve(); }
     struct Regs { T z[4]; };
+    __device__ __forceinline__ void accumulate(const Regs &, int, double (&)[4]) const {}
     template <bool NT> __device__ __forceinline__ void load_vec(size_t, Regs &) const {}
     __device__ __forceinline__ void load_part_(size_t, int, Regs &) const {}
     __device__ __forceinline__ void compute(size_t q, Regs &R) const { normal_quad(nk, q, R.z); }
@@ -385,8 +420,10 @@ template <typename T>
 struct MomentsOp {
     typedef T real;
     const T *theta; T *mean, *m2; T inv;
+    static constexpr double *stats_part = nullptr;
     __device__ __forceinline__ void prepare() {}
     struct Regs { T x[4], mu[4], m2[4]; };
+    __device__ __forceinline__ void accumulate(const Regs &, int, double (&)[4]) const {}
     template <bool NT> __device__ __forceinline__ void load_vec(size_t q, Regs &R) const
     { load_quad<NT>(theta, q, R.x); load_quad<NT>(mean, q, R.mu); load_quad<NT>(m2, q, R.m2); }
     __device__ __forceinline__ void load_part_(size_t q, int cnt, Regs &R) const
@@ -412,6 +449,61 @@ struct MomentsOp {
 // the one streaming kernel shape all operators share
 // --------------------------------------------------------------------------
 
+// Fused step statistics ("LDS-staged reduction, wavefront shuffles for the partial
+// sums"): every lane keeps 4 running sums in registers, a wave reduces them with
+// __shfl_down (64 lanes), the 4 waves of a block meet in LDS, and lane 0 writes ONE
+// 32-byte partial per block. A second, tiny kernel adds the partials in block order,
+// so the result is bit-reproducible for a given launch geometry. Costs no extra HBM
+// pass: the values are already in registers.
+__device__ __forceinline__ void stats_block_write(double (&acc)[4], double *__restrict__ part)
+{
+    __shared__ double lds[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) lds[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int nw = blockDim.x >> 6;
+        double v = 0.0;
+        for (int w = 0; w < nw; ++w) v += lds[w][threadIdx.x];
+        // workspace = 32-byte header {number of partials} + statistic-major partials [4][gridDim.x]
+        part[4 + (size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(part)[0] = gridDim.x;
+}
+
+// Final pass: ONE block of 1024 lanes = 4 statistics x 256 lanes. Lane t of statistic k adds
+// partials t, t+256, ... (coalesced 8-B reads, 8 loads in flight), then a fixed shuffle/LDS
+// tree combines the 256 lanes. Fixed association => deterministic.
+__global__ void __launch_bounds__(1024) stats_final_kernel(const double *__restrict__ part, double *__restrict__ out4)
+{
+    __shared__ double lds[4][4];
+    const unsigned nparts = (unsigned)reinterpret_cast<const unsigned long long *>(part)[0];
+    const int k = threadIdx.x >> 8, t = threadIdx.x & 255;
+    const int lane = threadIdx.x & 63, wave_in_k = (threadIdx.x >> 6) & 3;
+    const double *__restrict__ p = part + 4 + (size_t)k * nparts;
+    double v = 0.0;
+    unsigned i = t;
+    for (; i + 7u * 256u < nparts; i += 8u * 256u) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = p[i + (unsigned)u * 256u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += x[u];
+    }
+    for (; i < nparts; i += 256u) v += p[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) lds[k][wave_in_k] = v;
+    __syncthreads();
+    if (threadIdx.x < 4) out4[threadIdx.x] = ((lds[threadIdx.x][0] + lds[threadIdx.x][1]) + lds[threadIdx.x][2]) + lds[threadIdx.x][3];
+}
+
 // VEC: arrays are 16-B aligned; quads [0, nq_full) go through dwordx4 accesses,
 //      QPT quads in flight per lane; the ragged tail (n % 4 elements) is done
 //      element-wise by one lane.
@@ -422,6 +514,8 @@ __global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t n
     op.prepare();
     const size_t G = (size_t)gridDim.x * blockDim.x;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool stats = op.stats_part != nullptr;          // wave-uniform
     for (size_t base = gid; base < nq_full; base += G * QPT) {
         typename Op::Regs R[QPT];
 #pragma unroll
@@ -437,7 +531,10 @@ __global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t n
 #pragma unroll
         for (int u = 0; u < QPT; ++u) {
             size_t q = base + (size_t)u * G;
-            if (q < nq_full) op.template store_vec<NT>(q, R[u]);
+            if (q < nq_full) {
+                op.template store_vec<NT>(q, R[u]);
+                if (stats) op.accumulate(R[u], 4, acc);
+            }
         }
     }
     if (tail_cnt && gid == G - 1) {
@@ -445,7 +542,9 @@ __global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t n
         op.load_part_(nq_full, tail_cnt, R);
         op.compute(nq_full, R);
         op.store_part_(nq_full, tail_cnt, R);
+        if (stats) op.accumulate(R, tail_cnt, acc);
     }
+    if (stats) stats_block_write(acc, op.stats_part);
 }
 
 // element-wise path for misaligned arrays: same quads, same results
@@ -456,6 +555,8 @@ __global__ void __launch_bounds__(256) stream_quads_scalar(const Op op_in, size_
     op.prepare();
     const size_t G = (size_t)gridDim.x * blockDim.x;
     const size_t nq = (n + 3) / 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool stats = op.stats_part != nullptr;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += G) {
         size_t left = n - 4 * q;
         int cnt = left >= 4 ? 4 : (int)left;
@@ -463,7 +564,9 @@ __global__ void __launch_bounds__(256) stream_quads_scalar(const Op op_in, size_
         op.load_part_(q, cnt, R);
         op.compute(q, R);
         op.store_part_(q, cnt, R);
+        if (stats) op.accumulate(R, cnt, acc);
     }
+    if (stats) stats_block_write(acc, op.stats_part);
 }
 
 // --------------------------------------------------------------------------
@@ -574,6 +677,73 @@ __global__ void __launch_bounds__(256) philox_bits_kernel(uint32_t *__restrict__
     }
 }
 
+
+// --------------------------------------------------------------------------
+// BNN cost path helpers (pysgmcmc/models/bayesian_neural_network.py:365-388): the
+// loss head and the tanh backward, so that a whole BNN step is ~26 launches instead
+// of ~90 tiny framework ops. Single-block / plain elementwise: launch-bound by design.
+// --------------------------------------------------------------------------
+
+struct BnnHeadConsts {
+    double batch_size, n_examples, wp_den, lvp_den, ln_prior_mean, ln_prior_var, wdecay;
+    int fold_prior_grad;     // 1: the update kernel adds the weight-prior gradient (grad_decay), omit it here
+};
+
+// mean[B], y[B]: network mean output and targets; s_ptr: the scalar log-variance parameter
+// (output_bias); theta_sumsq: sum over ALL parameters of theta^2 (double, from the step kernel's
+// fused statistics). Writes delta[B] = d cost/d mean, cost_out, grad_s_out (into the gradient
+// arena slot of output_bias) and mse_out.
+template <typename T>
+__global__ void __launch_bounds__(256) bnn_head_kernel(const T *__restrict__ mean, const T *__restrict__ y,
+                                                       const T *__restrict__ s_ptr, const double *__restrict__ theta_sumsq,
+                                                       size_t B, BnnHeadConsts k, T *__restrict__ delta,
+                                                       T *__restrict__ cost_out, T *__restrict__ grad_s_out,
+                                                       T *__restrict__ mse_out)
+{
+    __shared__ double lds[4];
+    const double s = (double)*s_ptr;
+    const double es = exp(s);
+    const double inv = 1.0 / (es + 1e-16);                       // :369
+    const double dscale = -(inv / k.batch_size);
+    double sse = 0.0;
+    for (size_t i = threadIdx.x; i < B; i += blockDim.x) {
+        double r = (double)y[i] - (double)mean[i];
+        sse += r * r;                                            // :370
+        delta[i] = (T)(r * dscale);                              // d cost / d mean_i
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sse += __shfl_down(sse, off, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = sse;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += lds[w];
+        const double Bd = (double)B;
+        double log_like = (-(tot * (0.5 * inv)) - 0.5 * s * Bd) / k.batch_size;            // :371-377
+        double d = s - k.ln_prior_mean;
+        double lvp = -(d * d) / k.lvp_den - 0.5 * k.ln_prior_var;                           // :102-107
+        double wp = (-0.5 * k.wdecay) * (*theta_sumsq) / k.wp_den;                          // :131-141
+        double cost = -(log_like + lvp / k.n_examples + wp / k.n_examples);                 // :380-388
+        double prior_coef = k.wdecay / (k.wp_den * k.n_examples);
+        double ds = -((tot * (0.5 * es * inv * inv) - 0.5 * Bd) / k.batch_size
+                      + (-2.0 * d / k.lvp_den) / k.n_examples) + (k.fold_prior_grad ? 0.0 : prior_coef * s);
+        *cost_out = (T)cost;
+        *grad_s_out = (T)ds;
+        *mse_out = (T)(tot / Bd);
+    }
+}
+
+// delta *= (1 - h^2), the tanh backward (h = tanh(a) kept from the forward pass)
+template <typename T>
+__global__ void __launch_bounds__(256) tanh_backward_kernel(T *__restrict__ delta, const T *__restrict__ h, size_t n)
+{
+    const size_t G = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += G) {
+        T hv = h[i];
+        delta[i] = delta[i] * (T(1) - hv * hv);
+    }
+}
+
 // --------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------
@@ -616,6 +786,17 @@ inline NoiseKey make_key(uint64_t seed, uint64_t step, const uint64_t *step_dev)
 
 __global__ void counter_add_kernel(uint64_t *ctr, uint64_t inc) { *ctr += inc; }
 
+// Upper bound of the grid any launch of n elements can use (sizes the stats workspace).
+inline size_t max_grid_for(size_t n)
+{
+    size_t nq = (n + 3) / 4;
+    size_t want = (nq + 63) / 64;                      // smallest block (64 threads), 1 quad per lane
+    size_t cap = (size_t)1 << 20;
+    return want < cap ? (want ? want : 1) : cap;
+}
+
+__attribute__((unused)) thread_local unsigned g_last_grid = 0;
+
 template <typename Op, int QPT, bool NT>
 int launch_vec(const Op &op, size_t n, hipStream_t st)
 {
@@ -627,6 +808,7 @@ int launch_vec(const Op &op, size_t n, hipStream_t st)
     if (want == 0) want = 1;
     size_t cap = (size_t)g_max_blocks.load();
     unsigned grid = (unsigned)(want < cap ? want : cap);
+    g_last_grid = grid;
     hipLaunchKernelGGL((stream_quads_vec<Op, QPT, NT>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch stream_quads_vec");
@@ -640,6 +822,7 @@ int launch_scalar(const Op &op, size_t n, hipStream_t st)
     if (want == 0) want = 1;
     size_t cap = (size_t)g_max_blocks.load();
     unsigned grid = (unsigned)(want < cap ? want : cap);
+    g_last_grid = grid;
     hipLaunchKernelGGL((stream_quads_scalar<Op>), dim3(grid), dim3(bt), 0, st, op, n);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch stream_quads_scalar");
@@ -648,7 +831,16 @@ int launch_scalar(const Op &op, size_t n, hipStream_t st)
 // f32 ops honour the (quads_per_thread, nontemporal) knobs; f64 ops (a quad is
 // already 32 B per lane per array) use one quad per lane.
 template <typename Op>
+int launch_inner(const Op &op, size_t n, bool vec_ok, size_t bytes_per_elem, hipStream_t st);
+
+template <typename Op>
 int launch(const Op &op, size_t n, bool vec_ok, size_t bytes_per_elem, hipStream_t st)
+{
+    return launch_inner(op, n, vec_ok, bytes_per_elem, st);
+}
+
+template <typename Op>
+int launch_inner(const Op &op, size_t n, bool vec_ok, size_t bytes_per_elem, hipStream_t st)
 {
     if (n == 0) return 0;
     if (!vec_ok) return launch_scalar<Op>(op, n, st);
@@ -670,7 +862,8 @@ int launch(const Op &op, size_t n, bool vec_ok, size_t bytes_per_elem, hipStream
 
 template <typename T>
 int sghmc_step(T *theta, T *V, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, size_t n,
-               T eps, T scale_grad, T mdecay, int adapt, const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev, hipStream_t st)
+               T eps, T scale_grad, T mdecay, T grad_decay, int adapt, const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+               void *stats_ws, hipStream_t st)
 {
     if (n == 0) return 0;
     if (!theta || !V || !grad || !minv) return fail(SGMCMC_EINVAL, "sghmc_step: theta, V, grad and minv must be non-NULL");
@@ -682,11 +875,12 @@ int sghmc_step(T *theta, T *V, const T *grad, T *tau, T *g, T *v_hat, T *minv, T
     T c3 = T(2) * std::pow(eps_s, T(3));
     T e4 = std::pow(eps_s, T(4));
     NoiseKey nk = make_key(seed, step, step_dev);
+    double *sp = static_cast<double *>(stats_ws);
     bool vec_ok = aligned16(theta) && aligned16(V) && aligned16(grad) && aligned16(minv) && aligned16(xi) &&
                   (!adapt || (aligned16(tau) && aligned16(g) && aligned16(v_hat) && aligned16(r)));
 #define SGHMC_GO(AD, INJ)                                                                              \
     {                                                                                                  \
-        SghmcOp<T, AD, INJ> op{theta, V, grad, tau, g, v_hat, minv, r, xi, e2, c1, c3, e4, mdecay, nk}; \
+        SghmcOp<T, AD, INJ> op{theta, V, grad, tau, g, v_hat, minv, r, xi, e2, c1, c3, e4, mdecay, grad_decay, nk, sp}; \
         return launch(op, n, vec_ok, sizeof(T) * ((AD ? 12 : 6) + (INJ ? 1 : 0)), st);                 \
     }
     if (adapt) { if (xi) SGHMC_GO(true, true) else SGHMC_GO(true, false) }
@@ -696,7 +890,8 @@ int sghmc_step(T *theta, T *V, const T *grad, T *tau, T *g, T *v_hat, T *minv, T
 
 template <typename T>
 int sgld_step(T *theta, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, size_t n,
-              T eps, T A, T scale_grad, int adapt, const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev, hipStream_t st)
+              T eps, T A, T scale_grad, T grad_decay, int adapt, const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+               void *stats_ws, hipStream_t st)
 {
     if (n == 0) return 0;
     if (!theta || !grad || !minv) return fail(SGMCMC_EINVAL, "sgld_step: theta, grad and minv must be non-NULL");
@@ -706,11 +901,12 @@ int sgld_step(T *theta, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, si
     T two_eps = T(2) * eps;
     T a_eff = A - T(0);
     NoiseKey nk = make_key(seed, step, step_dev);
+    double *sp = static_cast<double *>(stats_ws);
     bool vec_ok = aligned16(theta) && aligned16(grad) && aligned16(minv) && aligned16(xi) &&
                   (!adapt || (aligned16(tau) && aligned16(g) && aligned16(v_hat) && aligned16(r)));
 #define SGLD_GO(AD, INJ)                                                                            \
     {                                                                                               \
-        SgldOp<T, AD, INJ> op{theta, grad, tau, g, v_hat, minv, r, xi, eps, A, a_eff, two_eps, sg_den, nk}; \
+        SgldOp<T, AD, INJ> op{theta, grad, tau, g, v_hat, minv, r, xi, eps, A, a_eff, two_eps, sg_den, grad_decay, nk, sp}; \
         return launch(op, n, vec_ok, sizeof(T) * ((AD ? 10 : 4) + (INJ ? 1 : 0)), st);              \
     }
     if (adapt) { if (xi) SGLD_GO(true, true) else SGLD_GO(true, false) }
@@ -719,20 +915,22 @@ int sgld_step(T *theta, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, si
 }
 
 template <typename T>
-int rsghmc_step(T *theta, T *p, const T *grad, size_t n, T eps, T mass, T c, T D, T b_hat,
-                const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev, hipStream_t st)
+int rsghmc_step(T *theta, T *p, const T *grad, size_t n, T eps, T mass, T c, T D, T b_hat, T grad_decay,
+                const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+                void *stats_ws, hipStream_t st)
 {
     if (n == 0) return 0;
     if (!theta || !p || !grad) return fail(SGMCMC_EINVAL, "rsghmc_step: theta, p and grad_cost must be non-NULL");
     T m2c2 = (mass * mass) * (c * c);
     T nscale = std::sqrt(eps * ((T(2) * D) - (eps * b_hat)));
     NoiseKey nk = make_key(seed, step, step_dev);
+    double *sp = static_cast<double *>(stats_ws);
     bool vec_ok = aligned16(theta) && aligned16(p) && aligned16(grad) && aligned16(xi);
     if (xi) {
-        RsghmcOp<T, false, true> op{theta, p, grad, xi, eps, mass, D, m2c2, nscale, nk};
+        RsghmcOp<T, false, true> op{theta, p, grad, xi, eps, mass, D, m2c2, nscale, grad_decay, nk, sp};
         return launch(op, n, vec_ok, sizeof(T) * 6, st);
     }
-    RsghmcOp<T, false, false> op{theta, p, grad, xi, eps, mass, D, m2c2, nscale, nk};
+    RsghmcOp<T, false, false> op{theta, p, grad, xi, eps, mass, D, m2c2, nscale, grad_decay, nk, sp};
     return launch(op, n, vec_ok, sizeof(T) * 5, st);
 }
 
@@ -755,6 +953,26 @@ inline unsigned small_grid(size_t n)
     size_t cap = (size_t)g_max_blocks.load();
     return (unsigned)(want < cap ? (want ? want : 1) : cap);
 }
+
+template <typename T>
+int bnn_head(const T *mean, const T *y, const T *s_ptr, const double *theta_sumsq, size_t B,
+                    double batch_size, double n_examples, double n_params, double wdecay, double prior_mean,
+                    double prior_var, int fold_prior_grad, T *delta, T *cost_out, T *grad_s_out, T *mse_out, hipStream_t st)
+{
+    if (!mean || !y || !s_ptr || !theta_sumsq || !delta || !cost_out || !grad_s_out || !mse_out || B == 0)
+        return fail(SGMCMC_EINVAL, "bnn_head: NULL argument or B == 0");
+    BnnHeadConsts k;
+    k.batch_size = batch_size; k.n_examples = n_examples; k.wdecay = wdecay;
+    k.wp_den = n_params + (2.0 * 1e-16 + 1e-16);                 /* safe_divide, n_params > 0 */
+    k.lvp_den = 2.0 * prior_var + (2.0 * 1e-16 + 1e-16);
+    k.ln_prior_mean = std::log(prior_mean); k.ln_prior_var = std::log(prior_var);
+    k.fold_prior_grad = fold_prior_grad ? 1 : 0;
+    hipLaunchKernelGGL((bnn_head_kernel<T>), dim3(1), dim3(256), 0, st, mean, y, s_ptr, theta_sumsq, B, k, delta,
+                       cost_out, grad_s_out, mse_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch bnn_head");
+}
+
 
 }  // namespace
 
@@ -807,45 +1025,63 @@ int sgmcmc_get_launch_config(int *block_threads, int *quads_per_thread, int *max
 }
 
 int sgmcmc_sghmc_step_f32(float *theta, float *V, const float *grad, float *tau, float *g, float *v_hat,
-                          float *minv, float *r, size_t n, float eps, float scale_grad, float mdecay, int adapt,
-                          const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
+                          float *minv, float *r, size_t n, float eps, float scale_grad, float mdecay, float grad_decay, int adapt,
+                          const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+                          void *stats_ws, sgmcmc_stream_t stream)
 {
-    return sghmc_step<float>(theta, V, grad, tau, g, v_hat, minv, r, n, eps, scale_grad, mdecay, adapt, xi, seed, step, step_dev,
-                             static_cast<hipStream_t>(stream));
+    return sghmc_step<float>(theta, V, grad, tau, g, v_hat, minv, r, n, eps, scale_grad, mdecay, grad_decay, adapt, xi, seed, step,
+                             step_dev, stats_ws, static_cast<hipStream_t>(stream));
 }
 int sgmcmc_sghmc_step_f64(double *theta, double *V, const double *grad, double *tau, double *g, double *v_hat,
-                          double *minv, double *r, size_t n, double eps, double scale_grad, double mdecay, int adapt,
-                          const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
+                          double *minv, double *r, size_t n, double eps, double scale_grad, double mdecay, double grad_decay,
+                          int adapt,
+                          const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+                          void *stats_ws, sgmcmc_stream_t stream)
 {
-    return sghmc_step<double>(theta, V, grad, tau, g, v_hat, minv, r, n, eps, scale_grad, mdecay, adapt, xi, seed, step, step_dev,
-                              static_cast<hipStream_t>(stream));
+    return sghmc_step<double>(theta, V, grad, tau, g, v_hat, minv, r, n, eps, scale_grad, mdecay, grad_decay, adapt, xi, seed, step,
+                              step_dev, stats_ws, static_cast<hipStream_t>(stream));
 }
 int sgmcmc_sgld_step_f32(float *theta, const float *grad, float *tau, float *g, float *v_hat, float *minv, float *r,
-                         size_t n, float eps, float A, float scale_grad, int adapt, const float *xi, uint64_t seed,
-                         uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
+                         size_t n, float eps, float A, float scale_grad, float grad_decay, int adapt, const float *xi,
+                         uint64_t seed,
+                         uint64_t step, const uint64_t *step_dev, void *stats_ws,
+                         sgmcmc_stream_t stream)
 {
-    return sgld_step<float>(theta, grad, tau, g, v_hat, minv, r, n, eps, A, scale_grad, adapt, xi, seed, step, step_dev,
-                            static_cast<hipStream_t>(stream));
+    return sgld_step<float>(theta, grad, tau, g, v_hat, minv, r, n, eps, A, scale_grad, grad_decay, adapt, xi, seed, step, step_dev,
+                            stats_ws, static_cast<hipStream_t>(stream));
 }
 int sgmcmc_sgld_step_f64(double *theta, const double *grad, double *tau, double *g, double *v_hat, double *minv,
-                         double *r, size_t n, double eps, double A, double scale_grad, int adapt, const double *xi,
-                         uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
+                         double *r, size_t n, double eps, double A, double scale_grad, double grad_decay, int adapt,
+                         const double *xi,
+                         uint64_t seed, uint64_t step, const uint64_t *step_dev, void *stats_ws,
+                         sgmcmc_stream_t stream)
 {
-    return sgld_step<double>(theta, grad, tau, g, v_hat, minv, r, n, eps, A, scale_grad, adapt, xi, seed, step, step_dev,
-                             static_cast<hipStream_t>(stream));
+    return sgld_step<double>(theta, grad, tau, g, v_hat, minv, r, n, eps, A, scale_grad, grad_decay, adapt, xi, seed, step, step_dev,
+                             stats_ws, static_cast<hipStream_t>(stream));
 }
 int sgmcmc_rsghmc_step_f32(float *theta, float *p, const float *grad_cost, size_t n, float eps, float mass, float c,
-                           float D, float b_hat, const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
+                           float D, float b_hat, float grad_decay, const float *xi, uint64_t seed, uint64_t step,
+                           const uint64_t *step_dev, void *stats_ws, sgmcmc_stream_t stream)
 {
-    return rsghmc_step<float>(theta, p, grad_cost, n, eps, mass, c, D, b_hat, xi, seed, step, step_dev,
-                              static_cast<hipStream_t>(stream));
+    return rsghmc_step<float>(theta, p, grad_cost, n, eps, mass, c, D, b_hat, grad_decay, xi, seed, step, step_dev,
+                              stats_ws, static_cast<hipStream_t>(stream));
 }
 int sgmcmc_rsghmc_step_f64(double *theta, double *p, const double *grad_cost, size_t n, double eps, double mass,
-                           double c, double D, double b_hat, const double *xi, uint64_t seed, uint64_t step,
-                           const uint64_t *step_dev, sgmcmc_stream_t stream)
+                           double c, double D, double b_hat, double grad_decay, const double *xi, uint64_t seed,
+                           uint64_t step,
+                           const uint64_t *step_dev, void *stats_ws, sgmcmc_stream_t stream)
 {
-    return rsghmc_step<double>(theta, p, grad_cost, n, eps, mass, c, D, b_hat, xi, seed, step, step_dev,
-                               static_cast<hipStream_t>(stream));
+    return rsghmc_step<double>(theta, p, grad_cost, n, eps, mass, c, D, b_hat, grad_decay, xi, seed, step, step_dev,
+                               stats_ws, static_cast<hipStream_t>(stream));
+}
+size_t sgmcmc_step_stats_workspace_bytes(size_t n) { return (max_grid_for(n) + 1) * 4 * sizeof(double); }
+int sgmcmc_step_stats_finish(const void *stats_ws, double *stats_out, sgmcmc_stream_t stream)
+{
+    if (!stats_ws || !stats_out) return fail(SGMCMC_EINVAL, "step_stats_finish: NULL argument");
+    hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const double *>(stats_ws), stats_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch stats_final");
 }
 
 int sgmcmc_philox_normal_f32(float *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
@@ -922,6 +1158,39 @@ int sgmcmc_summary_f32(const float *x, size_t n, double *out4, void *workspace, 
 int sgmcmc_summary_f64(const double *x, size_t n, double *out4, void *workspace, sgmcmc_stream_t stream)
 {
     return summary<double>(x, n, out4, workspace, static_cast<hipStream_t>(stream));
+}
+
+int sgmcmc_bnn_head_f32(const float *mean, const float *y, const float *log_var, const double *theta_sumsq, size_t B,
+                        double batch_size, double n_examples, double n_params, double wdecay, double prior_mean,
+                        double prior_var, int fold_prior_grad, float *delta, float *cost_out, float *grad_log_var_out,
+                        float *mse_out, sgmcmc_stream_t stream)
+{
+    return bnn_head<float>(mean, y, log_var, theta_sumsq, B, batch_size, n_examples, n_params, wdecay, prior_mean,
+                           prior_var, fold_prior_grad, delta, cost_out, grad_log_var_out, mse_out, static_cast<hipStream_t>(stream));
+}
+int sgmcmc_bnn_head_f64(const double *mean, const double *y, const double *log_var, const double *theta_sumsq, size_t B,
+                        double batch_size, double n_examples, double n_params, double wdecay, double prior_mean,
+                        double prior_var, int fold_prior_grad, double *delta, double *cost_out, double *grad_log_var_out,
+                        double *mse_out, sgmcmc_stream_t stream)
+{
+    return bnn_head<double>(mean, y, log_var, theta_sumsq, B, batch_size, n_examples, n_params, wdecay, prior_mean,
+                            prior_var, fold_prior_grad, delta, cost_out, grad_log_var_out, mse_out, static_cast<hipStream_t>(stream));
+}
+int sgmcmc_tanh_backward_f32(float *delta, const float *h, size_t n, sgmcmc_stream_t stream)
+{
+    if (n == 0) return 0;
+    if (!delta || !h) return fail(SGMCMC_EINVAL, "tanh_backward: NULL argument");
+    hipLaunchKernelGGL((tanh_backward_kernel<float>), dim3(small_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), delta, h, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch tanh_backward");
+}
+int sgmcmc_tanh_backward_f64(double *delta, const double *h, size_t n, sgmcmc_stream_t stream)
+{
+    if (n == 0) return 0;
+    if (!delta || !h) return fail(SGMCMC_EINVAL, "tanh_backward: NULL argument");
+    hipLaunchKernelGGL((tanh_backward_kernel<double>), dim3(small_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), delta, h, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch tanh_backward");
 }
 
 }  // extern "C"

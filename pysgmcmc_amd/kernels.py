@@ -15,7 +15,7 @@ from pysgmcmc_amd._lib import SgmcmcLibraryError, check, lib
 __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
-    "set_launch_config", "get_launch_config", "counter_add",
+    "set_launch_config", "get_launch_config", "counter_add", "StepStats", "bnn_head", "tanh_backward", "step_stats_finish",
 ]
 
 _SFX = {torch.float32: "f32", torch.float64: "f64"}
@@ -61,6 +61,28 @@ def _ctr(step_dev):
     return _ptr(step_dev)
 
 
+class StepStats(object):
+    """Device buffers for the statistics a step kernel reduces on the fly:
+    ``out`` = float64[4] {sum theta'^2, sum V'^2 (p'^2), sum minv, sum minv^2}."""
+
+    def __init__(self, n, device):
+        self.out = torch.zeros(4, dtype=torch.float64, device=device)
+        self.workspace = torch.empty(max(lib().sgmcmc_step_stats_workspace_bytes(int(n)), 32),
+                                     dtype=torch.uint8, device=device)
+
+
+def _stats(stats):
+    return (None,) if stats is None else (_ptr(stats.workspace),)
+
+
+def step_stats_finish(stats):
+    """K7: reduce the per-block partials the last step kernel left in ``stats.workspace`` into ``stats.out``."""
+    with _on(stats.out):
+        rc = lib().sgmcmc_step_stats_finish(_ptr(stats.workspace), _ptr(stats.out), _stream(stats.out))
+    check(rc, "sgmcmc_step_stats_finish")
+    return stats.out
+
+
 def counter_add(counter, inc=1):
     """counter += inc on the current stream (graph-capturable)."""
     with _on(counter):
@@ -87,33 +109,36 @@ def get_launch_config():
     return {"block_threads": a.value, "quads_per_thread": b.value, "max_blocks": c.value, "nontemporal": d.value}
 
 
-def sghmc_step(theta, V, grad, tau, g, v_hat, minv, r, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step=0, step_dev=None):
+def sghmc_step(theta, V, grad, tau, g, v_hat, minv, r, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step=0, step_dev=None,
+               stats=None, grad_decay=0.0):
     """K1, one fused SGHMC step in place (pysgmcmc/samplers/sghmc.py:165-251)."""
     f = getattr(lib(), "sgmcmc_sghmc_step_" + _sfx(theta))
     with _on(theta):
         rc = f(_ptr(theta), _ptr(V, theta), _ptr(grad, theta), _ptr(tau, theta), _ptr(g, theta),
                _ptr(v_hat, theta), _ptr(minv, theta), _ptr(r, theta), theta.numel(),
-               float(eps), float(scale_grad), float(mdecay), int(bool(adapt)), _ptr(xi, theta),
-               int(seed), int(step), _ctr(step_dev), _stream(theta))
+               float(eps), float(scale_grad), float(mdecay), float(grad_decay), int(bool(adapt)), _ptr(xi, theta),
+               int(seed), int(step), _ctr(step_dev), *_stats(stats), _stream(theta))
     check(rc, "sgmcmc_sghmc_step")
 
 
-def sgld_step(theta, grad, tau, g, v_hat, minv, r, eps, A, scale_grad, adapt, xi=None, seed=0, step=0, step_dev=None):
+def sgld_step(theta, grad, tau, g, v_hat, minv, r, eps, A, scale_grad, adapt, xi=None, seed=0, step=0, step_dev=None,
+               stats=None, grad_decay=0.0):
     """K2, one fused SGLD step in place (pysgmcmc/samplers/sgld.py:149-211)."""
     f = getattr(lib(), "sgmcmc_sgld_step_" + _sfx(theta))
     with _on(theta):
         rc = f(_ptr(theta), _ptr(grad, theta), _ptr(tau, theta), _ptr(g, theta), _ptr(v_hat, theta),
                _ptr(minv, theta), _ptr(r, theta), theta.numel(), float(eps), float(A), float(scale_grad),
-               int(bool(adapt)), _ptr(xi, theta), int(seed), int(step), _ctr(step_dev), _stream(theta))
+               float(grad_decay), int(bool(adapt)), _ptr(xi, theta), int(seed), int(step), _ctr(step_dev), *_stats(stats), _stream(theta))
     check(rc, "sgmcmc_sgld_step")
 
 
-def rsghmc_step(theta, p, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, step=0, step_dev=None):
+def rsghmc_step(theta, p, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, step=0, step_dev=None,
+                stats=None, grad_decay=0.0):
     """K3, one fused relativistic SGHMC step (pysgmcmc/samplers/relativistic_sghmc.py:120-140)."""
     f = getattr(lib(), "sgmcmc_rsghmc_step_" + _sfx(theta))
     with _on(theta):
         rc = f(_ptr(theta), _ptr(p, theta), _ptr(grad_cost, theta), theta.numel(), float(eps), float(mass),
-               float(c), float(D), float(b_hat), _ptr(xi, theta), int(seed), int(step), _ctr(step_dev), _stream(theta))
+               float(c), float(D), float(b_hat), float(grad_decay), _ptr(xi, theta), int(seed), int(step), _ctr(step_dev), *_stats(stats), _stream(theta))
     check(rc, "sgmcmc_rsghmc_step")
 
 
@@ -171,3 +196,24 @@ def summary(x, out4=None, workspace=None):
         rc = f(_ptr(x), x.numel(), _ptr(out4), _ptr(workspace), _stream(x))
     check(rc, "sgmcmc_summary")
     return out4
+
+
+def bnn_head(mean, y, log_var, theta_sumsq, batch_size, n_examples, n_params, wdecay, prior_mean, prior_var,
+             delta, cost_out, grad_log_var_out, mse_out, fold_prior_grad=False):
+    """Loss head of the BNN cost path in one launch (see include/sgmcmc_hip.h)."""
+    f = getattr(lib(), "sgmcmc_bnn_head_" + _sfx(mean))
+    if theta_sumsq.dtype != torch.float64:
+        raise TypeError("theta_sumsq must be a float64 device scalar")
+    with _on(mean):
+        rc = f(_ptr(mean), _ptr(y, mean), _ptr(log_var), _ptr(theta_sumsq), mean.numel(), float(batch_size),
+               float(n_examples), float(n_params), float(wdecay), float(prior_mean), float(prior_var),
+               int(bool(fold_prior_grad)), _ptr(delta, mean), _ptr(cost_out), _ptr(grad_log_var_out), _ptr(mse_out), _stream(mean))
+    check(rc, "sgmcmc_bnn_head")
+
+
+def tanh_backward(delta, h):
+    """delta *= 1 - h^2 in place."""
+    f = getattr(lib(), "sgmcmc_tanh_backward_" + _sfx(delta))
+    with _on(delta):
+        rc = f(_ptr(delta), _ptr(h, delta), delta.numel(), _stream(delta))
+    check(rc, "sgmcmc_tanh_backward")

@@ -18,6 +18,13 @@ What differs, by design:
     straight into the arena).
   * ``session`` is accepted for signature compatibility; a ``torch.device`` (or
     device string) there selects the GPU, anything else is ignored.
+  * ``use_hip_graph`` (attribute): ``True`` captures the cost/gradient pipeline (the many small
+    launches) into one hipGraph replayed every step, followed by a direct launch of the fused
+    update (so stepsize, phase and Philox step stay by-value arguments); ``"full"`` captures the
+    update kernel too (Philox step read from a device counter). See ``_step_graph``.
+  * ``collect_stats`` (attribute, default True): the step kernel also reduces
+    {sum theta^2, sum V^2, sum minv, sum minv^2} from registers (``sampler.stats``); a cost
+    function that sets ``accepts_theta_sumsq`` gets sum theta^2 for free (BNN weight prior).
   * ``sample_format`` (attribute, not a constructor keyword so that the
     ``get_sampler`` keyword reflection stays identical to the reference):
     ``"numpy"`` (default, reference behaviour: one D2H copy of theta per step),
@@ -114,6 +121,18 @@ class MCMCSampler(object):
         self.theta_t = self.arena.views("theta")
         # injected-noise hook (tests / reproducing a trajectory): callable(step, n) -> flat tensor or None
         self.noise_source = None
+        # fused step statistics (sum theta^2, sum V^2, sum minv, sum minv^2), reduced inside the kernel
+        self.collect_stats = True
+        self._stats = None
+        self._stats_valid = False
+        # hipGraph mode
+        self.use_hip_graph = False
+        self._graphs = {}
+        self._static_feeds = {}
+        self._step_ctr = None
+        self._ctr_value = -1
+        self._capturing = False
+        self._grad_decay = 0.0
 
     # ------------------------------------------------------------------ feeds
     def _next_batch(self):
@@ -133,12 +152,53 @@ class MCMCSampler(object):
                 placeholder.feed(value)
 
     # ------------------------------------------------------------------ cost
+    def _step_stats(self):
+        """StepStats buffers for the kernel (None on CPU state or when disabled)."""
+        if not self.collect_stats or self.device.type != "cuda":
+            return None
+        if self._stats is None:
+            self._stats = kernels.StepStats(self.arena.n, self.device)
+        return self._stats
+
+    def _ensure_stats(self):
+        """Make stats.out[0] = sum theta^2 valid before the first step (K6), later steps keep it fresh."""
+        st = self._step_stats()
+        if st is not None and not self._stats_valid:
+            s = kernels.summary(self.arena.row("theta"))
+            st.out.zero_()
+            st.out[0:1].copy_(s[1:2])
+            self._stats_valid = True
+        return st
+
+    @property
+    def stats(self):
+        """``{"theta_sq", "momentum_sq", "minv_sum", "minv_sq"}`` after the last step (host floats)."""
+        st = self._ensure_stats()
+        if st is None:
+            return None
+        v = st.out.cpu().numpy()
+        return {"theta_sq": float(v[0]), "momentum_sq": float(v[1]), "minv_sum": float(v[2]), "minv_sq": float(v[3])}
+
+    def _noise_args(self):
+        """(seed, step, step_dev) of the in-register Philox stream; graph capture uses the device counter."""
+        if self._capturing:
+            return dict(seed=self._philox_seed, step=0, step_dev=self._step_ctr)
+        return dict(seed=self._philox_seed, step=self.n_iterations, step_dev=None)
+
     def _cost_and_grad(self):
         """Evaluate cost at the current theta and leave d cost/d theta in the arena's grad row."""
         fused = getattr(self.cost_fun, "cost_and_grad", None)
         if fused is not None:
-            cost = fused(self.params, self.arena.grad_views)
+            kw = {}
+            if getattr(self.cost_fun, "accepts_theta_sumsq", False):
+                st = self._ensure_stats()
+                if st is not None:
+                    kw["theta_sumsq"] = st.out[0]
+            cost = fused(self.params, self.arena.grad_views, **kw)
+            # a cost function may leave a term coef * theta of its gradient to the update kernel
+            self._grad_decay = float(getattr(self.cost_fun, "grad_theta_coef", 0.0))
             return cost.detach() if isinstance(cost, torch.Tensor) else torch.as_tensor(cost)
+        self._grad_decay = 0.0
         with torch.enable_grad():
             cost = self.cost_fun(self.params)
             if not isinstance(cost, torch.Tensor) or not cost.requires_grad:
@@ -198,6 +258,8 @@ class MCMCSampler(object):
         assert (feed_dict is None or hasattr(feed_dict, "update"))
         if feed_dict is None:
             feed_dict = dict()
+        if self.use_hip_graph and self.noise_source is None and self.device.type == "cuda":
+            return self._step_graph(feed_dict)
         feed_dict.update(self._next_batch())
         eps = self._next_stepsize()
         self._feed(feed_dict)
@@ -210,6 +272,80 @@ class MCMCSampler(object):
         self.stepsize_schedule.update(sample, cost_out)
         self.n_iterations += 1
         return sample, cost_out
+
+    # ------------------------------------------------------------------ hipGraph mode
+    def _graph_key(self, eps):
+        return (float(eps),)
+
+    def _step_graph(self, feed_dict):
+        """One step with the launch-bound part replayed from a hipGraph.
+
+        ``use_hip_graph = True``: the graph holds cost + gradient into the arena; the fused update is
+        then launched directly (stepsize / phase / Philox step by value, HIP events can bracket it).
+        ``use_hip_graph = "full"``: the graph also holds the fused update (Philox step read from a
+        device counter) and ``counter += 1``; a new (eps, phase) pair captures a new graph, so
+        constant-stepsize sampling replays one graph for burn-in and one for the frozen phase.
+        Feeds are copied into static buffers first. Requirements: static feed shapes; a cost
+        function without host synchronisation."""
+        feed_dict.update(self._next_batch())
+        eps = self._next_stepsize()
+        for placeholder, value in feed_dict.items():
+            if not hasattr(placeholder, "feed"):
+                continue
+            value = placeholder.feed(value).value
+            buf = self._static_feeds.get(placeholder)
+            if buf is None or buf.shape != value.shape or buf.dtype != value.dtype:
+                buf = value.clone()
+                self._static_feeds[placeholder] = buf
+                self._graphs.clear()
+            else:
+                buf.copy_(value)
+            placeholder.value = buf
+        self._ensure_stats()
+        if self._step_ctr is None:
+            self._step_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
+        if self._ctr_value != self.n_iterations:
+            self._step_ctr.fill_(self.n_iterations)
+            self._ctr_value = self.n_iterations
+        full = self.use_hip_graph == "full"
+        key = self._graph_key(eps) if full else ("cost",)
+        entry = self._graphs.get(key)
+        if entry is None:
+            entry = self._capture(eps, full)
+            self._graphs[key] = entry
+        graph, cost = entry
+        graph.replay()
+        if full:
+            self._ctr_value += 1
+        else:
+            with torch.no_grad():
+                self._kernel_step(eps, None)
+        self.cost = cost
+        sample = self._format_sample()
+        cost_out = self._format_cost(cost)
+        self.stepsize_schedule.update(sample, cost_out)
+        self.n_iterations += 1
+        return sample, cost_out
+
+    def _capture(self, eps, full):
+        cur = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                 # warm-up: cost only, no state change
+            self._cost_and_grad()
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        self._capturing = full
+        try:
+            with torch.cuda.graph(graph):
+                cost = self._cost_and_grad()
+                if full:
+                    with torch.no_grad():
+                        self._kernel_step(eps, None)
+                    kernels.counter_add(self._step_ctr, 1)
+        finally:
+            self._capturing = False
+        return graph, cost
 
     # iterator protocol, base_classes.py:226-310
     def __iter__(self):
@@ -226,6 +362,7 @@ class MCMCSampler(object):
 
     def load_state_dict(self, state):
         self.arena.load_state_dict(state["arena"])
+        self._stats_valid = False
         self.n_iterations = int(state["n_iterations"])
         self._philox_seed = int(state["philox_seed"])
         self.epsilon = state["epsilon"]
@@ -269,6 +406,9 @@ class BurnInMCMCSampler(MCMCSampler):
     @property
     def _adapting(self):
         return self.is_burning_in or self.burn_in_steps <= 0
+
+    def _graph_key(self, eps):
+        return (float(eps), bool(self._adapting))
 
     @property
     def minv(self):

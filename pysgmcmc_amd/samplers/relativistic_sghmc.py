@@ -100,4 +100,7 @@ class RelativisticSGHMCSampler(MCMCSampler):
         kernels.rsghmc_step(
             a.row("theta"), a.row("p"), a.row("grad"),
             eps, self.mass, self.speed_of_light, self.D, self.Bhat,
-            xi=xi, seed=self._philox_seed, step=self.n_iterations)
+            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, **self._noise_args())
+        if self._stats is not None:
+            kernels.step_stats_finish(self._stats)
+            self._stats_valid = True

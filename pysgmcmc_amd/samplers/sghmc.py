@@ -40,4 +40,7 @@ class SGHMCSampler(BurnInMCMCSampler):
             a.row("theta"), a.row("V"), a.row("grad"),
             a.row("tau"), a.row("g"), a.row("v_hat"), a.row("minv"), self._r_row(),
             eps, self.scale_grad, self.mdecay, self._adapting,
-            xi=xi, seed=self._philox_seed, step=self.n_iterations)
+            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, **self._noise_args())
+        if self._stats is not None:
+            kernels.step_stats_finish(self._stats)
+            self._stats_valid = True

@@ -22,32 +22,35 @@ def _sfx(t):
     return "f32" if t.dtype == torch.float32 else "f64"
 
 
-def sghmc_step(theta, V, grad, tau, g, v_hat, minv, r, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step=0, step_dev=None):
+def sghmc_step(theta, V, grad, tau, g, v_hat, minv, r, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step=0,
+               step_dev=None, stats=None, grad_decay=0.0):
     lib = O.load_c()
     f = getattr(lib, "oracle_sghmc_step_" + _sfx(theta))
     p = lambda t: None if t is None else t.data_ptr()
     rc = f(p(theta), p(V), p(grad), p(tau), p(g), p(v_hat), p(minv), p(r), theta.numel(),
-           float(eps), float(scale_grad), float(mdecay), int(bool(adapt)), p(xi), int(seed), int(step))
+           float(eps), float(scale_grad), float(mdecay), float(grad_decay), int(bool(adapt)), p(xi), int(seed), int(step))
     assert rc == 0
     calls.append(("sghmc", bool(adapt), float(eps), int(step)))
 
 
-def sgld_step(theta, grad, tau, g, v_hat, minv, r, eps, A, scale_grad, adapt, xi=None, seed=0, step=0, step_dev=None):
+def sgld_step(theta, grad, tau, g, v_hat, minv, r, eps, A, scale_grad, adapt, xi=None, seed=0, step=0,
+              step_dev=None, stats=None, grad_decay=0.0):
     lib = O.load_c()
     f = getattr(lib, "oracle_sgld_step_" + _sfx(theta))
     p = lambda t: None if t is None else t.data_ptr()
     rc = f(p(theta), p(grad), p(tau), p(g), p(v_hat), p(minv), p(r), theta.numel(),
-           float(eps), float(A), float(scale_grad), int(bool(adapt)), p(xi), int(seed), int(step))
+           float(eps), float(A), float(scale_grad), float(grad_decay), int(bool(adapt)), p(xi), int(seed), int(step))
     assert rc == 0
     calls.append(("sgld", bool(adapt), float(eps), int(step)))
 
 
-def rsghmc_step(theta, p_, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, step=0, step_dev=None):
+def rsghmc_step(theta, p_, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, step=0, step_dev=None, stats=None,
+                grad_decay=0.0):
     lib = O.load_c()
     f = getattr(lib, "oracle_rsghmc_step_" + _sfx(theta))
     p = lambda t: None if t is None else t.data_ptr()
     rc = f(p(theta), p(p_), p(grad_cost), theta.numel(), float(eps), float(mass), float(c), float(D),
-           float(b_hat), p(xi), int(seed), int(step))
+           float(b_hat), float(grad_decay), p(xi), int(seed), int(step))
     assert rc == 0
     calls.append(("rsghmc", False, float(eps), int(step)))
 

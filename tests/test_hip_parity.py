@@ -294,3 +294,85 @@ def test_full_size_properties(gpu):
     assert abs(z.mean().item()) < 5 / np.sqrt(n)
     assert abs(z.var().item() - 1.0) < 0.01
     assert z.abs().max().item() < 7.0
+
+
+@pytest.mark.parametrize("n", [3, 1023, 70001, 3_000_001])
+def test_fused_step_statistics(gpu, oracle, n):
+    """stats_out = {sum theta'^2, sum V'^2, sum minv, sum minv^2} reduced inside the step kernel
+    (wave shuffles -> LDS -> block partials -> fixed-order final): equal to a float64 reduction of the
+    arrays the kernel wrote, deterministic, and the step itself is unchanged by asking for them."""
+    from pysgmcmc_amd import kernels
+    rng = np.random.default_rng(n)
+    th0 = rng.normal(size=n).astype(np.float32)
+    grad = _dev(rng.normal(size=n).astype(np.float32), gpu)
+    for adapt in (True, False):
+        a = GpuState(oracle.CState(th0, np.float32), gpu)
+        b = GpuState(oracle.CState(th0, np.float32), gpu)
+        a.minv.copy_(torch.rand(n, device=gpu) + 0.5); b.minv.copy_(a.minv)
+        st = kernels.StepStats(n, gpu)
+        kernels.sghmc_step(a.theta, a.V, grad, a.tau, a.g, a.v_hat, a.minv, None, 0.01, 50.0, 0.05, adapt,
+                           seed=3, step=1, stats=st)
+        kernels.step_stats_finish(st)
+        kernels.sghmc_step(b.theta, b.V, grad, b.tau, b.g, b.v_hat, b.minv, None, 0.01, 50.0, 0.05, adapt,
+                           seed=3, step=1)
+        assert torch.equal(a.theta, b.theta) and torch.equal(a.V, b.V) and torch.equal(a.minv, b.minv)
+        got = st.out.cpu().numpy()
+        want = [(a.theta.double() ** 2).sum().item(), (a.V.double() ** 2).sum().item(),
+                a.minv.double().sum().item(), (a.minv.double() ** 2).sum().item()]
+        assert np.allclose(got, want, rtol=1e-12), (adapt, got, want)
+        first = got.copy()
+        c = GpuState(oracle.CState(th0, np.float32), gpu)
+        c.minv.copy_(b.minv if not adapt else torch.ones(n, device=gpu))
+        if not adapt:
+            kernels.sghmc_step(c.theta, c.V, grad, None, None, None, c.minv, None, 0.01, 50.0, 0.05, False,
+                               seed=3, step=1, stats=st)
+            kernels.step_stats_finish(st)
+            assert np.array_equal(st.out.cpu().numpy(), first)      # bit-reproducible
+    # SGLD and relativistic variants fill their slots
+    a = GpuState(oracle.CState(th0, np.float32), gpu)
+    st = kernels.StepStats(n, gpu)
+    kernels.sgld_step(a.theta, grad, a.tau, a.g, a.v_hat, a.minv, None, 0.01, 1.0, 50.0, True, seed=1, step=0, stats=st)
+    kernels.step_stats_finish(st)
+    got = st.out.cpu().numpy()
+    assert np.isclose(got[0], (a.theta.double() ** 2).sum().item(), rtol=1e-12) and got[1] == 0.0
+    assert np.isclose(got[2], a.minv.double().sum().item(), rtol=1e-12)
+    kernels.rsghmc_step(a.theta, a.p, grad, 0.001, 1.0, 1.0, 1.0, 0.0, seed=1, step=0, stats=st)
+    kernels.step_stats_finish(st)
+    got = st.out.cpu().numpy()
+    assert np.isclose(got[0], (a.theta.double() ** 2).sum().item(), rtol=1e-12)
+    assert np.isclose(got[1], (a.p.double() ** 2).sum().item(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("npdt,thdt", DTYPES)
+def test_grad_decay_bit_exact(gpu, oracle, npdt, thdt):
+    """grad_decay != 0: the kernel forms grad + grad_decay * theta in registers; bit-equal to the
+    oracle for all three samplers, burn-in and frozen."""
+    from pysgmcmc_amd import kernels
+    n = 10007
+    rng = np.random.default_rng(21)
+    wd = 3.7e-4
+    for sampler in ("sghmc", "sgld", "rsghmc"):
+        cst = oracle.CState(rng.normal(size=n), npdt)
+        cst.p[:] = rng.normal(size=n).astype(npdt)
+        gst = GpuState(cst, gpu)
+        for t in range(8):
+            grad = (rng.normal(size=n) * 2).astype(npdt)
+            xi = rng.normal(size=n).astype(npdt)
+            adapt = t < 4
+            if sampler == "sghmc":
+                oracle.c_sghmc_step(cst, grad, 0.01, 100.0, 0.05, adapt, xi, grad_decay=wd)
+                kernels.sghmc_step(gst.theta, gst.V, _dev(grad, gpu), gst.tau, gst.g, gst.v_hat, gst.minv, None,
+                                   0.01, 100.0, 0.05, adapt, xi=_dev(xi, gpu), grad_decay=wd)
+                names = ("theta", "V", "tau", "g", "v_hat", "minv")
+            elif sampler == "sgld":
+                oracle.c_sgld_step(cst, grad, 0.01, 1.0, 100.0, adapt, xi, grad_decay=wd)
+                kernels.sgld_step(gst.theta, _dev(grad, gpu), gst.tau, gst.g, gst.v_hat, gst.minv, None,
+                                  0.01, 1.0, 100.0, adapt, xi=_dev(xi, gpu), grad_decay=wd)
+                names = ("theta", "tau", "g", "v_hat", "minv")
+            else:
+                oracle.c_rsghmc_step(cst, grad, 0.001, 1.0, 1.0, 1.0, 0.0, xi, grad_decay=wd)
+                kernels.rsghmc_step(gst.theta, gst.p, _dev(grad, gpu), 0.001, 1.0, 1.0, 1.0, 0.0, xi=_dev(xi, gpu),
+                                    grad_decay=wd)
+                names = ("theta", "p")
+            for name in names:
+                _assert_same(getattr(gst, name), getattr(cst, name), "%s grad_decay step %d %s" % (sampler, t, name))

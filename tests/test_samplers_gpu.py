@@ -74,9 +74,10 @@ def test_bnn_golden_trajectory(gpu, dtname):
         params.append(torch.tensor(theta0[off:off + k].reshape(shp), dtype=dt, device=gpu))
         off += k
     xp, yp = Placeholder(dtype=dt, device=gpu), Placeholder(dtype=dt, device=gpu)
-    for fused in (True, False):
+    # fused + prior folded into the update kernel / fused + prior in the GEMM epilogue / plain autograd
+    for fused, fold in ((True, True), (True, False), (False, False)):
         ps = [p.clone() for p in params]
-        cost = BNNCost(xp, yp, batch_size=20, n_examples=100)
+        cost = BNNCost(xp, yp, batch_size=20, n_examples=100, fold_prior=fold)
         cost_fun = cost if fused else (lambda p, *_: cost(p))
         s = SGHMCSampler(params=ps, cost_fun=cost_fun,
                          batch_generator=generate_batches(d["X"], d["y"], xp, yp, batch_size=20, seed=1),
@@ -89,11 +90,14 @@ def test_bnn_golden_trajectory(gpu, dtname):
         want = d[dtname + "|theta"]
         tol = 2e-4 if dt == torch.float32 else 1e-9
         for t in range(12):
+            theta_prev = s.arena.row("theta").cpu().numpy().astype(np.float64)
             _, c = next(s)
             got = s.arena.row("theta").cpu().numpy()
-            assert np.abs(got - want[t]).max() <= tol * np.abs(want[t]).max(), (fused, t)
+            assert np.abs(got - want[t]).max() <= tol * np.abs(want[t]).max(), (fused, fold, t)
             assert np.isclose(float(c), d[dtname + "|cost"][t], rtol=1e-4 if dt == torch.float32 else 1e-9)
-            gerr = np.abs(s.arena.row("grad").cpu().numpy() - d[dtname + "|grad"][t]).max()
+            assert (s._grad_decay > 0) == (fused and fold)
+            full_grad = s.arena.row("grad").cpu().numpy() + s._grad_decay * theta_prev
+            gerr = np.abs(full_grad - d[dtname + "|grad"][t]).max()
             assert gerr <= (2e-4 if dt == torch.float32 else 1e-10) * np.abs(d[dtname + "|grad"][t]).max()
 
 
@@ -207,3 +211,70 @@ def test_hip_graph_capture_of_update_kernel(gpu):
     torch.cuda.synchronize()
     assert int(ctr.item()) == 3
     assert torch.equal(theta, th2) and torch.equal(V, V2)
+
+
+def test_hip_graph_mode_equals_eager(gpu):
+    """use_hip_graph: one captured graph per (eps, phase) replayed each step gives the SAME chain as
+    eager stepping (Philox step comes from the device counter), across the burn-in -> frozen switch,
+    and the fused-statistics weight-prior value equals the recomputed one."""
+    from pysgmcmc_amd.data_batches import Placeholder, generate_batches
+    from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
+    rng = np.random.RandomState(0)
+    X, y = rng.rand(200, 3), rng.rand(200)
+
+    def chain(graph):
+        xp, yp = Placeholder(dtype=torch.float32, device=gpu), Placeholder(dtype=torch.float32, device=gpu)
+        params = init_mlp_params(3, hidden=(32, 32), seed=5, dtype=torch.float32, device=gpu)
+        s = SGHMCSampler(params=params, cost_fun=BNNCost(xp, yp, batch_size=16, n_examples=200),
+                         batch_generator=generate_batches(X, y, xp, yp, batch_size=16, seed=2),
+                         stepsize_schedule=ConstantStepsizeSchedule(0.01), burn_in_steps=5, scale_grad=200.0,
+                         session=gpu, dtype=torch.float32, seed=9)
+        s.sample_format = "view"
+        s.use_hip_graph = graph
+        costs = [float(c) for _, c in islice(s, 12)]
+        return s, costs
+    eager, ce = chain(False)
+    split, cs = chain(True)                                           # cost graph + direct update launch
+    graph, cg = chain("full")                                         # everything in the graph
+    assert len(split._graphs) == 1
+    assert len(graph._graphs) == 2                                    # burn-in graph + frozen graph
+    for other in (split, graph):
+        assert torch.equal(eager.arena.row("theta"), other.arena.row("theta"))
+        assert torch.equal(eager.arena.row("V"), other.arena.row("V"))
+    assert np.allclose(ce, cg, rtol=1e-6) and np.allclose(ce, cs, rtol=1e-6)
+    assert graph.n_iterations == 12 and int(graph._step_ctr.item()) == 12
+    st = graph.stats
+    assert np.isclose(st["theta_sq"], (graph.arena.row("theta").double() ** 2).sum().item(), rtol=1e-12)
+    assert np.isclose(st["momentum_sq"], (graph.arena.row("V").double() ** 2).sum().item(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_bnn_cost_path_hip_equals_autograd(gpu, dt):
+    """The MI355X cost path (GEMMs + loss-head + tanh-backward kernels writing into the arena)
+    against plain autograd of the same NLL: cost, every gradient tensor, mse."""
+    from pysgmcmc_amd.data_batches import Placeholder
+    from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
+    torch.manual_seed(0)
+    for hidden, B, D in (((50, 50, 50), 20, 1), ((64, 32), 33, 5), ((128,), 256, 17)):
+        params = init_mlp_params(D, hidden=hidden, seed=1, dtype=dt, device=gpu)
+        for p in params[1::2]:
+            p.normal_()
+        xp = Placeholder().feed(torch.randn(B, D, dtype=dt, device=gpu))
+        yp = Placeholder().feed(torch.randn(B, 1, dtype=dt, device=gpu))
+        for fold in (False, True):
+            c = BNNCost(xp, yp, batch_size=20, n_examples=1000, fold_prior=fold)
+            ps = [p.clone().requires_grad_(True) for p in params]
+            cost = c(ps)
+            mse_ref = float(c.last_mse)
+            grads = torch.autograd.grad(cost, ps)
+            gv = [torch.full_like(p, float("nan")) for p in params]
+            sumsq = sum((p.double() ** 2).sum() for p in params)
+            for ts in (None, sumsq):
+                cost2 = c.cost_and_grad(params, gv, theta_sumsq=ts)
+                assert (c.grad_theta_coef > 0) == fold
+                tol = 2e-5 if dt == torch.float32 else 1e-11
+                assert abs(float(cost2) - float(cost)) <= tol * abs(float(cost))
+                assert abs(float(c.last_mse) - mse_ref) <= tol * mse_ref
+                for a, b, p in zip(grads, gv, params):
+                    full = b + c.grad_theta_coef * p           # the term the update kernel adds when folded
+                    assert float((a - full).abs().max()) <= tol * float(a.abs().max()) + (1e-9 if dt == torch.float32 else 1e-15)
