@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(1024) stats_final_kernel(const double *__restr
 // VEC: arrays are 16-B aligned; quads [0, nq_full) go through dwordx4 accesses,
 //      QPT quads in flight per lane; the ragged tail (n % 4 elements) is done
 //      element-wise by one lane.
-template <typename Op, int QPT, bool NT>
+template <typename Op, int QPT, bool NT, bool STATS>
 __global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t nq_full, int tail_cnt)
 {
     Op op = op_in;
@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t n
     const size_t G = (size_t)gridDim.x * blockDim.x;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const bool stats = op.stats_part != nullptr;          // wave-uniform
+    constexpr bool stats = STATS;                         // compile-time: the plain variant carries no reduction code
     for (size_t base = gid; base < nq_full; base += G * QPT) {
         typename Op::Regs R[QPT];
 #pragma unroll
@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t n
             size_t q = base + (size_t)u * G;
             if (q < nq_full) {
                 op.template store_vec<NT>(q, R[u]);
-                if (stats) op.accumulate(R[u], 4, acc);
+                if constexpr (stats) op.accumulate(R[u], 4, acc);
             }
         }
     }
@@ -542,13 +542,13 @@ __global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t n
         op.load_part_(nq_full, tail_cnt, R);
         op.compute(nq_full, R);
         op.store_part_(nq_full, tail_cnt, R);
-        if (stats) op.accumulate(R, tail_cnt, acc);
+        if constexpr (stats) op.accumulate(R, tail_cnt, acc);
     }
-    if (stats) stats_block_write(acc, op.stats_part);
+    if constexpr (stats) stats_block_write(acc, op.stats_part);
 }
 
 // element-wise path for misaligned arrays: same quads, same results
-template <typename Op>
+template <typename Op, bool STATS>
 __global__ void __launch_bounds__(256) stream_quads_scalar(const Op op_in, size_t n)
 {
     Op op = op_in;
@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(256) stream_quads_scalar(const Op op_in, size_
     const size_t G = (size_t)gridDim.x * blockDim.x;
     const size_t nq = (n + 3) / 4;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const bool stats = op.stats_part != nullptr;
+    constexpr bool stats = STATS;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += G) {
         size_t left = n - 4 * q;
         int cnt = left >= 4 ? 4 : (int)left;
@@ -564,9 +564,9 @@ __global__ void __launch_bounds__(256) stream_quads_scalar(const Op op_in, size_
         op.load_part_(q, cnt, R);
         op.compute(q, R);
         op.store_part_(q, cnt, R);
-        if (stats) op.accumulate(R, cnt, acc);
+        if constexpr (stats) op.accumulate(R, cnt, acc);
     }
-    if (stats) stats_block_write(acc, op.stats_part);
+    if constexpr (stats) stats_block_write(acc, op.stats_part);
 }
 
 // --------------------------------------------------------------------------
@@ -809,7 +809,10 @@ int launch_vec(const Op &op, size_t n, hipStream_t st)
     size_t cap = (size_t)g_max_blocks.load();
     unsigned grid = (unsigned)(want < cap ? want : cap);
     g_last_grid = grid;
-    hipLaunchKernelGGL((stream_quads_vec<Op, QPT, NT>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
+    if (op.stats_part != nullptr)
+        hipLaunchKernelGGL((stream_quads_vec<Op, QPT, NT, true>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
+    else
+        hipLaunchKernelGGL((stream_quads_vec<Op, QPT, NT, false>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch stream_quads_vec");
 }
@@ -823,7 +826,10 @@ int launch_scalar(const Op &op, size_t n, hipStream_t st)
     size_t cap = (size_t)g_max_blocks.load();
     unsigned grid = (unsigned)(want < cap ? want : cap);
     g_last_grid = grid;
-    hipLaunchKernelGGL((stream_quads_scalar<Op>), dim3(grid), dim3(bt), 0, st, op, n);
+    if (op.stats_part != nullptr)
+        hipLaunchKernelGGL((stream_quads_scalar<Op, true>), dim3(grid), dim3(bt), 0, st, op, n);
+    else
+        hipLaunchKernelGGL((stream_quads_scalar<Op, false>), dim3(grid), dim3(bt), 0, st, op, n);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch stream_quads_scalar");
 }

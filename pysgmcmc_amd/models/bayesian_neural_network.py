@@ -357,6 +357,9 @@ class BayesianNeuralNetwork(object):
         self.is_trained = False
         # use the analytic-backward cost path (gradients straight into the arena)
         self.fused_cost = True
+        # replay the ~25 launches of the cost/gradient pipeline from one hipGraph per step; the 3x50
+        # default net is launch-bound (50x50 GEMMs), SURVEY.md 8(f).1
+        self.use_hip_graph = True
 
     def _device(self):
         if isinstance(self.session, (torch.device, str)):
@@ -385,8 +388,7 @@ class BayesianNeuralNetwork(object):
         for l in range(len(self.hidden) + 1):
             names += ["fc_layer_%d/kernel:0" % (l + 1), "fc_layer_%d/bias:0" % (l + 1)]
         names.append("output_bias:0")
-        for p, name in zip(self.network_params, names):
-            p.name = name
+        self.network_param_names = names          # torch tensors cannot carry a `.name` like tf.Variables
         self.cost = BNNCost(self.X_Minibatch, self.Y_Minibatch, self.batch_size, n_datapoints)
         cost_fun = self.cost
         if not self.fused_cost:
@@ -415,6 +417,8 @@ class BayesianNeuralNetwork(object):
         self.sampler = Sampler.get_sampler(self.sampling_method, **self.sampler_kwargs)
         # samples are kept on the device; no per-step D2H copy of all parameters
         self.sampler.sample_format = "view"
+        self.sampler.param_names = list(names)
+        self.sampler.use_hip_graph = bool(self.use_hip_graph and self.fused_cost and device.type == "cuda")
         X_full = torch.as_tensor(self.X, dtype=self._torch_dtype, device=device)
         Y_full = torch.as_tensor(self.y, dtype=self._torch_dtype, device=device).reshape(-1, 1)
 

@@ -113,6 +113,9 @@ class MCMCSampler(object):
         for p in self.params:
             p.requires_grad_(True)
 
+        # names of the parameters (the reference reads `param.name` of tf.Variables for trace variable
+        # names, diagnostics/sample_chains.py:174-180); enumerated strings by default (:80-90)
+        self.param_names = [str(i) for i in range(len(params))]
         self.cost_fun = cost_fun
         self.cost = None                      # last evaluated cost (device tensor)
         self.epsilon = self.stepsize_schedule.initial_value

@@ -1,0 +1,165 @@
+"""BNN cost path, model driver and minibatch generator: what the reference's own tests pin
+(tests/bayesian_neural_network/*, tests/test_data_batches.py), CPU parts here, GPU parts marked."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+from pysgmcmc_amd.data_batches import Placeholder, generate_batches, generate_shuffled_batches
+from pysgmcmc_amd.models.bayesian_neural_network import (
+    BayesianNeuralNetwork, BNNCost, init_mlp_params, log_variance_prior_log_like, weight_prior_log_like)
+from pysgmcmc_amd.sampling import Sampler
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---------------------------------------------------------------- priors (golden values of the reference)
+
+def test_prior_golden_values():
+    """tests/bayesian_neural_network/test_priors.py:20-81; 1 ulp of fp64 allowed (reduction order)."""
+    d = np.load(os.path.join(GOLDEN, "bnn_priors.npz"))
+    got = float(log_variance_prior_log_like(d["log_variance_input"], mean=1e-6, var=0.01, dtype=torch.float64))
+    assert np.isclose(got, -325.5744411137498, rtol=1e-14, atol=0)
+    got = float(weight_prior_log_like([d["weights_input_%d" % k] for k in range(9)]))
+    assert np.isclose(got, -0.01895130158314839, rtol=1e-14, atol=0)
+
+
+def test_bnn_cost_matches_oracle_and_fused_path(oracle):
+    """torch NLL == numpy restatement of bayesian_neural_network.py:365-388; fused analytic backward == autograd."""
+    rng = np.random.default_rng(0)
+    params = init_mlp_params(1, seed=4, dtype=torch.float64)
+    for p in params[1::2]:
+        p.normal_()
+    X, Y = rng.normal(size=(20, 1)), rng.normal(size=(20, 1))
+    xp, yp = Placeholder().feed(torch.tensor(X)), Placeholder().feed(torch.tensor(Y))
+    c = BNNCost(xp, yp, batch_size=20, n_examples=100)
+    nll, mse = c.negative_log_likelihood(params, xp.value, yp.value)
+    want_nll, want_mse = oracle.bnn_negative_log_likelihood([p.numpy() for p in params], X, Y, 20, 100)
+    assert np.isclose(float(nll), want_nll, rtol=1e-13) and np.isclose(float(mse), want_mse, rtol=1e-13)
+    ps = [p.clone().requires_grad_(True) for p in params]
+    grads = torch.autograd.grad(c(ps), ps)
+    gv = [torch.empty_like(p) for p in params]
+    cost2 = c.cost_and_grad(params, gv)
+    assert np.isclose(float(cost2), want_nll, rtol=1e-13)
+    for a, b in zip(grads, gv):
+        assert torch.allclose(a, b, rtol=1e-10, atol=1e-14)
+
+
+def test_init_seeding_and_shapes():
+    """tests/bayesian_neural_network/test_seeding.py: same seed => identical initial weights."""
+    a, b, c = init_mlp_params(1, seed=7), init_mlp_params(1, seed=7), init_mlp_params(1, seed=8)
+    assert [tuple(p.shape) for p in a] == [(1, 50), (50,), (50, 50), (50,), (50, 50), (50,), (50, 1), (1,), (1, 1)]
+    assert sum(p.numel() for p in a) == 5252
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and not torch.equal(a[0], c[0])
+    assert float(a[-1]) == pytest.approx(np.log(1e-3)) and all(float(p.abs().sum()) == 0 for p in a[1:-1:2])
+    w = init_mlp_params(400, hidden=(300,), seed=0)[0]
+    assert abs(float(w.var()) * 400 - 1.0) < 0.03 and float(w.abs().max()) <= 2.3 / 20
+
+
+# ---------------------------------------------------------------- constructor checks
+# tests/bayesian_neural_network/test_invalid_inputs.py:17-100
+
+@pytest.mark.parametrize("kw", [dict(n_nets=0), dict(n_nets=1.5), dict(n_iters=-3), dict(n_iters="a"),
+                                dict(batch_size=0), dict(batch_size=2.0), dict(sample_steps=0),
+                                dict(burn_in_steps=-1), dict(burn_in_steps=1.0), dict(dtype=torch.int32)])
+def test_invalid_constructor_arguments(kw):
+    with pytest.raises(AssertionError):
+        BayesianNeuralNetwork(**kw)
+
+
+def test_unsupported_sampling_method_and_predict_before_train():
+    for bad in (Sampler.RelativisticSGHMC, Sampler.SVGD, "SGHMC", 0):
+        with pytest.raises(ValueError):
+            BayesianNeuralNetwork(sampling_method=bad)
+    with pytest.raises(ValueError):
+        BayesianNeuralNetwork().predict(np.zeros((3, 1)))
+
+
+# ---------------------------------------------------------------- batches (tests/test_data_batches.py:79-209)
+
+@given(st.integers(max_value=0))
+@settings(max_examples=20, deadline=None)
+def test_invalid_batch_size(batch_size):
+    X, y = np.zeros((10, 2)), np.zeros(10)
+    with pytest.raises(AssertionError):
+        next(generate_batches(X, y, Placeholder(), Placeholder(), batch_size=batch_size))
+
+
+@pytest.mark.parametrize("seed", [-1, 2 ** 32, 1.5, "a"])
+def test_invalid_seed(seed):
+    X, y = np.zeros((10, 2)), np.zeros(10)
+    with pytest.raises(AssertionError):
+        next(generate_batches(X, y, Placeholder(), Placeholder(), batch_size=2, seed=seed))
+
+
+@given(st.integers(1, 60), st.integers(1, 80), st.integers(1, 5), st.integers(0, 2 ** 32 - 1))
+@settings(max_examples=40, deadline=None)
+def test_batch_shapes_clamping_and_seed_reproducibility(n, batch_size, d, seed):
+    rng = np.random.RandomState(0)
+    X, y = rng.rand(n, d), rng.rand(n)
+    xp, yp = Placeholder(), Placeholder()
+    g1 = generate_batches(X, y, xp, yp, batch_size=batch_size, seed=seed)
+    g2 = generate_batches(X, y, xp, yp, batch_size=batch_size, seed=seed)
+    ref = np.random.RandomState(seed)
+    eff = min(batch_size, n)
+    for _ in range(4):
+        b1, b2 = next(g1), next(g2)
+        assert tuple(b1[xp].shape) == (eff, d) and tuple(b1[yp].shape) == (eff, 1)
+        assert torch.equal(b1[xp], b2[xp]) and torch.equal(b1[yp], b2[yp])
+        start = ref.randint(0, n - eff + 1)                   # the reference's window stream
+        assert np.array_equal(b1[xp].numpy(), X[start:start + eff])
+        assert np.array_equal(b1[yp].numpy().ravel(), y[start:start + eff])
+
+
+def test_shuffled_batches_keep_rows_paired():
+    X = np.arange(50, dtype=np.float64).reshape(50, 1)
+    y = np.arange(50, dtype=np.float64)
+    xp, yp = Placeholder(), Placeholder()
+    g = generate_shuffled_batches(X, y, xp, yp, batch_size=10, seed=3)
+    for _ in range(5):
+        b = next(g)
+        assert torch.equal(b[xp].ravel(), b[yp].ravel())
+        assert sorted(b[xp].ravel().tolist()) == list(range(int(b[xp].min()), int(b[xp].min()) + 10))
+
+
+# ---------------------------------------------------------------- end to end on the GPU
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,dtype", [(Sampler.SGHMC, torch.float64), (Sampler.SGHMC, torch.float32),
+                                           (Sampler.SGLD, torch.float32)])
+def test_train_predict_sinc(gpu, method, dtype):
+    """tests/bayesian_neural_network/test_train_predict.py:12-48: 100 sinc points, burn_in_steps=1000,
+    n_nets=10, defaults otherwise -> test MSE < 0.1; individual predictions have n_nets rows (:75-115)."""
+    rng = np.random.RandomState(1)
+    X = rng.rand(100, 1)
+    y = np.sinc(X * 10 - 5).sum(axis=1)
+    X_test = np.linspace(0, 1, 100)[:, None]
+    y_test = np.sinc(X_test * 10 - 5).sum(axis=1)
+    bnn = BayesianNeuralNetwork(session=gpu, sampling_method=method, dtype=dtype, burn_in_steps=1000, n_nets=10,
+                                seed=1)
+    bnn.train(X, y)
+    assert bnn.is_trained and len(bnn.samples) == 10
+    mean, var = bnn.predict(X_test)
+    assert mean.shape == (100,) and var.shape == (100,) and (var >= 0).all()
+    assert np.mean((y_test - mean) ** 2) < 0.1
+    f_out, noise = bnn.predict(X_test, return_individual_predictions=True)
+    assert f_out.shape == (10, 100) and noise.shape == (10, 100)
+    assert bnn.sampler.use_hip_graph and bnn.sampler.n_iterations >= 1900
+
+
+@pytest.mark.gpu
+def test_train_is_seed_reproducible_and_graph_equals_eager(gpu):
+    rng = np.random.RandomState(2)
+    X, y = rng.rand(60, 2), rng.rand(60)
+
+    def run(graph):
+        bnn = BayesianNeuralNetwork(session=gpu, dtype=torch.float32, burn_in_steps=40, sample_steps=10, n_nets=5,
+                                    seed=3, hidden=(16, 16))
+        bnn.use_hip_graph = graph
+        bnn.train(X, y)
+        return bnn.predict(X[:7])
+    (m1, v1), (m2, v2), (m3, v3) = run(True), run(True), run(False)
+    assert np.array_equal(m1, m2) and np.array_equal(v1, v2)
+    assert np.allclose(m1, m3, rtol=1e-5, atol=1e-6)
