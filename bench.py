@@ -35,10 +35,18 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:35
-BYTES_PER_PARAM = {"sghmc_frozen": 24, "sghmc_adapt": 48}
-LAYERS = (784, 2048, 2048, 2048)
+# algorithmic bytes per parameter per launch, fp32
+BYTES_PER_PARAM = {"sghmc_frozen": 24, "sghmc_adapt": 48, "sgld_frozen": 16, "sgld_adapt": 40, "rsghmc": 20}
 BATCH = 256
 N_DATA = 100_000
+# workloads: the default is BASELINE.json configs[2]; the 50 M ones are configs[4]'s two samplers
+# (HBM-resident working sets, burn-in stepsize ramp) for profiles/, not the headline line.
+WORKLOADS = {
+    "bnn10m-sghmc": dict(sampler="sghmc", layers=(784, 2048, 2048, 2048)),        # 10 002 434 params
+    "bnn50m-sgld": dict(sampler="sgld", layers=(512, 4864, 4864, 4864)),          # 49 826 818 params
+    "bnn50m-rsghmc": dict(sampler="rsghmc", layers=(512, 4864, 4864, 4864)),
+}
+LAYERS = WORKLOADS["bnn10m-sghmc"]["layers"]
 
 
 def parse():
@@ -48,6 +56,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rhat-every", type=int, default=100, help="R-hat exchange cadence (steps), N > 1")
     ap.add_argument("--moments-every", type=int, default=10, help="Welford moments cadence (steps)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bnn10m-sghmc")
     ap.add_argument("--eager", action="store_true", help="step eagerly instead of replaying one hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-update-only", action="store_true", help="skip the kernel-only loops (for rocprof runs)")
@@ -55,25 +64,35 @@ def parse():
     return ap.parse_args()
 
 
-def build_chain(dev, rank):
+def build_chain(dev, rank, workload="bnn10m-sghmc"):
     from pysgmcmc_amd.data_batches import Placeholder, generate_batches
     from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
-    from pysgmcmc_amd.samplers import SGHMCSampler
-    from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+    from pysgmcmc_amd.samplers import RelativisticSGHMCSampler, SGHMCSampler, SGLDSampler
+    from pysgmcmc_amd.stepsize_schedules import BurnInRampStepsizeSchedule, ConstantStepsizeSchedule
 
+    spec = WORKLOADS[workload]
+    layers = spec["layers"]
     g = torch.Generator(device=dev).manual_seed(0)             # same synthetic dataset on every rank
-    X = torch.randn(N_DATA, LAYERS[0], device=dev, generator=g)
+    X = torch.randn(N_DATA, layers[0], device=dev, generator=g)
     y = torch.randn(N_DATA, device=dev, generator=g)
     xp = Placeholder(dtype=torch.float32, device=dev, name="X_Minibatch")
     yp = Placeholder(dtype=torch.float32, device=dev, name="Y_Minibatch")
-    params = init_mlp_params(LAYERS[0], hidden=LAYERS[1:], seed=1000 + rank, dtype=torch.float32, device=dev)
+    params = init_mlp_params(layers[0], hidden=layers[1:], seed=1000 + rank, dtype=torch.float32, device=dev)
     cost = BNNCost(xp, yp, batch_size=BATCH, n_examples=N_DATA)
-    return SGHMCSampler(
-        params=params, cost_fun=cost,
-        batch_generator=generate_batches(X, y, xp, yp, batch_size=BATCH, seed=rank),
-        stepsize_schedule=ConstantStepsizeSchedule(0.01), mdecay=0.05, scale_grad=float(N_DATA),
-        burn_in_steps=8,                                       # adapted during warmup; timed steps are frozen
-        session=dev, dtype=torch.float32, seed=1234 + rank)
+    common = dict(params=params, cost_fun=cost,
+                  batch_generator=generate_batches(X, y, xp, yp, batch_size=BATCH, seed=rank),
+                  session=dev, dtype=torch.float32, seed=1234 + rank)
+    if spec["sampler"] == "sghmc":
+        return SGHMCSampler(stepsize_schedule=ConstantStepsizeSchedule(0.01), mdecay=0.05,
+                            scale_grad=float(N_DATA),
+                            burn_in_steps=8,                   # adapted during warmup; timed steps are frozen
+                            **common)
+    if spec["sampler"] == "sgld":
+        # configs[4]: preconditioned SGLD with a burn-in stepsize ramp (a StepsizeSchedule subclass)
+        return SGLDSampler(stepsize_schedule=BurnInRampStepsizeSchedule(1e-4, 1e-3, burn_in_steps=8),
+                           A=1.0, scale_grad=float(N_DATA), burn_in_steps=8, **common)
+    return RelativisticSGHMCSampler(stepsize_schedule=BurnInRampStepsizeSchedule(1e-4, 1e-3, burn_in_steps=8),
+                                    mass=1.0, speed_of_light=1.0, D=1.0, Bhat=0.0, **common)
 
 
 class KernelTimer(object):
@@ -83,8 +102,10 @@ class KernelTimer(object):
         from pysgmcmc_amd import kernels
         self.pairs = []
         self.enabled = False
-        inner = kernels.sghmc_step                 # ONE launch: the fused update kernel (K1)
+        for name in ("sghmc_step", "sgld_step", "rsghmc_step"):   # each is ONE launch: the fused update kernel
+            setattr(kernels, name, self._wrap(getattr(kernels, name)))
 
+    def _wrap(self, inner):
         def timed(*a, **kw):
             if not self.enabled:
                 return inner(*a, **kw)
@@ -93,7 +114,7 @@ class KernelTimer(object):
             inner(*a, **kw)
             e1.record()
             self.pairs.append((e0, e1))
-        kernels.sghmc_step = timed
+        return timed
 
     @staticmethod
     def event_pair_overhead_us(reps=200):
@@ -195,7 +216,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)         # RCCL over xGMI
 
     from pysgmcmc_amd import kernels
-    sampler = build_chain(dev, rank)
+    sampler = build_chain(dev, rank, args.workload)
+    kind = WORKLOADS[args.workload]["sampler"]
     sampler.sample_format = "view"                             # no D2H copy of 40 MB per sample
     sampler.use_hip_graph = not args.eager
     n = sampler.arena.n
@@ -222,8 +244,7 @@ def main():
 
     for i in range(args.warmup):
         one_step(i)
-    assert args.warmup < 8 or not sampler.is_burning_in
-    frozen_phase = not sampler._adapting
+    frozen_phase = not getattr(sampler, "_adapting", False)
     moments.reset()
     timer.enabled = True
     fence()
@@ -240,7 +261,8 @@ def main():
     assert torch.isfinite(sampler.arena.row("theta")).all()
 
     if rank == 0:
-        mode = "sghmc_frozen" if frozen_phase else "sghmc_adapt"
+        mode = "rsghmc" if kind == "rsghmc" else "%s_%s" % (kind, "frozen" if frozen_phase else "adapt")
+        op_name = {"sghmc": "SghmcOp", "sgld": "SgldOp", "rsghmc": "RsghmcOp"}[kind]
         k_us = timer.mean_us()                      # raw hipEvent bracket, includes the event-pair overhead
         ev_us = timer.event_pair_overhead_us()
         alg_bytes = BYTES_PER_PARAM[mode] * n
@@ -253,15 +275,17 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SGHMC (frozen preconditioner) full next(sampler) step: BNN fwd+bwd + fused update; "
-                                   "4-layer tanh MLP BNN 784-2048-2048-2048-1, %d params, batch %d, "
-                                   "1 chain per GPU" % (n, BATCH),
+            "config": {"workload": "%s: %s (%s) full next(sampler) step: BNN fwd+bwd + fused update; "
+                                   "4-layer tanh MLP BNN %s-1, %d params, batch %d, 1 chain per GPU" % (
+                                       args.workload, kind.upper(), mode, "-".join(map(str, WORKLOADS[args.workload]["layers"])),
+                                       n, BATCH),
                        "params": n, "batch": BATCH, "chains": world,
                        "rhat_every": args.rhat_every if world > 1 else None,
                        "moments_every": args.moments_every, "hip_graph": bool(sampler.use_hip_graph),
                        "launch": kernels.get_launch_config()},
-            "roofline": {"bound": "hbm", "kernel": "stream_quads_vec<SghmcOp<float,%s,false>>" %
-                         ("false" if frozen_phase else "true"),
+            "roofline": {"bound": "hbm", "kernel": "stream_quads_vec<%s<float,%s,false>,1,%s,true>" % (
+                             op_name, "false" if frozen_phase else "true",
+                             "true" if alg_bytes > (640 << 20) else "false"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes,
@@ -276,9 +300,9 @@ def main():
         if rhat_summary[0] is not None:
             line["rhat"] = {k: round(v, 4) for k, v in rhat_summary[0].items()}
         if world == 1:
-            if not args.no_update_only:
+            if not args.no_update_only and kind == "sghmc":
                 line["update_only"] = update_only(sampler)
-            if not args.no_cpu_baseline:
+            if not args.no_cpu_baseline and kind == "sghmc":
                 line["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(line))
         sys.stdout.flush()

@@ -60,7 +60,7 @@ int sgmcmc_device_count(void);
  *   quads_per_thread: 1, 2 or 4 float4 groups in flight per lane (default 1)
  *   max_blocks: grid cap, the kernel grid-strides beyond it (default 2^20 = uncapped)
  *   nontemporal: 0 plain, 1 nt loads+stores, 2 auto = nt iff one launch touches more
- *                than 768 MiB, i.e. cannot live in the 256 MiB Infinity Cache (default 2)
+ *                than 640 MiB, i.e. cannot live in the 256 MiB Infinity Cache (default 2)
  * Pass 0 (or -1 for nontemporal) to keep the current value. */
 int sgmcmc_set_launch_config(int block_threads, int quads_per_thread, int max_blocks, int nontemporal);
 int sgmcmc_get_launch_config(int *block_threads, int *quads_per_thread, int *max_blocks, int *nontemporal);

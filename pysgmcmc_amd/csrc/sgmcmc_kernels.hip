@@ -770,8 +770,8 @@ std::atomic<int> g_nt{2};                 // 0 = plain, 1 = nt, 2 = auto by work
 // Above this many bytes touched per launch the arrays cannot stay in the 256 MiB
 // Infinity Cache between steps and nt accesses win (+6..7 % at 1.2 GB); below it
 // plain accesses win (the cache holds part of the working set across steps:
-// -5..-12 % with nt at 240 MB and 480 MB). Measured on MI355X, gpurun_out/tune_*.txt.
-constexpr size_t NT_AUTO_BYTES = (size_t)768 << 20;
+// -5..-12 % with nt at 240 MB and 480 MB; +8 % at 800 MB). Measured on MI355X, profiles/r01_tune_*.txt.
+constexpr size_t NT_AUTO_BYTES = (size_t)640 << 20;
 
 inline bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
