@@ -20,11 +20,13 @@ explicitly passed per-chain moments.
 """
 import math
 
+import numpy as np
 import torch
 
 from pysgmcmc_amd import kernels
 
-__all__ = ["ChainMoments", "cross_chain_rhat", "gelman_rubin", "effective_sample_sizes", "effective_n"]
+__all__ = ["ChainMoments", "cross_chain_rhat", "gelman_rubin_from_chains", "ess_across_ranks", "effective_n",
+           "effective_sample_sizes", "gelman_rubin"]
 
 
 def _dist():
@@ -81,7 +83,7 @@ def cross_chain_rhat(moments, group=None, pack=None, rhat=None, with_summary=Tru
     return rhat, {"mean": float(s[0] / n), "max": float(s[3])}
 
 
-def gelman_rubin(chains):
+def gelman_rubin_from_chains(chains):
     """R-hat from explicit chains ``(m, n_samples, P)`` on any device (torch ops; small inputs).
 
     B = n var_c(mean_c), W = mean_c(var_c), Vhat = W (n-1)/n + B/n, Rhat = sqrt(Vhat / W)."""
@@ -129,7 +131,7 @@ def effective_n(traces):
     return int(m * n / (1.0 + 2.0 * float(rho[1:t].sum())))
 
 
-def effective_sample_sizes(local_traces, group=None):
+def ess_across_ranks(local_traces, group=None):
     """ESS of each of K scalar summaries. ``local_traces``: this chain's ``(n_kept, K)`` thinned
     trace (device tensor). With a process group the traces of all chains are all-gathered
     (``n_kept * K`` floats per rank); returns a list of K ints on every rank."""
@@ -144,3 +146,32 @@ def effective_sample_sizes(local_traces, group=None):
     else:
         allx = x[None]
     return [effective_n(allx[:, :, k]) for k in range(allx.shape[2])]
+
+
+# ---------------------------------------------------------------------------
+# The reference's entry points (pysgmcmc/diagnostics/sampler_diagnostics.py:47-194):
+# sequential chains from a sampler factory, one value per parameter dimension.
+# ---------------------------------------------------------------------------
+
+def _per_variable(get_sampler, n_chains, samples_per_chain, fun):
+    from pysgmcmc_amd.diagnostics.sample_chains import multitrace
+    mt = multitrace(get_sampler, n_chains=n_chains, samples_per_chain=samples_per_chain)
+    out = {}
+    for name in mt.varnames:
+        vals = np.stack([np.asarray(v, dtype=np.float64) for v in mt.get_values(name, combine=False)])   # (m, n, ...)
+        flat = vals.reshape(vals.shape[0], vals.shape[1], -1)
+        res = np.asarray([fun(flat[:, :, k]) for k in range(flat.shape[2])])
+        out[name] = res.reshape(vals.shape[2:]) if vals.ndim > 2 else res[0]
+    return out
+
+
+def effective_sample_sizes(get_sampler, n_chains=2, samples_per_chain=100):
+    """ESS per parameter dimension: ``{varname: array}`` (signature of ``sampler_diagnostics.py:47``).
+    ``get_sampler(session=...)`` returns a fresh (possibly burnt-in) sampler."""
+    return _per_variable(get_sampler, n_chains, samples_per_chain, lambda x: effective_n(torch.as_tensor(x)))
+
+
+def gelman_rubin(get_sampler, n_chains=2, samples_per_chain=100):
+    """R-hat per parameter dimension: ``{varname: array}`` (signature of ``sampler_diagnostics.py:118``)."""
+    return _per_variable(get_sampler, n_chains, samples_per_chain,
+                         lambda x: float(gelman_rubin_from_chains(torch.as_tensor(x)[:, :, None])[0]))
