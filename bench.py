@@ -222,19 +222,23 @@ def main():
     sampler.use_hip_graph = not args.eager
     n = sampler.arena.n
     timer = KernelTimer(sampler)
-    from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, cross_chain_rhat
+    from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange
     moments = ChainMoments(n, dev)
-    pack = torch.empty(3 * n, dtype=torch.float32, device=dev)
-    rhat = torch.empty(n, dtype=torch.float32, device=dev)
+    exchange = RhatExchange(n, dev) if world > 1 else None
     rhat_summary = [None]
+    half = max(args.rhat_every // 2, 1)
 
     def one_step(i):
         next(sampler)
         if (i + 1) % args.moments_every == 0:
             moments.update(sampler.arena.row("theta"))                 # K4 Welford, every chain
-        if world > 1 and (i + 1) % args.rhat_every == 0 and moments.count >= 2:
-            # the only exchange on the path: ONE all-reduce of 3P floats over RCCL/xGMI
-            _, rhat_summary[0] = cross_chain_rhat(moments, pack=pack, rhat=rhat)
+        if exchange is not None:
+            # the only exchange on the path: ONE all-reduce of 3P floats over RCCL/xGMI, issued
+            # asynchronously and collected half a period later, so it overlaps with sampling
+            if (i + 1) % args.rhat_every == 0 and moments.count >= 2 and not exchange.pending:
+                exchange.start(moments)
+            elif exchange.pending and (i + 1) % args.rhat_every == half:
+                _, rhat_summary[0] = exchange.finish()
 
     def fence():
         torch.cuda.synchronize()
@@ -251,6 +255,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
+    if exchange is not None and exchange.pending:                      # inside the timed region
+        _, rhat_summary[0] = exchange.finish()
     fence()
     elapsed = time.perf_counter() - t0
     timer.enabled = False

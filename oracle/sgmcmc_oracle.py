@@ -74,6 +74,9 @@ def load_c():
         f = getattr(lib, "oracle_philox_normal_" + sfx)
         f.argtypes = [u64, u64, sz, vp]
         f.restype = None
+        f = getattr(lib, "oracle_philox_normal_range_" + sfx)
+        f.argtypes = [u64, u64, u64, sz, vp]
+        f.restype = None
         f = getattr(lib, "oracle_sghmc_consts_" + sfx)
         f.argtypes = [real, real, real, vp]
         f.restype = None
@@ -174,6 +177,14 @@ def c_philox_normal(seed, step, n, dtype=np.float32):
     lib = load_c()
     out = np.empty(n, dtype)
     getattr(lib, "oracle_philox_normal_" + _sfx(dtype))(seed, step, n, _p(out))
+    return out
+
+
+def c_philox_normal_range(seed, step, start, n, dtype=np.float32):
+    """xi(seed, step, i) for i in [start, start + n)."""
+    lib = load_c()
+    out = np.empty(n, dtype)
+    getattr(lib, "oracle_philox_normal_range_" + _sfx(dtype))(seed, step, start, n, _p(out))
     return out
 
 

@@ -25,7 +25,7 @@ import torch
 
 from pysgmcmc_amd import kernels
 
-__all__ = ["ChainMoments", "cross_chain_rhat", "gelman_rubin_from_chains", "ess_across_ranks", "effective_n",
+__all__ = ["ChainMoments", "cross_chain_rhat", "RhatExchange", "gelman_rubin_from_chains", "ess_across_ranks", "effective_n",
            "effective_sample_sizes", "gelman_rubin"]
 
 
@@ -81,6 +81,44 @@ def cross_chain_rhat(moments, group=None, pack=None, rhat=None, with_summary=Tru
         return rhat, None
     s = kernels.summary(rhat).cpu().numpy()
     return rhat, {"mean": float(s[0] / n), "max": float(s[3])}
+
+
+class RhatExchange(object):
+    """Non-blocking form of :func:`cross_chain_rhat`: ``start`` packs a snapshot of the moments and
+    issues the all-reduce asynchronously on RCCL's own stream, sampling continues, ``finish`` waits
+    for the collective and computes R-hat. The snapshot buffer is private, so the chain may keep
+    updating its moments in between (overlaps the only collective of the path with compute)."""
+
+    def __init__(self, n, device, group=None):
+        self.n = int(n)
+        self.group = group
+        self.pack = torch.empty(3 * self.n, dtype=torch.float32, device=device)
+        self.rhat = torch.empty(self.n, dtype=torch.float32, device=device)
+        self._work = None
+        self._count = 0
+
+    @property
+    def pending(self):
+        return self._work is not None
+
+    def start(self, moments):
+        dist = _dist()
+        if dist is None or dist.get_world_size(self.group) < 2:
+            raise RuntimeError("RhatExchange needs an initialised process group with >= 2 chains")
+        assert not self.pending, "finish() the previous exchange first"
+        kernels.rhat_pack(moments.mean, moments.m2, moments.count, self.pack)
+        self._count = moments.count
+        self._work = dist.all_reduce(self.pack, group=self.group, async_op=True)
+
+    def finish(self, with_summary=True):
+        dist = _dist()
+        self._work.wait()                     # stream-level wait: the current stream now depends on the collective
+        self._work = None
+        kernels.rhat_finish(self.pack, self.n, dist.get_world_size(self.group), self._count, self.rhat)
+        if not with_summary:
+            return self.rhat, None
+        s = kernels.summary(self.rhat).cpu().numpy()
+        return self.rhat, {"mean": float(s[0] / self.n), "max": float(s[3])}
 
 
 def gelman_rubin_from_chains(chains):

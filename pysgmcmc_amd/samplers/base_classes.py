@@ -340,7 +340,9 @@ class MCMCSampler(object):
         graph = torch.cuda.CUDAGraph()
         self._capturing = full
         try:
-            with torch.cuda.graph(graph):
+            # thread_local: other threads (e.g. the RCCL watchdog of a multi-chain job) may keep calling
+            # HIP while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 cost = self._cost_and_grad()
                 if full:
                     with torch.no_grad():

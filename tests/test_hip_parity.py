@@ -376,3 +376,32 @@ def test_grad_decay_bit_exact(gpu, oracle, npdt, thdt):
                 names = ("theta", "p")
             for name in names:
                 _assert_same(getattr(gst, name), getattr(cst, name), "%s grad_decay step %d %s" % (sampler, t, name))
+
+
+def test_large_array_64bit_indexing(gpu, oracle):
+    """268 435 459 parameters (2^28 + 3: > 2^30 bytes per array, ragged tail, > 2^20-block grid-stride):
+    slices at the start, around 2^27 and at the very end are bit-equal to the oracle (injected noise), and
+    the in-register Philox stream at element indices ~2^28 equals the oracle's stream."""
+    from pysgmcmc_amd import kernels
+    n = (1 << 28) + 3
+    g = torch.Generator(device=gpu).manual_seed(1)
+    theta = torch.randn(n, device=gpu, generator=g)
+    V = torch.randn(n, device=gpu, generator=g) * 0.01
+    grad = torch.randn(n, device=gpu, generator=g)
+    minv = torch.rand(n, device=gpu, generator=g) + 0.5
+    xi = torch.randn(n, device=gpu, generator=g)
+    windows = [(0, 1001), ((1 << 27) - 500, (1 << 27) + 501), (n - 1003, n)]
+    before = [{k: t[a:b].cpu().numpy().copy() for k, t in (("theta", theta), ("V", V), ("grad", grad), ("minv", minv),
+                                                          ("xi", xi))} for a, b in windows]
+    kernels.sghmc_step(theta, V, grad, None, None, None, minv, None, 0.01, 1e5, 0.05, False, xi=xi)
+    for (a, b), old in zip(windows, before):
+        st = oracle.CState(old["theta"], np.float32)
+        st.V[:] = old["V"]; st.minv[:] = old["minv"]
+        oracle.c_sghmc_step(st, old["grad"], 0.01, 1e5, 0.05, False, old["xi"])
+        assert np.array_equal(theta[a:b].cpu().numpy(), st.theta) and np.array_equal(V[a:b].cpu().numpy(), st.V)
+    del xi, grad, V, minv
+    kernels.philox_normal(theta, 77, 5)
+    for a, b in windows:
+        want = oracle.c_philox_normal_range(77, 5, a, b - a, np.float32).astype(np.float64)
+        got = theta[a:b].cpu().numpy().astype(np.float64)
+        assert np.abs(got - want).max() < 1e-4 and np.abs(got - want).mean() < 1e-6

@@ -34,7 +34,7 @@ def _worker(rank, world, port, out_dir):
     kernels.sghmc_step = oracle_shim.sghmc_step
     oracle_shim.install_diagnostics()
     from itertools import islice
-    from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, cross_chain_rhat, ess_across_ranks
+    from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange, cross_chain_rhat, ess_across_ranks
     from pysgmcmc_amd.samplers import SGHMCSampler
     from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
 
@@ -52,6 +52,12 @@ def _worker(rank, world, port, out_dir):
             kept.append(sample.clone().numpy())
             trace.append([float(cost), float(sample[0]), float(sample[1])])
     rhat, summ = cross_chain_rhat(mom)
+    # the non-blocking form gives the same numbers, and the chain may move on in between
+    ex = RhatExchange(n, "cpu")
+    ex.start(mom)
+    next(s)
+    rhat2, summ2 = ex.finish()
+    assert torch.equal(rhat, rhat2) and summ == summ2 and not ex.pending
     ess = ess_across_ranks(torch.tensor(trace, dtype=torch.float32))
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), kept=np.array(kept), rhat=rhat.numpy(),
              rhat_mean=summ["mean"], rhat_max=summ["max"], ess=np.array(ess), trace=np.array(trace),
