@@ -162,11 +162,24 @@ def update_only(sampler, iters=200):
     return out
 
 
+def usable_cores():
+    """Cores this process may actually use: min(affinity mask, cgroup CPU quota). (The GPU box shows
+    256 logical CPUs but a 16-CPU cgroup quota; 256 OpenMP threads there run 8x SLOWER than 16.)"""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(n, budget_s):
     """The fused C oracle (kind "port") on the host cores: frozen SGHMC update, Philox noise, same n."""
     from oracle import sgmcmc_oracle as O
     lib = O.load_c()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     lib.oracle_set_num_threads(cores)
     rng = np.random.default_rng(0)
     st = O.CState(rng.standard_normal(n, dtype=np.float32) * 0.02, np.float32)
@@ -191,9 +204,19 @@ def cpu_baseline(n, budget_s):
         _ = ns.theta.copy()
         asteps += 1
     adt = time.perf_counter() - t1
+    # the same fused update with pre-generated noise (no RNG work): the memory-bound CPU figure
+    xi = rng.standard_normal(n, dtype=np.float32)
+    t2 = time.perf_counter()
+    isteps = 0
+    while isteps < 200 and (time.perf_counter() - t2) < budget_s / 4:
+        O.c_sghmc_step(st, grad, 0.01, float(N_DATA), 0.05, False, xi)
+        isteps += 1
+    idt = time.perf_counter() - t2
     return {"value": round(steps / dt, 3), "unit": "update-steps/s", "cores": cores, "kind": "port",
             "sample": "%d frozen SGHMC update steps (update kernel only, no BNN gradient) of %d fp32 params, "
-                      "fused C oracle + OpenMP, Philox noise, %.1f s" % (steps, n, dt),
+                      "fused C oracle + OpenMP on %d threads, Philox noise generated in the loop like the GPU "
+                      "kernel, %.1f s" % (steps, n, cores, dt),
+            "injected_noise_steps_per_s": round(isteps / idt, 3) if isteps else None,
             "opbyop_numpy_steps_per_s": round(asteps / adt, 3) if asteps else None}
 
 

@@ -220,6 +220,17 @@ class MCMCSampler(object):
                 torch._foreach_copy_(dst, src)
         return cost.detach()
 
+    def _draw_noise_sample(self, sigma, shape):
+        """``sigma * N(0, 1)`` of the given shape (``base_classes.py:199-220``), materialised by the K5
+        Philox kernel from this chain's stream. The step kernels never call this: they draw the
+        same stream in registers. Uses the reserved step index 2^62 + n_iterations."""
+        n = 1
+        for d in tuple(shape):
+            n *= int(d)
+        out = torch.empty(n, dtype=self._torch_dtype, device=self.device)
+        kernels.philox_normal(out, self._philox_seed, (1 << 62) + self.n_iterations)
+        return torch.as_tensor(sigma, dtype=self._torch_dtype, device=self.device) * out.reshape(tuple(shape))
+
     def _draw_noise(self):
         """Injected xi for this step, or None for the in-register Philox stream."""
         if self.noise_source is None:

@@ -278,3 +278,11 @@ def test_bnn_cost_path_hip_equals_autograd(gpu, dt):
                 for a, b, p in zip(grads, gv, params):
                     full = b + c.grad_theta_coef * p           # the term the update kernel adds when folded
                     assert float((a - full).abs().max()) <= tol * float(a.abs().max()) + (1e-9 if dt == torch.float32 else 1e-15)
+
+
+def test_draw_noise_sample_api(gpu):
+    s = SGHMCSampler(params=[torch.zeros(3, 2)], cost_fun=lambda p: (p[0] ** 2).sum(), session=gpu,
+                     dtype=torch.float32, seed=4)
+    z = s._draw_noise_sample(sigma=2.0, shape=(1000, 1))
+    z2 = s._draw_noise_sample(sigma=2.0, shape=(1000, 1))
+    assert z.shape == (1000, 1) and torch.equal(z, z2) and abs(z.std().item() - 2.0) < 0.2
