@@ -175,24 +175,37 @@ int sgmcmc_summary_f64(const double *x, size_t n, double *out4, void *workspace,
 
 /* BNN cost path helpers (the gradient producer of the update path; replaces the TF graph of
  * pysgmcmc/models/bayesian_neural_network.py:365-388 after the network's last GEMM).
+ *
  * bnn_head: from the network mean output `mean[B]`, targets `y[B]`, the scalar log-variance
- * parameter `log_var` and sum(theta^2) over all parameters (`theta_sumsq`, a device double, e.g.
- * stats_out[0] of the previous step), computes in one launch: delta[B] = d NLL / d mean,
- * cost_out = NLL (likelihood / batch_size + both priors / n_examples), grad_log_var_out = d NLL /
- * d log_var and mse_out. All scalar outputs are device pointers. fold_prior_grad = 1 leaves the
- * weight-prior gradient term (wdecay / (n_params * n_examples)) * theta out of grad_log_var_out
- * because the caller passes it to the update kernel as grad_decay.
- * tanh_backward: delta[i] *= 1 - h[i]^2.                                                       */
-int sgmcmc_bnn_head_f32(const float *mean, const float *y, const float *log_var, const double *theta_sumsq, size_t B,
+ * parameter `log_var` and sum(theta^2) over all parameters, computes in ONE launch:
+ *   delta[B] = d NLL / d mean, cost_out = NLL (likelihood / batch_size + both priors / n_examples),
+ *   grad_log_var_out = d NLL / d log_var, mse_out, and (if grad_last_bias_out != NULL) the bias
+ *   gradient of a single-output last layer = sum_i delta[i] (+ prior term; `last_bias` = that bias).
+ * sum(theta^2) comes from `theta_sumsq` (a device double) or, when `stats_ws` != NULL, from the
+ * per-block partials the previous step kernel left in its statistics workspace (summed here in a
+ * fixed order; saves the K7 launch on the critical path). All scalar outputs are device pointers.
+ * fold_prior_grad = 1 leaves the weight-prior gradient term (wdecay / (n_params * n_examples)) * theta
+ * out of the gradients because the caller passes it to the update kernel as grad_decay.
+ *
+ * tanh_backward: delta[i] *= 1 - h[i]^2.
+ * tanh_backward_colsum: the same on a row-major [rows][cols] matrix, plus colsum[c] = sum_r delta[r][c]
+ * (+ beta * bias[c] if beta != 0): the bias gradient of that layer, deterministic (no atomics).         */
+int sgmcmc_bnn_head_f32(const float *mean, const float *y, const float *log_var, const double *theta_sumsq,
+                        const void *stats_ws, const float *last_bias, size_t B,
                         double batch_size, double n_examples, double n_params, double wdecay, double prior_mean,
                         double prior_var, int fold_prior_grad, float *delta, float *cost_out, float *grad_log_var_out,
-                        float *mse_out, sgmcmc_stream_t stream);
-int sgmcmc_bnn_head_f64(const double *mean, const double *y, const double *log_var, const double *theta_sumsq, size_t B,
+                        float *grad_last_bias_out, float *mse_out, sgmcmc_stream_t stream);
+int sgmcmc_bnn_head_f64(const double *mean, const double *y, const double *log_var, const double *theta_sumsq,
+                        const void *stats_ws, const double *last_bias, size_t B,
                         double batch_size, double n_examples, double n_params, double wdecay, double prior_mean,
                         double prior_var, int fold_prior_grad, double *delta, double *cost_out, double *grad_log_var_out,
-                        double *mse_out, sgmcmc_stream_t stream);
+                        double *grad_last_bias_out, double *mse_out, sgmcmc_stream_t stream);
 int sgmcmc_tanh_backward_f32(float *delta, const float *h, size_t n, sgmcmc_stream_t stream);
 int sgmcmc_tanh_backward_f64(double *delta, const double *h, size_t n, sgmcmc_stream_t stream);
+int sgmcmc_tanh_backward_colsum_f32(float *delta, const float *h, size_t rows, size_t cols, const float *bias, float beta,
+                                    float *colsum, sgmcmc_stream_t stream);
+int sgmcmc_tanh_backward_colsum_f64(double *delta, const double *h, size_t rows, size_t cols, const double *bias,
+                                    double beta, double *colsum, sgmcmc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -46,7 +46,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <bool NT>
 __device__ __forceinline__ void load_quad(const float *__restrict__ p, size_t q, float (&v)[4])
@@ -694,42 +693,67 @@ struct BnnHeadConsts {
 // fused statistics). Writes delta[B] = d cost/d mean, cost_out, grad_s_out (into the gradient
 // arena slot of output_bias) and mse_out.
 template <typename T>
-__global__ void __launch_bounds__(256) bnn_head_kernel(const T *__restrict__ mean, const T *__restrict__ y,
+__global__ void __launch_bounds__(1024) bnn_head_kernel(const T *__restrict__ mean, const T *__restrict__ y,
                                                        const T *__restrict__ s_ptr, const double *__restrict__ theta_sumsq,
+                                                       const double *__restrict__ stats_ws, const T *__restrict__ last_bias,
                                                        size_t B, BnnHeadConsts k, T *__restrict__ delta,
                                                        T *__restrict__ cost_out, T *__restrict__ grad_s_out,
-                                                       T *__restrict__ mse_out)
+                                                       T *__restrict__ grad_bias_out, T *__restrict__ mse_out)
 {
-    __shared__ double lds[4];
+    __shared__ double lds[2][16];
     const double s = (double)*s_ptr;
     const double es = exp(s);
     const double inv = 1.0 / (es + 1e-16);                       // :369
     const double dscale = -(inv / k.batch_size);
-    double sse = 0.0;
+    double sse = 0.0, sumr = 0.0;
     for (size_t i = threadIdx.x; i < B; i += blockDim.x) {
         double r = (double)y[i] - (double)mean[i];
         sse += r * r;                                            // :370
+        sumr += r;
         delta[i] = (T)(r * dscale);                              // d cost / d mean_i
     }
+    // sum(theta^2): given directly, or as the per-block partials the previous step kernel left in its
+    // statistics workspace (statistic 0 of [4][nparts] after the 32-byte header), summed here in a
+    // fixed order -- saves the separate K7 launch on the step's critical path
+    double tsq = 0.0;
+    if (stats_ws != nullptr) {
+        const unsigned nparts = (unsigned)reinterpret_cast<const unsigned long long *>(stats_ws)[0];
+        const double *__restrict__ p = stats_ws + 4;
+        unsigned i = threadIdx.x;
+        const unsigned bd = blockDim.x;
+        for (; i + 3u * bd < nparts; i += 4u * bd) {           // 4 loads in flight, fixed add order
+            double x0 = p[i], x1 = p[i + bd], x2 = p[i + 2u * bd], x3 = p[i + 3u * bd];
+            tsq += x0; tsq += x1; tsq += x2; tsq += x3;
+        }
+        for (; i < nparts; i += bd) tsq += p[i];
+    }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sse += __shfl_down(sse, off, 64);
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = sse;
+    for (int off = 32; off >= 1; off >>= 1) {
+        sse += __shfl_down(sse, off, 64);
+        sumr += __shfl_down(sumr, off, 64);
+        tsq += __shfl_down(tsq, off, 64);
+    }
+    __shared__ double lds_t[16];
+    if ((threadIdx.x & 63) == 0) { lds[0][threadIdx.x >> 6] = sse; lds[1][threadIdx.x >> 6] = sumr; lds_t[threadIdx.x >> 6] = tsq; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += lds[w];
+        double tot = 0.0, rs = 0.0, tq = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { tot += lds[0][w]; rs += lds[1][w]; tq += lds_t[w]; }
+        if (stats_ws == nullptr) tq = *theta_sumsq;
         const double Bd = (double)B;
         double log_like = (-(tot * (0.5 * inv)) - 0.5 * s * Bd) / k.batch_size;            // :371-377
         double d = s - k.ln_prior_mean;
         double lvp = -(d * d) / k.lvp_den - 0.5 * k.ln_prior_var;                           // :102-107
-        double wp = (-0.5 * k.wdecay) * (*theta_sumsq) / k.wp_den;                          // :131-141
+        double wp = (-0.5 * k.wdecay) * tq / k.wp_den;                                      // :131-141
         double cost = -(log_like + lvp / k.n_examples + wp / k.n_examples);                 // :380-388
-        double prior_coef = k.wdecay / (k.wp_den * k.n_examples);
+        double prior_coef = k.fold_prior_grad ? 0.0 : k.wdecay / (k.wp_den * k.n_examples);
         double ds = -((tot * (0.5 * es * inv * inv) - 0.5 * Bd) / k.batch_size
-                      + (-2.0 * d / k.lvp_den) / k.n_examples) + (k.fold_prior_grad ? 0.0 : prior_coef * s);
+                      + (-2.0 * d / k.lvp_den) / k.n_examples) + prior_coef * s;
         *cost_out = (T)cost;
         *grad_s_out = (T)ds;
         *mse_out = (T)(tot / Bd);
+        // bias gradient of the single-output last layer: sum_i delta_i (+ prior term unless folded)
+        if (grad_bias_out != nullptr) *grad_bias_out = (T)(rs * dscale + prior_coef * (double)*last_bias);
     }
 }
 
@@ -741,6 +765,50 @@ __global__ void __launch_bounds__(256) tanh_backward_kernel(T *__restrict__ delt
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += G) {
         T hv = h[i];
         delta[i] = delta[i] * (T(1) - hv * hv);
+    }
+}
+
+// Fused tanh backward + bias gradient of the layer below: delta[r][c] *= 1 - h[r][c]^2 and
+// colsum[c] = sum_r delta[r][c] (+ beta * bias[c]). One block of 1024 lanes owns 64 columns:
+// lane = column, the 16 waves stride over the rows, LDS combines the 16 row-partials in a fixed
+// order (deterministic, no atomics). Row-major [rows][cols].
+template <typename T>
+__global__ void __launch_bounds__(1024) tanh_backward_colsum_kernel(T *__restrict__ delta, const T *__restrict__ h,
+                                                                     size_t rows, size_t cols, const T *__restrict__ bias,
+                                                                     T beta, T *__restrict__ colsum)
+{
+    __shared__ T lds[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t c = (size_t)blockIdx.x * 64 + lane;
+    T acc = T(0);
+    if (c < cols) {
+        size_t r = wave;
+        for (; r + 48 < rows; r += 64) {                      // 4 rows per trip: 8 loads in flight per lane
+            T hv[4], dv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const size_t i = (r + 16 * u) * cols + c; hv[u] = h[i]; dv[u] = delta[i]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                T d = dv[u] * (T(1) - hv[u] * hv[u]);
+                delta[(r + 16 * u) * cols + c] = d;
+                acc += d;
+            }
+        }
+        for (; r < rows; r += 16) {
+            const size_t i = r * cols + c;
+            T hv = h[i];
+            T d = delta[i] * (T(1) - hv * hv);
+            delta[i] = d;
+            acc += d;
+        }
+    }
+    lds[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < cols) {
+        T tot = T(0);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += lds[w][lane];
+        colsum[c] = (beta != T(0)) ? tot + beta * bias[c] : tot;
     }
 }
 
@@ -795,8 +863,6 @@ inline size_t max_grid_for(size_t n)
     return want < cap ? (want ? want : 1) : cap;
 }
 
-__attribute__((unused)) thread_local unsigned g_last_grid = 0;
-
 template <typename Op, int QPT, bool NT>
 int launch_vec(const Op &op, size_t n, hipStream_t st)
 {
@@ -808,7 +874,6 @@ int launch_vec(const Op &op, size_t n, hipStream_t st)
     if (want == 0) want = 1;
     size_t cap = (size_t)g_max_blocks.load();
     unsigned grid = (unsigned)(want < cap ? want : cap);
-    g_last_grid = grid;
     if (op.stats_part != nullptr)
         hipLaunchKernelGGL((stream_quads_vec<Op, QPT, NT, true>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
     else
@@ -825,7 +890,6 @@ int launch_scalar(const Op &op, size_t n, hipStream_t st)
     if (want == 0) want = 1;
     size_t cap = (size_t)g_max_blocks.load();
     unsigned grid = (unsigned)(want < cap ? want : cap);
-    g_last_grid = grid;
     if (op.stats_part != nullptr)
         hipLaunchKernelGGL((stream_quads_scalar<Op, true>), dim3(grid), dim3(bt), 0, st, op, n);
     else
@@ -961,11 +1025,14 @@ inline unsigned small_grid(size_t n)
 }
 
 template <typename T>
-int bnn_head(const T *mean, const T *y, const T *s_ptr, const double *theta_sumsq, size_t B,
+int bnn_head(const T *mean, const T *y, const T *s_ptr, const double *theta_sumsq, const void *stats_ws,
+             const T *last_bias, size_t B,
                     double batch_size, double n_examples, double n_params, double wdecay, double prior_mean,
-                    double prior_var, int fold_prior_grad, T *delta, T *cost_out, T *grad_s_out, T *mse_out, hipStream_t st)
+                    double prior_var, int fold_prior_grad, T *delta, T *cost_out, T *grad_s_out, T *grad_bias_out,
+             T *mse_out, hipStream_t st)
 {
-    if (!mean || !y || !s_ptr || !theta_sumsq || !delta || !cost_out || !grad_s_out || !mse_out || B == 0)
+    if (!mean || !y || !s_ptr || (!theta_sumsq && !stats_ws) || !delta || !cost_out || !grad_s_out || !mse_out || B == 0 ||
+        (grad_bias_out && !last_bias))
         return fail(SGMCMC_EINVAL, "bnn_head: NULL argument or B == 0");
     BnnHeadConsts k;
     k.batch_size = batch_size; k.n_examples = n_examples; k.wdecay = wdecay;
@@ -973,12 +1040,26 @@ int bnn_head(const T *mean, const T *y, const T *s_ptr, const double *theta_sums
     k.lvp_den = 2.0 * prior_var + (2.0 * 1e-16 + 1e-16);
     k.ln_prior_mean = std::log(prior_mean); k.ln_prior_var = std::log(prior_var);
     k.fold_prior_grad = fold_prior_grad ? 1 : 0;
-    hipLaunchKernelGGL((bnn_head_kernel<T>), dim3(1), dim3(256), 0, st, mean, y, s_ptr, theta_sumsq, B, k, delta,
-                       cost_out, grad_s_out, mse_out);
+    hipLaunchKernelGGL((bnn_head_kernel<T>), dim3(1), dim3(1024), 0, st, mean, y, s_ptr, theta_sumsq,
+                       static_cast<const double *>(stats_ws), last_bias, B, k, delta, cost_out, grad_s_out, grad_bias_out,
+                       mse_out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch bnn_head");
 }
 
+
+template <typename T>
+int tanh_backward_colsum_impl(T *delta, const T *h, size_t rows, size_t cols, const T *bias, T beta, T *colsum,
+                                     hipStream_t st)
+{
+    if (rows == 0 || cols == 0) return 0;
+    if (!delta || !h || !colsum || (beta != T(0) && !bias))
+        return fail(SGMCMC_EINVAL, "tanh_backward_colsum: NULL argument");
+    hipLaunchKernelGGL((tanh_backward_colsum_kernel<T>), dim3((unsigned)((cols + 63) / 64)), dim3(1024), 0, st, delta, h,
+                       rows, cols, bias, beta, colsum);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch tanh_backward_colsum");
+}
 
 }  // namespace
 
@@ -1166,21 +1247,25 @@ int sgmcmc_summary_f64(const double *x, size_t n, double *out4, void *workspace,
     return summary<double>(x, n, out4, workspace, static_cast<hipStream_t>(stream));
 }
 
-int sgmcmc_bnn_head_f32(const float *mean, const float *y, const float *log_var, const double *theta_sumsq, size_t B,
+int sgmcmc_bnn_head_f32(const float *mean, const float *y, const float *log_var, const double *theta_sumsq,
+                        const void *stats_ws, const float *last_bias, size_t B,
                         double batch_size, double n_examples, double n_params, double wdecay, double prior_mean,
                         double prior_var, int fold_prior_grad, float *delta, float *cost_out, float *grad_log_var_out,
-                        float *mse_out, sgmcmc_stream_t stream)
+                        float *grad_last_bias_out, float *mse_out, sgmcmc_stream_t stream)
 {
-    return bnn_head<float>(mean, y, log_var, theta_sumsq, B, batch_size, n_examples, n_params, wdecay, prior_mean,
-                           prior_var, fold_prior_grad, delta, cost_out, grad_log_var_out, mse_out, static_cast<hipStream_t>(stream));
+    return bnn_head<float>(mean, y, log_var, theta_sumsq, stats_ws, last_bias, B, batch_size, n_examples, n_params, wdecay, prior_mean,
+                           prior_var, fold_prior_grad, delta, cost_out, grad_log_var_out, grad_last_bias_out, mse_out,
+                           static_cast<hipStream_t>(stream));
 }
-int sgmcmc_bnn_head_f64(const double *mean, const double *y, const double *log_var, const double *theta_sumsq, size_t B,
+int sgmcmc_bnn_head_f64(const double *mean, const double *y, const double *log_var, const double *theta_sumsq,
+                        const void *stats_ws, const double *last_bias, size_t B,
                         double batch_size, double n_examples, double n_params, double wdecay, double prior_mean,
                         double prior_var, int fold_prior_grad, double *delta, double *cost_out, double *grad_log_var_out,
-                        double *mse_out, sgmcmc_stream_t stream)
+                        double *grad_last_bias_out, double *mse_out, sgmcmc_stream_t stream)
 {
-    return bnn_head<double>(mean, y, log_var, theta_sumsq, B, batch_size, n_examples, n_params, wdecay, prior_mean,
-                            prior_var, fold_prior_grad, delta, cost_out, grad_log_var_out, mse_out, static_cast<hipStream_t>(stream));
+    return bnn_head<double>(mean, y, log_var, theta_sumsq, stats_ws, last_bias, B, batch_size, n_examples, n_params, wdecay, prior_mean,
+                            prior_var, fold_prior_grad, delta, cost_out, grad_log_var_out, grad_last_bias_out, mse_out,
+                           static_cast<hipStream_t>(stream));
 }
 int sgmcmc_tanh_backward_f32(float *delta, const float *h, size_t n, sgmcmc_stream_t stream)
 {
@@ -1189,6 +1274,16 @@ int sgmcmc_tanh_backward_f32(float *delta, const float *h, size_t n, sgmcmc_stre
     hipLaunchKernelGGL((tanh_backward_kernel<float>), dim3(small_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), delta, h, n);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch tanh_backward");
+}
+int sgmcmc_tanh_backward_colsum_f32(float *delta, const float *h, size_t rows, size_t cols, const float *bias, float beta,
+                                    float *colsum, sgmcmc_stream_t stream)
+{
+    return tanh_backward_colsum_impl<float>(delta, h, rows, cols, bias, beta, colsum, static_cast<hipStream_t>(stream));
+}
+int sgmcmc_tanh_backward_colsum_f64(double *delta, const double *h, size_t rows, size_t cols, const double *bias,
+                                    double beta, double *colsum, sgmcmc_stream_t stream)
+{
+    return tanh_backward_colsum_impl<double>(delta, h, rows, cols, bias, beta, colsum, static_cast<hipStream_t>(stream));
 }
 int sgmcmc_tanh_backward_f64(double *delta, const double *h, size_t n, sgmcmc_stream_t stream)
 {

@@ -15,7 +15,7 @@ from pysgmcmc_amd._lib import SgmcmcLibraryError, check, lib
 __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
-    "set_launch_config", "get_launch_config", "counter_add", "StepStats", "bnn_head", "tanh_backward", "step_stats_finish",
+    "set_launch_config", "get_launch_config", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "step_stats_finish",
 ]
 
 _SFX = {torch.float32: "f32", torch.float64: "f64"}
@@ -199,15 +199,18 @@ def summary(x, out4=None, workspace=None):
 
 
 def bnn_head(mean, y, log_var, theta_sumsq, batch_size, n_examples, n_params, wdecay, prior_mean, prior_var,
-             delta, cost_out, grad_log_var_out, mse_out, fold_prior_grad=False):
-    """Loss head of the BNN cost path in one launch (see include/sgmcmc_hip.h)."""
+             delta, cost_out, grad_log_var_out, mse_out, fold_prior_grad=False, stats_workspace=None,
+             last_bias=None, grad_last_bias_out=None):
+    """Loss head of the BNN cost path in one launch (see include/sgmcmc_hip.h). ``theta_sumsq`` is a
+    float64 device scalar, or None when ``stats_workspace`` (a StepStats.workspace) is given."""
     f = getattr(lib(), "sgmcmc_bnn_head_" + _sfx(mean))
-    if theta_sumsq.dtype != torch.float64:
+    if theta_sumsq is not None and theta_sumsq.dtype != torch.float64:
         raise TypeError("theta_sumsq must be a float64 device scalar")
     with _on(mean):
-        rc = f(_ptr(mean), _ptr(y, mean), _ptr(log_var), _ptr(theta_sumsq), mean.numel(), float(batch_size),
-               float(n_examples), float(n_params), float(wdecay), float(prior_mean), float(prior_var),
-               int(bool(fold_prior_grad)), _ptr(delta, mean), _ptr(cost_out), _ptr(grad_log_var_out), _ptr(mse_out), _stream(mean))
+        rc = f(_ptr(mean), _ptr(y, mean), _ptr(log_var), _ptr(theta_sumsq), _ptr(stats_workspace), _ptr(last_bias),
+               mean.numel(), float(batch_size), float(n_examples), float(n_params), float(wdecay), float(prior_mean),
+               float(prior_var), int(bool(fold_prior_grad)), _ptr(delta, mean), _ptr(cost_out),
+               _ptr(grad_log_var_out), _ptr(grad_last_bias_out), _ptr(mse_out), _stream(mean))
     check(rc, "sgmcmc_bnn_head")
 
 
@@ -217,3 +220,13 @@ def tanh_backward(delta, h):
     with _on(delta):
         rc = f(_ptr(delta), _ptr(h, delta), delta.numel(), _stream(delta))
     check(rc, "sgmcmc_tanh_backward")
+
+
+def tanh_backward_colsum(delta, h, colsum, bias=None, beta=0.0):
+    """delta *= 1 - h^2 in place on a row-major (rows, cols) matrix and colsum[c] = sum_r delta[r, c]
+    (+ beta * bias[c]): tanh backward fused with the bias gradient of that layer."""
+    f = getattr(lib(), "sgmcmc_tanh_backward_colsum_" + _sfx(delta))
+    rows, cols = delta.shape
+    with _on(delta):
+        rc = f(_ptr(delta), _ptr(h, delta), rows, cols, _ptr(bias), float(beta), _ptr(colsum), _stream(delta))
+    check(rc, "sgmcmc_tanh_backward_colsum")

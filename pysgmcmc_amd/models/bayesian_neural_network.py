@@ -157,11 +157,8 @@ class BNNCost(object):
         # per step at 10 M parameters. The autograd path (__call__) always includes the term.
         self.fold_prior = bool(fold_prior)
         self.grad_theta_coef = 0.0
-        # Forking the weight-gradient GEMMs onto a second stream inside the captured graph was measured
-        # on MI355X at batch 256: 291 us/step vs 275 us on one stream (the GEMMs contend for the same CUs
-        # and the cross-stream edges add latency) -> off by default.
-        self.fork_weight_grads = False
-        self._streams = {}
+        # (Forking the weight-gradient GEMMs onto a second stream inside the captured graph was measured
+        # on MI355X at batch 256: 291 us/step vs 275 us on one stream -- not kept.)
 
     # -- autograd path (any differentiable network) --
     def __call__(self, params, *_):
@@ -200,12 +197,12 @@ class BNNCost(object):
         return ws
 
     @torch.no_grad()
-    def cost_and_grad(self, params, grad_views, theta_sumsq=None):
+    def cost_and_grad(self, params, grad_views, theta_sumsq=None, theta_sumsq_partials=None):
         """NLL at ``params`` with d NLL/d params written into ``grad_views`` (views of the sampler's
         gradient arena). On a GPU: rocBLAS GEMMs + the library's loss-head and tanh-backward
         kernels (~26 launches per step for 4 layers); elsewhere the same algebra in torch ops."""
         if params[0].is_cuda:
-            return self._cost_and_grad_hip(params, grad_views, theta_sumsq)
+            return self._cost_and_grad_hip(params, grad_views, theta_sumsq, theta_sumsq_partials)
         return self._cost_and_grad_torch(params, grad_views, theta_sumsq)
 
     def _forward(self, params, X, hs):
@@ -222,7 +219,7 @@ class BNNCost(object):
                 torch.tanh_(hs[l])
             h = hs[l]
 
-    def _cost_and_grad_hip(self, params, grad_views, theta_sumsq):
+    def _cost_and_grad_hip(self, params, grad_views, theta_sumsq, theta_sumsq_partials=None):
         from pysgmcmc_amd import kernels
         X, Y = self.x_placeholder.value, self.y_placeholder.value
         B = X.shape[0]
@@ -231,77 +228,54 @@ class BNNCost(object):
         hs, ds = ws["h"], ws["d"]
         self._forward(params, X, hs)
         n_params = float(sum(p.numel() for p in params))
-        if theta_sumsq is None:
+        if theta_sumsq is None and theta_sumsq_partials is None:
             theta_sumsq = torch.zeros((), dtype=torch.float64, device=X.device)
             for p in params:
                 theta_sumsq = theta_sumsq + (p.double() ** 2).sum()
-        kernels.bnn_head(hs[-1].view(-1), Y.reshape(-1), params[-1], theta_sumsq, self.batch_size, self.n_examples,
-                         n_params, self.wdecay, self.prior_mean, self.prior_var,
-                         ds[-1].view(-1), ws["cost"], grad_views[-1], ws["mse"], fold_prior_grad=self.fold_prior)
-        self.last_mse = ws["mse"]
         prior_coef = self.wdecay / ((n_params + 3e-16) * self.n_examples)
         self.grad_theta_coef = prior_coef if self.fold_prior else 0.0
+        beta = 0.0 if self.fold_prior else prior_coef
+        single_out = params[2 * (n_layers - 1)].shape[1] == 1
+        # loss head: delta_L, cost, d/d log_var, mse and (single-output net) the last bias gradient
+        kernels.bnn_head(hs[-1].view(-1), Y.reshape(-1), params[-1], theta_sumsq, self.batch_size, self.n_examples,
+                         n_params, self.wdecay, self.prior_mean, self.prior_var,
+                         ds[-1].view(-1), ws["cost"], grad_views[-1], ws["mse"], fold_prior_grad=self.fold_prior,
+                         stats_workspace=theta_sumsq_partials,
+                         last_bias=params[2 * n_layers - 1] if single_out else None,
+                         grad_last_bias_out=grad_views[2 * n_layers - 1] if single_out else None)
+        self.last_mse = ws["mse"]
         ones = ws["ones"]
-        # Under hipGraph capture the weight/bias-gradient products of a layer run on a forked stream,
-        # concurrently with the delta back-propagation chain (they only share the read-only delta_l and
-        # h_{l-1}): at batch 256 one fp32 GEMM fills a fraction of the 256 CUs. In the captured graph the
-        # fork/join are plain dependency edges. Eagerly they would be event waits that cost more than
-        # they save, so the eager path stays on one stream.
-        fork = self.fork_weight_grads and torch.cuda.is_current_stream_capturing()
-        main = torch.cuda.current_stream(X.device) if fork else None
-        side = self._side_stream(X.device) if fork else None
         for l in range(n_layers - 1, -1, -1):
             h_in = X if l == 0 else hs[l - 1]
             W, b = params[2 * l], params[2 * l + 1]
-            if fork:
-                side.wait_stream(main)               # delta_l is ready
-                if l > 0:
-                    if W.shape[1] == 1:
-                        torch.mul(ds[l], W.view(1, -1), out=ds[l - 1])
-                    else:
-                        torch.mm(ds[l], W.t(), out=ds[l - 1])
-                    kernels.tanh_backward(ds[l - 1], hs[l - 1])
-                with torch.cuda.stream(side):
-                    self._weight_grads(l, h_in, W, b, ds, ones, grad_views, prior_coef)
-                continue
-            # gW = h_in^T delta, gb = delta^T 1, written directly into the gradient arena. The
-            # weight-prior term coef * theta is added by the update kernel (fold_prior) or rides in
-            # the GEMM / GEMV epilogue (beta).
             single = W.shape[1] == 1                 # one output unit: GEMV / outer product instead of N = 1 GEMMs
-            self._weight_grads(l, h_in, W, b, ds, ones, grad_views, prior_coef)
+            # gW_l = h_{l-1}^T delta_l written directly into the gradient arena. The weight-prior term
+            # coef * theta is added by the update kernel (fold_prior) or rides in the GEMM epilogue (beta).
+            if single:
+                if self.fold_prior:
+                    torch.mv(h_in.t(), ds[l].view(-1), out=grad_views[2 * l].view(-1))
+                else:
+                    torch.addmv(W.view(-1), h_in.t(), ds[l].view(-1), beta=prior_coef, alpha=1.0,
+                                out=grad_views[2 * l].view(-1))
+            elif self.fold_prior:
+                torch.mm(h_in.t(), ds[l], out=grad_views[2 * l])
+            else:
+                torch.addmm(W, h_in.t(), ds[l], beta=prior_coef, alpha=1.0, out=grad_views[2 * l])
+            if l == n_layers - 1 and not single_out:
+                # bias gradient of a multi-output last layer (hidden layers get theirs from the fused kernel below)
+                if self.fold_prior:
+                    torch.mv(ds[l].t(), ones, out=grad_views[2 * l + 1])
+                else:
+                    torch.addmv(b, ds[l].t(), ones, beta=prior_coef, alpha=1.0, out=grad_views[2 * l + 1])
             if l > 0:
                 if single:
                     torch.mul(ds[l], W.view(1, -1), out=ds[l - 1])       # (B,1) x (1,H) outer product
                 else:
                     torch.mm(ds[l], W.t(), out=ds[l - 1])
-                kernels.tanh_backward(ds[l - 1], hs[l - 1])
-        if fork:
-            main.wait_stream(side)
+                # delta_{l-1} *= 1 - h_{l-1}^2, and gb_{l-1} = column sums of the result (+ beta * b_{l-1})
+                kernels.tanh_backward_colsum(ds[l - 1], hs[l - 1], grad_views[2 * (l - 1) + 1],
+                                             bias=params[2 * (l - 1) + 1], beta=beta)
         return ws["cost"].reshape(())
-
-    def _side_stream(self, device):
-        st = self._streams.get(device)
-        if st is None:
-            st = torch.cuda.Stream(device=device)
-            self._streams[device] = st
-        return st
-
-    def _weight_grads(self, l, h_in, W, b, ds, ones, grad_views, prior_coef):
-        """gW_l = h_{l-1}^T delta_l, gb_l = delta_l^T 1 (+ prior term unless folded), into the arena."""
-        single = W.shape[1] == 1
-        if self.fold_prior:
-            if single:
-                torch.mv(h_in.t(), ds[l].view(-1), out=grad_views[2 * l].view(-1))
-            else:
-                torch.mm(h_in.t(), ds[l], out=grad_views[2 * l])
-            torch.mv(ds[l].t(), ones, out=grad_views[2 * l + 1])
-        else:
-            if single:
-                torch.addmv(W.view(-1), h_in.t(), ds[l].view(-1), beta=prior_coef, alpha=1.0,
-                            out=grad_views[2 * l].view(-1))
-            else:
-                torch.addmm(W, h_in.t(), ds[l], beta=prior_coef, alpha=1.0, out=grad_views[2 * l])
-            torch.addmv(b, ds[l].t(), ones, beta=prior_coef, alpha=1.0, out=grad_views[2 * l + 1])
 
     def _cost_and_grad_torch(self, params, grad_views, theta_sumsq):
         self.grad_theta_coef = 0.0                                # the torch path always writes the full gradient

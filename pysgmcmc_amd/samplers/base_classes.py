@@ -128,6 +128,7 @@ class MCMCSampler(object):
         self.collect_stats = True
         self._stats = None
         self._stats_valid = False
+        self._stats_out_valid = False
         # hipGraph mode
         self.use_hip_graph = False
         self._graphs = {}
@@ -164,21 +165,29 @@ class MCMCSampler(object):
         return self._stats
 
     def _ensure_stats(self):
-        """Make stats.out[0] = sum theta^2 valid before the first step (K6), later steps keep it fresh."""
+        """Make the statistics workspace valid before the first step: sum theta^2 by K6, stored as a
+        one-partial workspace (header nparts = 1), so consumers always read the same buffer the step
+        kernels refresh afterwards."""
         st = self._step_stats()
         if st is not None and not self._stats_valid:
             s = kernels.summary(self.arena.row("theta"))
-            st.out.zero_()
-            st.out[0:1].copy_(s[1:2])
+            st.workspace.view(torch.int64)[0:1].fill_(1)
+            ws = st.workspace.view(torch.float64)
+            ws[4:8].zero_()
+            ws[4:5].copy_(s[1:2])
             self._stats_valid = True
+            self._stats_out_valid = False
         return st
 
     @property
     def stats(self):
-        """``{"theta_sq", "momentum_sq", "minv_sum", "minv_sq"}`` after the last step (host floats)."""
+        """``{"theta_sq", "momentum_sq", "minv_sum", "minv_sq"}`` after the last step (host floats; K7)."""
         st = self._ensure_stats()
         if st is None:
             return None
+        if not self._stats_out_valid:
+            kernels.step_stats_finish(st)
+            self._stats_out_valid = True
         v = st.out.cpu().numpy()
         return {"theta_sq": float(v[0]), "momentum_sq": float(v[1]), "minv_sum": float(v[2]), "minv_sq": float(v[3])}
 
@@ -196,7 +205,7 @@ class MCMCSampler(object):
             if getattr(self.cost_fun, "accepts_theta_sumsq", False):
                 st = self._ensure_stats()
                 if st is not None:
-                    kw["theta_sumsq"] = st.out[0]
+                    kw["theta_sumsq_partials"] = st.workspace
             cost = fused(self.params, self.arena.grad_views, **kw)
             # a cost function may leave a term coef * theta of its gradient to the update kernel
             self._grad_decay = float(getattr(self.cost_fun, "grad_theta_coef", 0.0))

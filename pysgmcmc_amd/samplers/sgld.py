@@ -46,5 +46,5 @@ class SGLDSampler(BurnInMCMCSampler):
             eps, self.A, self.scale_grad, self._adapting,
             xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, **self._noise_args())
         if self._stats is not None:
-            kernels.step_stats_finish(self._stats)
-            self._stats_valid = True
+            self._stats_valid = True          # the workspace now holds this step's per-block partials
+            self._stats_out_valid = False     # K7 runs lazily (sampler.stats); the BNN head reads the partials

@@ -10,14 +10,6 @@ import torch
 from oracle import sgmcmc_oracle as O
 
 
-class _St(object):
-    pass
-
-
-def _np(t):
-    return None if t is None else t.detach().numpy()
-
-
 def _sfx(t):
     return "f32" if t.dtype == torch.float32 else "f64"
 
