@@ -92,12 +92,12 @@ int sgmcmc_sghmc_step_f32(float *theta, float *V, const float *grad,
                           float *tau, float *g, float *v_hat, float *minv, float *r,
                           size_t n, float eps, float scale_grad, float mdecay, float grad_decay, int adapt,
                           const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        void *stats_ws, sgmcmc_stream_t stream);
+                          void *stats_ws, sgmcmc_stream_t stream);
 int sgmcmc_sghmc_step_f64(double *theta, double *V, const double *grad,
                           double *tau, double *g, double *v_hat, double *minv, double *r,
                           size_t n, double eps, double scale_grad, double mdecay, double grad_decay, int adapt,
                           const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        void *stats_ws, sgmcmc_stream_t stream);
+                          void *stats_ws, sgmcmc_stream_t stream);
 
 size_t sgmcmc_step_stats_workspace_bytes(size_t n);
 /* K7 -- stats_out[0..3] (device doubles) = fixed-order sum of the per-block partials a step kernel left
@@ -111,12 +111,12 @@ int sgmcmc_sgld_step_f32(float *theta, const float *grad,
                          float *tau, float *g, float *v_hat, float *minv, float *r,
                          size_t n, float eps, float A, float scale_grad, float grad_decay, int adapt,
                          const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        void *stats_ws, sgmcmc_stream_t stream);
+                          void *stats_ws, sgmcmc_stream_t stream);
 int sgmcmc_sgld_step_f64(double *theta, const double *grad,
                          double *tau, double *g, double *v_hat, double *minv, double *r,
                          size_t n, double eps, double A, double scale_grad, double grad_decay, int adapt,
                          const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        void *stats_ws, sgmcmc_stream_t stream);
+                          void *stats_ws, sgmcmc_stream_t stream);
 
 /* K3 -- fused relativistic SGHMC step, per element. Replaces
  * pysgmcmc/samplers/relativistic_sghmc.py:120-140. grad_cost = d cost / d theta
@@ -125,22 +125,22 @@ int sgmcmc_sgld_step_f64(double *theta, const double *grad,
 int sgmcmc_rsghmc_step_f32(float *theta, float *p, const float *grad_cost, size_t n,
                            float eps, float mass, float c, float D, float b_hat, float grad_decay,
                            const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        void *stats_ws, sgmcmc_stream_t stream);
+                          void *stats_ws, sgmcmc_stream_t stream);
 int sgmcmc_rsghmc_step_f64(double *theta, double *p, const double *grad_cost, size_t n,
                            double eps, double mass, double c, double D, double b_hat, double grad_decay,
                            const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        void *stats_ws, sgmcmc_stream_t stream);
+                          void *stats_ws, sgmcmc_stream_t stream);
 
 /* K5 -- write the N(0,1) stream itself: out[i] = xi(seed, step, i). Replaces
  * tf.random_normal in pysgmcmc/samplers/base_classes.py:218-220 for callers that
  * want the draws materialised (tests, relativistic momentum initialisation).      */
 int sgmcmc_philox_normal_f32(float *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        sgmcmc_stream_t stream);
+                             sgmcmc_stream_t stream);
 int sgmcmc_philox_normal_f64(double *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        sgmcmc_stream_t stream);
+                             sgmcmc_stream_t stream);
 /* raw Philox words: out[i] = x[i & 3] of quad i >> 2 (bit-exact integer check)     */
 int sgmcmc_philox_bits_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-        sgmcmc_stream_t stream);
+                             sgmcmc_stream_t stream);
 
 /* *counter += inc on the stream (1-thread kernel; the graph-safe step counter).     */
 int sgmcmc_counter_add_u64(uint64_t *counter, uint64_t inc, sgmcmc_stream_t stream);

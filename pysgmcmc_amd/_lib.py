@@ -11,7 +11,8 @@ __all__ = ["SgmcmcLibraryError", "lib", "lib_path", "check", "build"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_LIB_PATH = os.path.join(_CSRC, "libsgmcmc_hip.so")
+# PYSGMCMC_AMD_LIB: load an alternative build of the same ABI (kernel experiments)
+_LIB_PATH = os.environ.get("PYSGMCMC_AMD_LIB") or os.path.join(_CSRC, "libsgmcmc_hip.so")
 
 
 class SgmcmcLibraryError(RuntimeError):

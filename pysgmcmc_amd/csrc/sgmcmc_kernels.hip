@@ -44,6 +44,14 @@ namespace {
 // vector types and quad memory access
 // --------------------------------------------------------------------------
 
+// experiment knobs (build-time): which side of an nt launch actually carries the nt hint
+#ifndef SGMCMC_NT_LOADS
+#define SGMCMC_NT_LOADS 1
+#endif
+#ifndef SGMCMC_NT_STORES
+#define SGMCMC_NT_STORES 1
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
@@ -51,7 +59,7 @@ template <bool NT>
 __device__ __forceinline__ void load_quad(const float *__restrict__ p, size_t q, float (&v)[4])
 {
     const f32x4 *p4 = reinterpret_cast<const f32x4 *>(p) + q;
-    f32x4 t = NT ? __builtin_nontemporal_load(p4) : *p4;
+    f32x4 t = (NT && SGMCMC_NT_LOADS) ? __builtin_nontemporal_load(p4) : *p4;
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
 }
 template <bool NT>
@@ -59,14 +67,14 @@ __device__ __forceinline__ void store_quad(float *__restrict__ p, size_t q, cons
 {
     f32x4 t = {v[0], v[1], v[2], v[3]};
     f32x4 *p4 = reinterpret_cast<f32x4 *>(p) + q;
-    if (NT) __builtin_nontemporal_store(t, p4); else *p4 = t;
+    if (NT && SGMCMC_NT_STORES) __builtin_nontemporal_store(t, p4); else *p4 = t;
 }
 template <bool NT>
 __device__ __forceinline__ void load_quad(const double *__restrict__ p, size_t q, double (&v)[4])
 {
     const f64x2 *p2 = reinterpret_cast<const f64x2 *>(p) + 2 * q;
-    f64x2 a = NT ? __builtin_nontemporal_load(p2) : p2[0];
-    f64x2 b = NT ? __builtin_nontemporal_load(p2 + 1) : p2[1];
+    f64x2 a = (NT && SGMCMC_NT_LOADS) ? __builtin_nontemporal_load(p2) : p2[0];
+    f64x2 b = (NT && SGMCMC_NT_LOADS) ? __builtin_nontemporal_load(p2 + 1) : p2[1];
     v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
 template <bool NT>
@@ -74,7 +82,7 @@ __device__ __forceinline__ void store_quad(double *__restrict__ p, size_t q, con
 {
     f64x2 a = {v[0], v[1]}, b = {v[2], v[3]};
     f64x2 *p2 = reinterpret_cast<f64x2 *>(p) + 2 * q;
-    if (NT) { __builtin_nontemporal_store(a, p2); __builtin_nontemporal_store(b, p2 + 1); }
+    if (NT && SGMCMC_NT_STORES) { __builtin_nontemporal_store(a, p2); __builtin_nontemporal_store(b, p2 + 1); }
     else { p2[0] = a; p2[1] = b; }
 }
 // element-wise access for misaligned arrays and the ragged tail (cnt in 1..4)
@@ -506,7 +514,7 @@ __global__ void __launch_bounds__(1024) stats_final_kernel(const double *__restr
 // VEC: arrays are 16-B aligned; quads [0, nq_full) go through dwordx4 accesses,
 //      QPT quads in flight per lane; the ragged tail (n % 4 elements) is done
 //      element-wise by one lane.
-template <typename Op, int QPT, bool NT, bool STATS>
+template <typename Op, int QPT, bool NT, bool STATS, bool LOOP>
 __global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t nq_full, int tail_cnt)
 {
     Op op = op_in;
@@ -515,24 +523,37 @@ __global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t n
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     constexpr bool stats = STATS;                         // compile-time: the plain variant carries no reduction code
-    for (size_t base = gid; base < nq_full; base += G * QPT) {
-        typename Op::Regs R[QPT];
-#pragma unroll
-        for (int u = 0; u < QPT; ++u) {
-            size_t q = base + (size_t)u * G;
-            if (q < nq_full) op.template load_vec<NT>(q, R[u]);
+    if constexpr (!LOOP) {
+        // the grid covers every quad (the default geometry): straight-line code, no loop-carried
+        // scalar state -> fewer SGPRs/VGPRs -> one more resident block per CU
+        static_assert(QPT == 1, "single-pass variant is one quad per lane");
+        if (gid < nq_full) {
+            typename Op::Regs R;
+            op.template load_vec<NT>(gid, R);
+            op.compute(gid, R);
+            op.template store_vec<NT>(gid, R);
+            if constexpr (stats) op.accumulate(R, 4, acc);
         }
+    } else {
+        for (size_t base = gid; base < nq_full; base += G * QPT) {
+            typename Op::Regs R[QPT];
 #pragma unroll
-        for (int u = 0; u < QPT; ++u) {
-            size_t q = base + (size_t)u * G;
-            if (q < nq_full) op.compute(q, R[u]);
-        }
+            for (int u = 0; u < QPT; ++u) {
+                size_t q = base + (size_t)u * G;
+                if (q < nq_full) op.template load_vec<NT>(q, R[u]);
+            }
 #pragma unroll
-        for (int u = 0; u < QPT; ++u) {
-            size_t q = base + (size_t)u * G;
-            if (q < nq_full) {
-                op.template store_vec<NT>(q, R[u]);
-                if constexpr (stats) op.accumulate(R[u], 4, acc);
+            for (int u = 0; u < QPT; ++u) {
+                size_t q = base + (size_t)u * G;
+                if (q < nq_full) op.compute(q, R[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) {
+                size_t q = base + (size_t)u * G;
+                if (q < nq_full) {
+                    op.template store_vec<NT>(q, R[u]);
+                    if constexpr (stats) op.accumulate(R[u], 4, acc);
+                }
             }
         }
     }
@@ -874,10 +895,21 @@ int launch_vec(const Op &op, size_t n, hipStream_t st)
     if (want == 0) want = 1;
     size_t cap = (size_t)g_max_blocks.load();
     unsigned grid = (unsigned)(want < cap ? want : cap);
-    if (op.stats_part != nullptr)
-        hipLaunchKernelGGL((stream_quads_vec<Op, QPT, NT, true>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
+    const bool with_stats = op.stats_part != nullptr;
+    if constexpr (QPT == 1) {
+        if (want <= cap) {                                 // one quad per lane, whole array in one pass
+            if (with_stats)
+                hipLaunchKernelGGL((stream_quads_vec<Op, 1, NT, true, false>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
+            else
+                hipLaunchKernelGGL((stream_quads_vec<Op, 1, NT, false, false>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
+            hipError_t e1 = hipGetLastError();
+            return e1 == hipSuccess ? 0 : hip_fail(e1, "launch stream_quads_vec");
+        }
+    }
+    if (with_stats)
+        hipLaunchKernelGGL((stream_quads_vec<Op, QPT, NT, true, true>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
     else
-        hipLaunchKernelGGL((stream_quads_vec<Op, QPT, NT, false>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
+        hipLaunchKernelGGL((stream_quads_vec<Op, QPT, NT, false, true>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch stream_quads_vec");
 }

@@ -15,5 +15,5 @@ for f, d in zip(funcs[1:], dem):
     g = lambda k: (re.search(r'; %s: (\d+)' % k, f) or [None, '?'])[1]
     hist = collections.Counter(re.sub(r'_e(32|64)$', '', m) for m in re.findall(r'^\s+([a-z_0-9]+)\s', f, re.M))
     print(d[:150])
-    print('   vgpr', g('NumVgprs'), 'sgpr', g('NumSgprs'), 'occ', g('Occupancy'), 'scratch', g('ScratchSize'),
+    print('   vgpr', g('NumVgprs'), 'sgpr', g('TotalNumSgprs'), 'occ', g('Occupancy'), 'scratch', g('ScratchSize'),
           {k: hist[k] for k in keys if hist[k]}, 'total', sum(hist.values()))
