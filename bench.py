@@ -37,6 +37,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:35
 # algorithmic bytes per parameter per launch, fp32
 BYTES_PER_PARAM = {"sghmc_frozen": 24, "sghmc_adapt": 48, "sgld_frozen": 16, "sgld_adapt": 40, "rsghmc": 20}
+# measured by rocprofv3 PMC counters (profiles/r01_pmc_traffic.md): read (2 x FETCH_SIZE) + written (WRITE_SIZE)
+PMC_BYTES_PER_PARAM = {"sghmc_frozen": 16.00 + 8.00, "sghmc_adapt": 24.00 + 24.00, "sgld_frozen": 12.00 + 4.00,
+                       "sgld_adapt": 20.00 + 20.00, "rsghmc": 12.00 + 8.00}
 BATCH = 256
 N_DATA = 100_000
 # workloads: the default is BASELINE.json configs[2]; the 50 M ones are configs[4]'s two samplers
@@ -316,7 +319,12 @@ def main():
                              op_name, "false" if frozen_phase else "true",
                              "true" if alg_bytes > (640 << 20) else "false"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         # HBM bytes per launch from the PMC passes of profiles/r01_pmc_traffic.md (separate
+                         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950
+                         # correction): measured bytes/param == algorithmic bytes/param for every kernel
+                         "traffic": int(round(PMC_BYTES_PER_PARAM[mode] * n)),
+                         "traffic_source": "profiles/r01_pmc_traffic.md",
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "us_per_launch_mean": round(k_us, 2), "us_per_launch_median": round(timer.median_us(), 2),
                          "launches_timed": len(timer.pairs),

@@ -286,3 +286,48 @@ def test_draw_noise_sample_api(gpu):
     z = s._draw_noise_sample(sigma=2.0, shape=(1000, 1))
     z2 = s._draw_noise_sample(sigma=2.0, shape=(1000, 1))
     assert z.shape == (1000, 1) and torch.equal(z, z2) and abs(z.std().item() - 2.0) < 0.2
+
+
+def test_checkpoint_resume_and_numpy_format_on_gpu(gpu):
+    """state_dict/load_state_dict resume a Philox chain bit-exactly (the reference cannot checkpoint);
+    the default "numpy" sample format returns host copies that do not alias the arena."""
+    mk = lambda: SGHMCSampler(params=[torch.zeros(1000), torch.ones(7, 3)],
+                              cost_fun=lambda p: (p[0] ** 2).sum() + ((p[1] - 1) ** 4).sum(),
+                              session=gpu, dtype=torch.float32, seed=21, burn_in_steps=6)
+    s = mk()
+    out = list(islice(s, 9))
+    assert isinstance(out[-1][0][0], np.ndarray) and out[-1][0][1].shape == (7, 3)
+    keep = out[-1][0][0].copy()
+    state = s.state_dict()
+    tail = [smp for smp, _ in islice(s, 5)]
+    assert np.array_equal(keep, out[-1][0][0])                      # earlier samples are untouched copies
+    s2 = mk()
+    s2.load_state_dict(state)
+    tail2 = [smp for smp, _ in islice(s2, 5)]
+    for a, b in zip(tail, tail2):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert s2.n_iterations == 14 and not s2.is_burning_in
+
+
+def test_materialize_r_and_relativistic_on_gpu(gpu, oracle):
+    """`materialize_r` writes the reference's R_i = 1/(tau+1) variable too; the relativistic sampler
+    draws its initial momenta from the relativistic law (seeded) and steps finitely."""
+    x = torch.randn(5000, device=gpu)
+    s = SGHMCSampler(params=[x], cost_fun=lambda p: 0.5 * (p[0] ** 2).sum(), session=gpu, dtype=torch.float32,
+                     seed=2, burn_in_steps=50)
+    s.materialize_r = True
+    s.sample_format = "view"
+    tau_before = None
+    for _ in range(10):
+        tau_before = s.arena.row("tau").clone()
+        next(s)
+    r = s.arena._rows["r"]
+    assert torch.equal(r, 1.0 / (tau_before + 1.0))
+    rs = [RelativisticSGHMCSampler(params=[torch.zeros(200000)], cost_fun=lambda p: 0.5 * (p[0] ** 2).sum(),
+                                   session=gpu, dtype=torch.float32, seed=sd) for sd in (5, 5, 6)]
+    p0 = [r_.arena.row("p").clone() for r_ in rs]
+    assert torch.equal(p0[0], p0[1]) and not torch.equal(p0[0], p0[2])
+    assert abs(p0[0].double().std().item() - 1.6430) < 0.02 and abs(p0[0].double().mean().item()) < 0.02
+    rs[0].sample_format = "view"
+    smp = [v for v, _ in islice(rs[0], 20)][-1]
+    assert torch.isfinite(smp).all() and smp.abs().max().item() < 1.0
