@@ -67,7 +67,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_chain(dev, rank, workload="bnn10m-sghmc"):
+def build_chain(dev, rank, workload="bnn10m-sghmc", burn_in=8):
     from pysgmcmc_amd.data_batches import Placeholder, generate_batches
     from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
     from pysgmcmc_amd.samplers import RelativisticSGHMCSampler, SGHMCSampler, SGLDSampler
@@ -88,13 +88,13 @@ def build_chain(dev, rank, workload="bnn10m-sghmc"):
     if spec["sampler"] == "sghmc":
         return SGHMCSampler(stepsize_schedule=ConstantStepsizeSchedule(0.01), mdecay=0.05,
                             scale_grad=float(N_DATA),
-                            burn_in_steps=8,                   # adapted during warmup; timed steps are frozen
+                            burn_in_steps=burn_in,             # adapted during warmup; timed steps are frozen
                             **common)
     if spec["sampler"] == "sgld":
         # configs[4]: preconditioned SGLD with a burn-in stepsize ramp (a StepsizeSchedule subclass)
-        return SGLDSampler(stepsize_schedule=BurnInRampStepsizeSchedule(1e-4, 1e-3, burn_in_steps=8),
-                           A=1.0, scale_grad=float(N_DATA), burn_in_steps=8, **common)
-    return RelativisticSGHMCSampler(stepsize_schedule=BurnInRampStepsizeSchedule(1e-4, 1e-3, burn_in_steps=8),
+        return SGLDSampler(stepsize_schedule=BurnInRampStepsizeSchedule(1e-4, 1e-3, burn_in_steps=burn_in),
+                           A=1.0, scale_grad=float(N_DATA), burn_in_steps=burn_in, **common)
+    return RelativisticSGHMCSampler(stepsize_schedule=BurnInRampStepsizeSchedule(1e-4, 1e-3, burn_in_steps=burn_in),
                                     mass=1.0, speed_of_light=1.0, D=1.0, Bhat=0.0, **common)
 
 
@@ -242,7 +242,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)         # RCCL over xGMI
 
     from pysgmcmc_amd import kernels
-    sampler = build_chain(dev, rank, args.workload)
+    # burn-in (preconditioner adaptation) happens inside the warm-up so that every TIMED step is in one
+    # phase: frozen if warmup >= 1, else (warmup = 0 -> burn_in_steps = 0) perpetual adaptation
+    sampler = build_chain(dev, rank, args.workload, burn_in=min(8, max(args.warmup, 0)))
     kind = WORKLOADS[args.workload]["sampler"]
     sampler.sample_format = "view"                             # no D2H copy of 40 MB per sample
     sampler.use_hip_graph = not args.eager

@@ -157,6 +157,10 @@ class BNNCost(object):
         # per step at 10 M parameters. The autograd path (__call__) always includes the term.
         self.fold_prior = bool(fold_prior)
         self.grad_theta_coef = 0.0
+        # True: loss head / tanh backward run as library kernels (device tensors required, raises
+        # otherwise). False: the same algebra in device-agnostic torch ops -- an explicit opt-in used
+        # to cross-check the kernels, never selected automatically.
+        self.use_hip_kernels = True
         # (Forking the weight-gradient GEMMs onto a second stream inside the captured graph was measured
         # on MI355X at batch 256: 291 us/step vs 275 us on one stream -- not kept.)
 
@@ -199,9 +203,10 @@ class BNNCost(object):
     @torch.no_grad()
     def cost_and_grad(self, params, grad_views, theta_sumsq=None, theta_sumsq_partials=None):
         """NLL at ``params`` with d NLL/d params written into ``grad_views`` (views of the sampler's
-        gradient arena). On a GPU: rocBLAS GEMMs + the library's loss-head and tanh-backward
-        kernels (~26 launches per step for 4 layers); elsewhere the same algebra in torch ops."""
-        if params[0].is_cuda:
+        gradient arena): rocBLAS GEMMs + the library's loss-head and fused tanh-backward/bias-gradient
+        kernels (~20 launches per step for 4 layers)."""
+        if self.use_hip_kernels:
+            # no silent fallback: the HIP path needs device tensors (kernels.* raises on CPU tensors)
             return self._cost_and_grad_hip(params, grad_views, theta_sumsq, theta_sumsq_partials)
         return self._cost_and_grad_torch(params, grad_views, theta_sumsq)
 

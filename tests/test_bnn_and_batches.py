@@ -41,6 +41,10 @@ def test_bnn_cost_matches_oracle_and_fused_path(oracle):
     ps = [p.clone().requires_grad_(True) for p in params]
     grads = torch.autograd.grad(c(ps), ps)
     gv = [torch.empty_like(p) for p in params]
+    from pysgmcmc_amd._lib import SgmcmcLibraryError
+    with pytest.raises(SgmcmcLibraryError):
+        c.cost_and_grad(params, gv)             # HIP kernels by default: CPU tensors are refused, no fallback
+    c.use_hip_kernels = False                   # explicit opt-in to the torch-op formulation
     cost2 = c.cost_and_grad(params, gv)
     assert np.isclose(float(cost2), want_nll, rtol=1e-13)
     for a, b in zip(grads, gv):
