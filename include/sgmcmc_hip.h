@@ -56,7 +56,8 @@ const char *sgmcmc_last_error(void);
 int sgmcmc_device_count(void);
 
 /* Launch geometry knobs (performance only; results never depend on them).
- *   block_threads: 64, 128, 192 or 256 (default 256)
+ *   block_threads: 64, 128, 192, 256, or -1 = auto (default): 128 when one launch streams more
+ *                than 640 MiB (HBM-resident working set), else 256
  *   quads_per_thread: 1, 2 or 4 float4 groups in flight per lane (default 1)
  *   max_blocks: grid cap, the kernel grid-strides beyond it (default 2^20 = uncapped)
  *   nontemporal: 0 plain, 1 nt loads+stores, 2 auto = nt iff one launch touches more

@@ -852,7 +852,7 @@ int hip_fail(hipError_t e, const char *what)
     return fail((int)e, "%s: %s", what, hipGetErrorString(e));
 }
 
-std::atomic<int> g_block_threads{256};
+std::atomic<int> g_block_threads{-1};   // -1 = auto: 128 lanes when a launch streams > NT_AUTO_BYTES, else 256
 std::atomic<int> g_qpt{1};
 std::atomic<int> g_max_blocks{1 << 20};
 std::atomic<int> g_nt{2};                 // 0 = plain, 1 = nt, 2 = auto by working-set size
@@ -884,10 +884,13 @@ inline size_t max_grid_for(size_t n)
     return want < cap ? (want ? want : 1) : cap;
 }
 
+// block size of the launch being issued on this thread (set by launch_inner)
+thread_local int g_bt_launch = 256;
+
 template <typename Op, int QPT, bool NT>
 int launch_vec(const Op &op, size_t n, hipStream_t st)
 {
-    const int bt = g_block_threads.load();
+    const int bt = g_bt_launch;
     const size_t nq_full = n / 4;
     const int tail = (int)(n % 4);
     size_t per_block = (size_t)bt * QPT;
@@ -916,7 +919,7 @@ int launch_vec(const Op &op, size_t n, hipStream_t st)
 template <typename Op>
 int launch_scalar(const Op &op, size_t n, hipStream_t st)
 {
-    const int bt = g_block_threads.load();
+    const int bt = g_bt_launch;
     size_t nq = (n + 3) / 4;
     size_t want = (nq + bt - 1) / bt;
     if (want == 0) want = 1;
@@ -945,9 +948,13 @@ template <typename Op>
 int launch_inner(const Op &op, size_t n, bool vec_ok, size_t bytes_per_elem, hipStream_t st)
 {
     if (n == 0) return 0;
+    const bool big = n * bytes_per_elem > NT_AUTO_BYTES;     // cannot stay in the Infinity Cache between steps
+    const int bt_cfg = g_block_threads.load();
+    // measured (profiles/r01_block_sweep.txt): 128-lane blocks +7 % at 50 M params (HBM-resident), 256 +2 % at 10 M
+    g_bt_launch = bt_cfg > 0 ? bt_cfg : (big ? 128 : 256);
     if (!vec_ok) return launch_scalar<Op>(op, n, st);
     const int nt_cfg = g_nt.load();
-    const bool nt = nt_cfg == 2 ? (n * bytes_per_elem > NT_AUTO_BYTES) : (nt_cfg != 0);
+    const bool nt = nt_cfg == 2 ? big : (nt_cfg != 0);
     if (sizeof(typename Op::real) == 8) {
         return nt ? launch_vec<Op, 1, true>(op, n, st) : launch_vec<Op, 1, false>(op, n, st);
     }
@@ -1115,8 +1122,8 @@ int sgmcmc_device_count(void)
 int sgmcmc_set_launch_config(int block_threads, int quads_per_thread, int max_blocks, int nontemporal)
 {
     if (block_threads != 0) {
-        if (block_threads < 64 || block_threads > 256 || (block_threads % 64) != 0)
-            return fail(SGMCMC_EINVAL, "block_threads must be 64, 128, 192 or 256");
+        if (block_threads != -1 && (block_threads < 64 || block_threads > 256 || (block_threads % 64) != 0))
+            return fail(SGMCMC_EINVAL, "block_threads must be 64, 128, 192, 256 or -1 (auto)");
         g_block_threads.store(block_threads);
     }
     if (quads_per_thread != 0) {

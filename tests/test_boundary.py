@@ -37,7 +37,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.sgmcmc_abi_version() == 1
     assert lib.sgmcmc_summary_workspace_bytes() >= 1024 * 32
     # launch-config knobs are host-only: usable without a GPU
-    assert lib.sgmcmc_set_launch_config(256, 1, 1 << 20, 2) == 0
+    assert lib.sgmcmc_set_launch_config(-1, 1, 1 << 20, 2) == 0
     assert lib.sgmcmc_set_launch_config(100, 0, 0, -1) != 0
     assert b"block_threads" in lib.sgmcmc_last_error()
 

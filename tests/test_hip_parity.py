@@ -217,7 +217,7 @@ def test_register_noise_equals_injected_stream(gpu, oracle, npdt, thdt):
                 assert torch.equal(a.theta, b.theta) and torch.equal(a.V, b.V)
             results.append(a.theta.clone())
     finally:
-        kernels.set_launch_config(256, 1, 1 << 20, 2)
+        kernels.set_launch_config(-1, 1, 1 << 20, 2)
     for r in results[1:]:
         assert torch.equal(results[0], r)     # geometry never changes the samples
 
