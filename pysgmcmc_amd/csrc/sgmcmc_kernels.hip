@@ -225,11 +225,14 @@ struct SghmcOp {
     template <typename RegsT>
     __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
     {
+        // the quad's 4 terms are summed in T (4 adds), the running totals in double
+        T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (j < cnt) {
-            double th = (double)R.th[j], v = (double)R.v[j], mi = (double)R.mi[j];
-            acc[0] += th * th; acc[1] += v * v; acc[2] += mi; acc[3] += mi * mi;
+            T th = R.th[j], v = R.v[j], mi = R.mi[j];
+            s0 += th * th; s1 += v * v; s2 += mi; s3 += mi * mi;
         }
+        acc[0] += (double)s0; acc[1] += (double)s1; acc[2] += (double)s2; acc[3] += (double)s3;
     }
     struct Regs { T th[4], v[4], gr[4], mi[4], tau[4], g[4], vh[4], rr[4], z[4]; };
 
@@ -297,11 +300,13 @@ struct SgldOp {
     template <typename RegsT>
     __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
     {
+        T s0 = T(0), s2 = T(0), s3 = T(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (j < cnt) {
-            double th = (double)R.th[j], mi = (double)R.mi[j];
-            acc[0] += th * th; acc[2] += mi; acc[3] += mi * mi;
+            T th = R.th[j], mi = R.mi[j];
+            s0 += th * th; s2 += mi; s3 += mi * mi;
         }
+        acc[0] += (double)s0; acc[2] += (double)s2; acc[3] += (double)s3;
     }
     struct Regs { T th[4], gr[4], mi[4], tau[4], g[4], vh[4], rr[4], z[4]; };
 
@@ -365,11 +370,13 @@ struct RsghmcOp {
     template <typename RegsT>
     __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
     {
+        T s0 = T(0), s1 = T(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (j < cnt) {
-            double th = (double)R.th[j], pp = (double)R.p[j];
-            acc[0] += th * th; acc[1] += pp * pp;
+            T th = R.th[j], pp = R.p[j];
+            s0 += th * th; s1 += pp * pp;
         }
+        acc[0] += (double)s0; acc[1] += (double)s1;
     }
     struct Regs { T th[4], p[4], gr[4], z[4]; };
 
@@ -458,20 +465,43 @@ struct MomentsOp {
 
 // Fused step statistics ("LDS-staged reduction, wavefront shuffles for the partial
 // sums"): every lane keeps 4 running sums in registers, a wave reduces them with
-// __shfl_down (64 lanes), the 4 waves of a block meet in LDS, and lane 0 writes ONE
+// DPP lane moves (row shifts + row broadcasts, 64 lanes), the 4 waves of a block meet in LDS, and ONE
 // 32-byte partial per block. A second, tiny kernel adds the partials in block order,
 // so the result is bit-reproducible for a given launch geometry. Costs no extra HBM
 // pass: the values are already in registers.
+// One DPP data-movement step on a double (two 32-bit halves). Lanes the control word / row mask
+// leaves without a source receive 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Wave64 sum with DPP cross-lane moves (VALU, no LDS crossbar traffic like __shfl/ds_bpermute):
+// quad_perm [1,0,3,2], [2,3,0,1], row_shr:4, row_shr:8, row_bcast:15 (rows 1,3), row_bcast:31
+// (rows 2,3). The total ends up in lane 63; fixed association => deterministic.
+__device__ __forceinline__ double wave_sum_dpp_lane63(double v)
+{
+    v += dpp_mov_f64<0xB1, 0xf>(v);
+    v += dpp_mov_f64<0x4E, 0xf>(v);
+    v += dpp_mov_f64<0x114, 0xf>(v);
+    v += dpp_mov_f64<0x118, 0xf>(v);
+    v += dpp_mov_f64<0x142, 0xa>(v);
+    v += dpp_mov_f64<0x143, 0xc>(v);
+    return v;
+}
+
 __device__ __forceinline__ void stats_block_write(double (&acc)[4], double *__restrict__ part)
 {
     __shared__ double lds[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        double v = acc[k];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) lds[wave][k] = v;
+        double v = wave_sum_dpp_lane63(acc[k]);
+        if (lane == 63) lds[wave][k] = v;
     }
     __syncthreads();
     if (threadIdx.x < 4) {

@@ -319,7 +319,7 @@ def test_fused_step_statistics(gpu, oracle, n):
         got = st.out.cpu().numpy()
         want = [(a.theta.double() ** 2).sum().item(), (a.V.double() ** 2).sum().item(),
                 a.minv.double().sum().item(), (a.minv.double() ** 2).sum().item()]
-        assert np.allclose(got, want, rtol=1e-12), (adapt, got, want)
+        assert np.allclose(got, want, rtol=5e-7), (adapt, got, want)   # quad-level sums in f32, totals in f64
         first = got.copy()
         c = GpuState(oracle.CState(th0, np.float32), gpu)
         c.minv.copy_(b.minv if not adapt else torch.ones(n, device=gpu))
@@ -334,13 +334,13 @@ def test_fused_step_statistics(gpu, oracle, n):
     kernels.sgld_step(a.theta, grad, a.tau, a.g, a.v_hat, a.minv, None, 0.01, 1.0, 50.0, True, seed=1, step=0, stats=st)
     kernels.step_stats_finish(st)
     got = st.out.cpu().numpy()
-    assert np.isclose(got[0], (a.theta.double() ** 2).sum().item(), rtol=1e-12) and got[1] == 0.0
-    assert np.isclose(got[2], a.minv.double().sum().item(), rtol=1e-12)
+    assert np.isclose(got[0], (a.theta.double() ** 2).sum().item(), rtol=5e-7) and got[1] == 0.0
+    assert np.isclose(got[2], a.minv.double().sum().item(), rtol=5e-7)
     kernels.rsghmc_step(a.theta, a.p, grad, 0.001, 1.0, 1.0, 1.0, 0.0, seed=1, step=0, stats=st)
     kernels.step_stats_finish(st)
     got = st.out.cpu().numpy()
-    assert np.isclose(got[0], (a.theta.double() ** 2).sum().item(), rtol=1e-12)
-    assert np.isclose(got[1], (a.p.double() ** 2).sum().item(), rtol=1e-12)
+    assert np.isclose(got[0], (a.theta.double() ** 2).sum().item(), rtol=5e-7)
+    assert np.isclose(got[1], (a.p.double() ** 2).sum().item(), rtol=5e-7)
 
 
 @pytest.mark.parametrize("npdt,thdt", DTYPES)

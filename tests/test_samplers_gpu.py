@@ -244,8 +244,8 @@ def test_hip_graph_mode_equals_eager(gpu):
     assert np.allclose(ce, cg, rtol=1e-6) and np.allclose(ce, cs, rtol=1e-6)
     assert graph.n_iterations == 12 and int(graph._step_ctr.item()) == 12
     st = graph.stats
-    assert np.isclose(st["theta_sq"], (graph.arena.row("theta").double() ** 2).sum().item(), rtol=1e-12)
-    assert np.isclose(st["momentum_sq"], (graph.arena.row("V").double() ** 2).sum().item(), rtol=1e-12)
+    assert np.isclose(st["theta_sq"], (graph.arena.row("theta").double() ** 2).sum().item(), rtol=5e-7)
+    assert np.isclose(st["momentum_sq"], (graph.arena.row("V").double() ** 2).sum().item(), rtol=5e-7)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])
