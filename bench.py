@@ -255,11 +255,19 @@ def main():
     exchange = RhatExchange(n, dev) if world > 1 else None
     rhat_summary = [None]
     half = max(args.rhat_every // 2, 1)
+    # thinned low-dimensional trace for ESS: [cost, theta[c0], theta[c1], theta[c2]] every moments_every steps,
+    # appended on the device (no sync); gathered across chains AFTER the timed region
+    coords = torch.tensor([0, n // 2, n - 1], device=dev)
+    trace = torch.zeros(max((args.steps + args.warmup) // max(args.moments_every, 1) + 1, 1), 4, device=dev)
+    kept = [0]
 
     def one_step(i):
-        next(sampler)
+        _, cost = next(sampler)
         if (i + 1) % args.moments_every == 0:
             moments.update(sampler.arena.row("theta"))                 # K4 Welford, every chain
+            trace[kept[0], 0:1].copy_(cost.reshape(1))
+            torch.index_select(sampler.arena.row("theta"), 0, coords, out=trace[kept[0], 1:4])
+            kept[0] += 1
         if exchange is not None:
             # the only exchange on the path: ONE all-reduce of 3P floats over RCCL/xGMI, issued
             # asynchronously and collected half a period later, so it overlaps with sampling
@@ -278,6 +286,7 @@ def main():
         one_step(i)
     frozen_phase = not getattr(sampler, "_adapting", False)
     moments.reset()
+    kept[0] = 0
     timer.enabled = True
     fence()
     t0 = time.perf_counter()
@@ -293,6 +302,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(sampler.arena.row("theta")).all()
+    ess = None
+    if kept[0] >= 8:
+        from pysgmcmc_amd.diagnostics.sampler_diagnostics import ess_across_ranks
+        ess = ess_across_ranks(trace[:kept[0]].contiguous())          # all-gather of kept x 4 floats (untimed)
 
     if rank == 0:
         mode = "rsghmc" if kind == "rsghmc" else "%s_%s" % (kind, "frozen" if frozen_phase else "adapt")
@@ -338,6 +351,8 @@ def main():
         }
         if rhat_summary[0] is not None:
             line["rhat"] = {k: round(v, 4) for k, v in rhat_summary[0].items()}
+        if ess is not None:
+            line["ess"] = {"kept_per_chain": kept[0], "cost": ess[0], "theta_coords": ess[1:]}
         if world == 1:
             if not args.no_update_only and kind == "sghmc":
                 line["update_only"] = update_only(sampler)

@@ -405,3 +405,49 @@ def test_large_array_64bit_indexing(gpu, oracle):
         want = oracle.c_philox_normal_range(77, 5, a, b - a, np.float32).astype(np.float64)
         got = theta[a:b].cpu().numpy().astype(np.float64)
         assert np.abs(got - want).max() < 1e-4 and np.abs(got - want).mean() < 1e-6
+
+
+def test_randomised_parity_sweep(gpu, oracle):
+    """60 random configurations (sampler, dtype, size incl. ragged tails, stepsize, scale_grad, mdecay/A,
+    grad_decay, phase, state magnitudes): injected-noise steps are bit-equal to the oracle."""
+    from pysgmcmc_amd import kernels
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        npdt = (np.float32, np.float64)[case % 2]
+        sampler = ("sghmc", "sgld", "rsghmc")[case % 3]
+        n = int(rng.integers(1, 40000))
+        eps = float(10 ** rng.uniform(-4, -0.5))
+        sg = float(10 ** rng.uniform(0, 6))
+        md = float(rng.uniform(0.001, 0.5))
+        wd = float(rng.choice([0.0, 10 ** rng.uniform(-6, -2)]))
+        cst = oracle.CState(rng.normal(size=n) * 10 ** rng.uniform(-3, 2), npdt)
+        cst.p[:] = rng.normal(size=n).astype(npdt)
+        cst.V[:] = (rng.normal(size=n) * 0.01).astype(npdt)
+        cst.v_hat[:] = (10 ** rng.uniform(-6, 4, size=n)).astype(npdt)
+        cst.g[:] = rng.normal(size=n).astype(npdt)
+        cst.tau[:] = (1 + rng.random(n) * 50).astype(npdt)
+        cst.minv[:] = (10 ** rng.uniform(-2, 2, size=n)).astype(npdt)
+        gst = GpuState(cst, gpu)
+        for t in range(3):
+            grad = (rng.normal(size=n) * 10 ** rng.uniform(-3, 3)).astype(npdt)
+            xi = rng.normal(size=n).astype(npdt)
+            adapt = bool(rng.integers(0, 2))
+            with np.errstate(all="ignore"):
+                if sampler == "sghmc":
+                    oracle.c_sghmc_step(cst, grad, eps, sg, md, adapt, xi, grad_decay=wd)
+                    kernels.sghmc_step(gst.theta, gst.V, _dev(grad, gpu), gst.tau, gst.g, gst.v_hat, gst.minv, gst.r,
+                                       eps, sg, md, adapt, xi=_dev(xi, gpu), grad_decay=wd)
+                    names = ("theta", "V", "tau", "g", "v_hat", "minv")
+                elif sampler == "sgld":
+                    oracle.c_sgld_step(cst, grad, eps, md * 4, sg, adapt, xi, grad_decay=wd)
+                    kernels.sgld_step(gst.theta, _dev(grad, gpu), gst.tau, gst.g, gst.v_hat, gst.minv, gst.r,
+                                      eps, md * 4, sg, adapt, xi=_dev(xi, gpu), grad_decay=wd)
+                    names = ("theta", "tau", "g", "v_hat", "minv")
+                else:
+                    oracle.c_rsghmc_step(cst, grad, eps, 1.0 + md, 0.5 + md, 1.0, md * 0.1, xi, grad_decay=wd)
+                    kernels.rsghmc_step(gst.theta, gst.p, _dev(grad, gpu), eps, 1.0 + md, 0.5 + md, 1.0, md * 0.1,
+                                        xi=_dev(xi, gpu), grad_decay=wd)
+                    names = ("theta", "p")
+            for name in names:
+                got = getattr(gst, name).cpu().numpy()
+                assert np.array_equal(got, getattr(cst, name), equal_nan=True), (case, sampler, npdt, n, t, name)

@@ -331,3 +331,31 @@ def test_materialize_r_and_relativistic_on_gpu(gpu, oracle):
     rs[0].sample_format = "view"
     smp = [v for v, _ in islice(rs[0], 20)][-1]
     assert torch.isfinite(smp).all() and smp.abs().max().item() < 1.0
+
+
+def test_torch_module_parameters_autograd_path(gpu):
+    """Drop-in use from PyTorch: the parameters of an nn.Module are adopted into the arena (the module keeps
+    working, its tensors alias theta), the cost is an ordinary autograd graph; chains are seed-reproducible
+    and the posterior samples fit the data."""
+    torch.manual_seed(0)
+    X = torch.linspace(-1, 1, 64, device=gpu).reshape(-1, 1)
+    Y = 2.0 * X - 0.5
+
+    def run(seed):
+        torch.manual_seed(1)
+        net = torch.nn.Sequential(torch.nn.Linear(1, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1)).to(gpu)
+        params = list(net.parameters())
+        cost = lambda p: 0.5 * ((net(X) - Y) ** 2).sum() / 0.01 + 0.5 * sum((q ** 2).sum() for q in p)
+        s = SGHMCSampler(params=params, cost_fun=cost, session=gpu, dtype=torch.float32, seed=seed,
+                         burn_in_steps=300, stepsize_schedule=ConstantStepsizeSchedule(0.003), mdecay=0.05)
+        s.sample_format = "view"
+        for p, v in zip(params, s.arena.views("theta")):
+            assert p.data_ptr() == v.data_ptr()                       # module tensors alias the arena
+        costs = [float(c) for _, c in islice(s, 1500)]
+        with torch.no_grad():
+            mse = float(((net(X) - Y) ** 2).mean())
+        return costs, mse, s.arena.row("theta").clone()
+    c1, mse1, th1 = run(3)
+    c2, mse2, th2 = run(3)
+    assert torch.equal(th1, th2) and c1 == c2
+    assert np.mean(c1[-200:]) < 0.05 * c1[0] and mse1 < 0.05
