@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--rhat-every", type=int, default=100, help="R-hat exchange cadence (steps), N > 1")
     ap.add_argument("--moments-every", type=int, default=10, help="Welford moments cadence (steps)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bnn10m-sghmc")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 code path "
+                         "on a box with fewer GPUs than ranks)")
+    ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="testing aid: every rank uses cuda:0")
     ap.add_argument("--eager", action="store_true", help="step eagerly instead of replaying one hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-update-only", action="store_true", help="skip the kernel-only loops (for rocprof runs)")
@@ -234,12 +238,15 @@ def main():
         raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists for the update path)")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.all_ranks_on_gpu0 else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)         # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     from pysgmcmc_amd import kernels
     # burn-in (preconditioner adaptation) happens inside the warm-up so that every TIMED step is in one
@@ -330,7 +337,8 @@ def main():
                        "rhat_every": args.rhat_every if world > 1 else None,
                        "moments_every": args.moments_every, "hip_graph": bool(sampler.use_hip_graph),
                        "launch": kernels.get_launch_config()},
-            "roofline": {"bound": "hbm", "kernel": "stream_quads_vec<%s<float,%s,false>,1,%s,true>" % (
+            # template args: <Op<float, ADAPT, INJECT>, quads per lane, NT, STATS, LOOP>
+            "roofline": {"bound": "hbm", "kernel": "stream_quads_vec<%s<float,%s,false>,1,%s,true,false>" % (
                              op_name, "false" if frozen_phase else "true",
                              "true" if alg_bytes > (640 << 20) else "false"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
