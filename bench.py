@@ -64,6 +64,8 @@ def parse():
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 code path "
                          "on a box with fewer GPUs than ranks)")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="testing aid: every rank uses cuda:0")
+    ap.add_argument("--no-gemm-tuning", action="store_true",
+                    help="keep the BLAS heuristics instead of letting TunableOp pick the GEMM solutions in warm-up")
     ap.add_argument("--eager", action="store_true", help="step eagerly instead of replaying one hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-update-only", action="store_true", help="skip the kernel-only loops (for rocprof runs)")
@@ -249,6 +251,9 @@ def main():
             dist.init_process_group("gloo")
 
     from pysgmcmc_amd import kernels
+    if not args.no_gemm_tuning:
+        from pysgmcmc_amd.models.bayesian_neural_network import enable_gemm_tuning
+        enable_gemm_tuning(True)                               # rocBLAS/hipBLASLt solution per shape, tuned in warm-up
     # burn-in (preconditioner adaptation) happens inside the warm-up so that every TIMED step is in one
     # phase: frozen if warmup >= 1, else (warmup = 0 -> burn_in_steps = 0) perpetual adaptation
     sampler = build_chain(dev, rank, args.workload, burn_in=min(8, max(args.warmup, 0)))
@@ -336,6 +341,7 @@ def main():
                        "params": n, "batch": BATCH, "chains": world,
                        "rhat_every": args.rhat_every if world > 1 else None,
                        "moments_every": args.moments_every, "hip_graph": bool(sampler.use_hip_graph),
+                       "gemm_tuning": not args.no_gemm_tuning,
                        "launch": kernels.get_launch_config()},
             # template args: <Op<float, ADAPT, INJECT>, quads per lane, NT, STATS, LOOP>
             "roofline": {"bound": "hbm", "kernel": "stream_quads_vec<%s<float,%s,false>,1,%s,true,false>" % (
