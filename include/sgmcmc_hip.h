@@ -185,12 +185,16 @@ int sgmcmc_summary_f64(const double *x, size_t n, double *out4, void *workspace,
  * sum(theta^2) comes from `theta_sumsq` (a device double) or, when `stats_ws` != NULL, from the
  * per-block partials the previous step kernel left in its statistics workspace (summed here in a
  * fixed order; saves the K7 launch on the critical path). All scalar outputs are device pointers.
- * fold_prior_grad = 1 leaves the weight-prior gradient term (wdecay / (n_params * n_examples)) * theta
- * out of the gradients because the caller passes it to the update kernel as grad_decay.
+ * fold_prior_grad is a bit mask: bit 0 leaves the weight-prior gradient term (wdecay / (n_params * n_examples)) * theta
+ * out of the gradients because the caller passes it to the update kernel as grad_decay; bit 1 says
+ * `mean` lacks the single-output layer's bias (a plain GEMV produced it) and *last_bias is added here.
  *
  * tanh_backward: delta[i] *= 1 - h[i]^2.
  * tanh_backward_colsum: the same on a row-major [rows][cols] matrix, plus colsum[c] = sum_r delta[r][c]
- * (+ beta * bias[c] if beta != 0): the bias gradient of that layer, deterministic (no atomics).         */
+ * (+ beta * bias[c] if beta != 0): the bias gradient of that layer, deterministic (no atomics).
+ * bnn_last_layer_backward: backward of a single-output last layer fused with the tanh backward below it:
+ * delta_prev[r][c] = dvec[r] w[c] (1 - h[r][c]^2), colsum[c] = sum_r delta_prev[r][c] (+ beta bias_prev[c]),
+ * gw[c] = sum_r h[r][c] dvec[r] (+ beta w[c]) -- replaces an outer product, a GEMV and the colsum kernel.      */
 int sgmcmc_bnn_head_f32(const float *mean, const float *y, const float *log_var, const double *theta_sumsq,
                         const void *stats_ws, const float *last_bias, size_t B,
                         double batch_size, double n_examples, double n_params, double wdecay, double prior_mean,
@@ -203,6 +207,12 @@ int sgmcmc_bnn_head_f64(const double *mean, const double *y, const double *log_v
                         double *grad_last_bias_out, double *mse_out, sgmcmc_stream_t stream);
 int sgmcmc_tanh_backward_f32(float *delta, const float *h, size_t n, sgmcmc_stream_t stream);
 int sgmcmc_tanh_backward_f64(double *delta, const double *h, size_t n, sgmcmc_stream_t stream);
+int sgmcmc_bnn_last_layer_backward_f32(const float *dvec, const float *w, const float *h, size_t rows, size_t cols,
+                                       const float *bias_prev, float beta, float *delta_prev, float *colsum, float *gw,
+                                       sgmcmc_stream_t stream);
+int sgmcmc_bnn_last_layer_backward_f64(const double *dvec, const double *w, const double *h, size_t rows, size_t cols,
+                                       const double *bias_prev, double beta, double *delta_prev, double *colsum,
+                                       double *gw, sgmcmc_stream_t stream);
 int sgmcmc_tanh_backward_colsum_f32(float *delta, const float *h, size_t rows, size_t cols, const float *bias, float beta,
                                     float *colsum, sgmcmc_stream_t stream);
 int sgmcmc_tanh_backward_colsum_f64(double *delta, const double *h, size_t rows, size_t cols, const double *bias,

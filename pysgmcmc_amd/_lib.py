@@ -70,6 +70,9 @@ def _declare(lib):
         f = getattr(lib, "sgmcmc_bnn_head_" + sfx)
         f.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz] + [ctypes.c_double] * 6 + [_ci, _vp, _vp, _vp, _vp, _vp, _vp]
         f.restype = _ci
+        f = getattr(lib, "sgmcmc_bnn_last_layer_backward_" + sfx)
+        f.argtypes = [_vp, _vp, _vp, _sz, _sz, _vp, real, _vp, _vp, _vp, _vp]
+        f.restype = _ci
         f = getattr(lib, "sgmcmc_tanh_backward_colsum_" + sfx)
         f.argtypes = [_vp, _vp, _sz, _sz, _vp, real, _vp, _vp]
         f.restype = _ci

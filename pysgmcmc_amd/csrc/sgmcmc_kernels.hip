@@ -737,6 +737,7 @@ __global__ void __launch_bounds__(256) philox_bits_kernel(uint32_t *__restrict__
 struct BnnHeadConsts {
     double batch_size, n_examples, wp_den, lvp_den, ln_prior_mean, ln_prior_var, wdecay;
     int fold_prior_grad;     // 1: the update kernel adds the weight-prior gradient (grad_decay), omit it here
+    int add_last_bias;       // 1: mean[] lacks the last layer's bias; add *last_bias
 };
 
 // mean[B], y[B]: network mean output and targets; s_ptr: the scalar log-variance parameter
@@ -757,8 +758,10 @@ __global__ void __launch_bounds__(1024) bnn_head_kernel(const T *__restrict__ me
     const double inv = 1.0 / (es + 1e-16);                       // :369
     const double dscale = -(inv / k.batch_size);
     double sse = 0.0, sumr = 0.0;
+    // add_bias: `mean` holds h W (no bias yet); the single-output layer's bias is added here
+    const double bias_add = (k.add_last_bias && last_bias != nullptr) ? (double)*last_bias : 0.0;
     for (size_t i = threadIdx.x; i < B; i += blockDim.x) {
-        double r = (double)y[i] - (double)mean[i];
+        double r = (double)y[i] - ((double)mean[i] + bias_add);
         sse += r * r;                                            // :370
         sumr += r;
         delta[i] = (T)(r * dscale);                              // d cost / d mean_i
@@ -860,6 +863,45 @@ __global__ void __launch_bounds__(1024) tanh_backward_colsum_kernel(T *__restric
 #pragma unroll
         for (int w = 0; w < 16; ++w) tot += lds[w][lane];
         colsum[c] = (beta != T(0)) ? tot + beta * bias[c] : tot;
+    }
+}
+
+// Backward of a single-output last layer fused with the tanh backward of the layer below:
+//   delta_prev[r][c] = dvec[r] * w[c] * (1 - h[r][c]^2)     (rank-1 back-propagation + tanh')
+//   colsum[c]        = sum_r delta_prev[r][c] (+ beta * bias_prev[c])   bias gradient of the layer below
+//   gw[c]            = sum_r h[r][c] * dvec[r] (+ beta * w[c])          weight gradient of the last layer
+// Same block shape as tanh_backward_colsum_kernel (64 columns x 16 row-strided waves), deterministic.
+template <typename T>
+__global__ void __launch_bounds__(1024) last_layer_backward_kernel(const T *__restrict__ dvec, const T *__restrict__ w,
+                                                                    const T *__restrict__ h, size_t rows, size_t cols,
+                                                                    const T *__restrict__ bias_prev, T beta,
+                                                                    T *__restrict__ delta_prev, T *__restrict__ colsum,
+                                                                    T *__restrict__ gw)
+{
+    __shared__ T lds[2][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t c = (size_t)blockIdx.x * 64 + lane;
+    T acc_b = T(0), acc_w = T(0);
+    if (c < cols) {
+        const T wc = w[c];
+        for (size_t r = wave; r < rows; r += 16) {
+            const size_t i = r * cols + c;
+            const T hv = h[i], dr = dvec[r];
+            const T d = (dr * wc) * (T(1) - hv * hv);
+            delta_prev[i] = d;
+            acc_b += d;
+            acc_w += hv * dr;
+        }
+    }
+    lds[0][wave][lane] = acc_b;
+    lds[1][wave][lane] = acc_w;
+    __syncthreads();
+    if (wave == 0 && c < cols) {
+        T tb = T(0), tw = T(0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { tb += lds[0][k][lane]; tw += lds[1][k][lane]; }
+        colsum[c] = (beta != T(0)) ? tb + beta * bias_prev[c] : tb;
+        gw[c] = (beta != T(0)) ? tw + beta * w[c] : tw;
     }
 }
 
@@ -1108,7 +1150,8 @@ int bnn_head(const T *mean, const T *y, const T *s_ptr, const double *theta_sums
     k.wp_den = n_params + (2.0 * 1e-16 + 1e-16);                 /* safe_divide, n_params > 0 */
     k.lvp_den = 2.0 * prior_var + (2.0 * 1e-16 + 1e-16);
     k.ln_prior_mean = std::log(prior_mean); k.ln_prior_var = std::log(prior_var);
-    k.fold_prior_grad = fold_prior_grad ? 1 : 0;
+    k.fold_prior_grad = (fold_prior_grad & 1) ? 1 : 0;
+    k.add_last_bias = (fold_prior_grad & 2) ? 1 : 0;
     hipLaunchKernelGGL((bnn_head_kernel<T>), dim3(1), dim3(1024), 0, st, mean, y, s_ptr, theta_sumsq,
                        static_cast<const double *>(stats_ws), last_bias, B, k, delta, cost_out, grad_s_out, grad_bias_out,
                        mse_out);
@@ -1116,6 +1159,19 @@ int bnn_head(const T *mean, const T *y, const T *s_ptr, const double *theta_sums
     return e == hipSuccess ? 0 : hip_fail(e, "launch bnn_head");
 }
 
+
+template <typename T>
+int last_layer_backward_impl(const T *dvec, const T *w, const T *h, size_t rows, size_t cols, const T *bias_prev, T beta,
+                             T *delta_prev, T *colsum, T *gw, hipStream_t st)
+{
+    if (rows == 0 || cols == 0) return 0;
+    if (!dvec || !w || !h || !delta_prev || !colsum || !gw || (beta != T(0) && !bias_prev))
+        return fail(SGMCMC_EINVAL, "last_layer_backward: NULL argument");
+    hipLaunchKernelGGL((last_layer_backward_kernel<T>), dim3((unsigned)((cols + 63) / 64)), dim3(1024), 0, st, dvec, w, h,
+                       rows, cols, bias_prev, beta, delta_prev, colsum, gw);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch last_layer_backward");
+}
 
 template <typename T>
 int tanh_backward_colsum_impl(T *delta, const T *h, size_t rows, size_t cols, const T *bias, T beta, T *colsum,
@@ -1353,6 +1409,20 @@ int sgmcmc_tanh_backward_colsum_f64(double *delta, const double *h, size_t rows,
                                     double beta, double *colsum, sgmcmc_stream_t stream)
 {
     return tanh_backward_colsum_impl<double>(delta, h, rows, cols, bias, beta, colsum, static_cast<hipStream_t>(stream));
+}
+int sgmcmc_bnn_last_layer_backward_f32(const float *dvec, const float *w, const float *h, size_t rows, size_t cols,
+                                       const float *bias_prev, float beta, float *delta_prev, float *colsum, float *gw,
+                                       sgmcmc_stream_t stream)
+{
+    return last_layer_backward_impl<float>(dvec, w, h, rows, cols, bias_prev, beta, delta_prev, colsum, gw,
+                                           static_cast<hipStream_t>(stream));
+}
+int sgmcmc_bnn_last_layer_backward_f64(const double *dvec, const double *w, const double *h, size_t rows, size_t cols,
+                                       const double *bias_prev, double beta, double *delta_prev, double *colsum,
+                                       double *gw, sgmcmc_stream_t stream)
+{
+    return last_layer_backward_impl<double>(dvec, w, h, rows, cols, bias_prev, beta, delta_prev, colsum, gw,
+                                            static_cast<hipStream_t>(stream));
 }
 int sgmcmc_tanh_backward_f64(double *delta, const double *h, size_t n, sgmcmc_stream_t stream)
 {

@@ -15,7 +15,7 @@ from pysgmcmc_amd._lib import SgmcmcLibraryError, check, lib
 __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
-    "set_launch_config", "get_launch_config", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "step_stats_finish",
+    "set_launch_config", "get_launch_config", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "step_stats_finish",
 ]
 
 _SFX = {torch.float32: "f32", torch.float64: "f64"}
@@ -200,7 +200,7 @@ def summary(x, out4=None, workspace=None):
 
 def bnn_head(mean, y, log_var, theta_sumsq, batch_size, n_examples, n_params, wdecay, prior_mean, prior_var,
              delta, cost_out, grad_log_var_out, mse_out, fold_prior_grad=False, stats_workspace=None,
-             last_bias=None, grad_last_bias_out=None):
+             last_bias=None, grad_last_bias_out=None, add_last_bias=False):
     """Loss head of the BNN cost path in one launch (see include/sgmcmc_hip.h). ``theta_sumsq`` is a
     float64 device scalar, or None when ``stats_workspace`` (a StepStats.workspace) is given."""
     f = getattr(lib(), "sgmcmc_bnn_head_" + _sfx(mean))
@@ -209,7 +209,7 @@ def bnn_head(mean, y, log_var, theta_sumsq, batch_size, n_examples, n_params, wd
     with _on(mean):
         rc = f(_ptr(mean), _ptr(y, mean), _ptr(log_var), _ptr(theta_sumsq), _ptr(stats_workspace), _ptr(last_bias),
                mean.numel(), float(batch_size), float(n_examples), float(n_params), float(wdecay), float(prior_mean),
-               float(prior_var), int(bool(fold_prior_grad)), _ptr(delta, mean), _ptr(cost_out),
+               float(prior_var), int(bool(fold_prior_grad)) | (2 if add_last_bias else 0), _ptr(delta, mean), _ptr(cost_out),
                _ptr(grad_log_var_out), _ptr(grad_last_bias_out), _ptr(mse_out), _stream(mean))
     check(rc, "sgmcmc_bnn_head")
 
@@ -230,3 +230,14 @@ def tanh_backward_colsum(delta, h, colsum, bias=None, beta=0.0):
     with _on(delta):
         rc = f(_ptr(delta), _ptr(h, delta), rows, cols, _ptr(bias), float(beta), _ptr(colsum), _stream(delta))
     check(rc, "sgmcmc_tanh_backward_colsum")
+
+
+def bnn_last_layer_backward(dvec, w, h, delta_prev, colsum, gw, bias_prev=None, beta=0.0):
+    """Backward of a single-output last layer fused with the tanh backward of the layer below
+    (see include/sgmcmc_hip.h): fills delta_prev (rows, cols), colsum (cols,), gw (cols,)."""
+    f = getattr(lib(), "sgmcmc_bnn_last_layer_backward_" + _sfx(h))
+    rows, cols = h.shape
+    with _on(h):
+        rc = f(_ptr(dvec), _ptr(w), _ptr(h), rows, cols, _ptr(bias_prev), float(beta), _ptr(delta_prev, h),
+               _ptr(colsum), _ptr(gw), _stream(h))
+    check(rc, "sgmcmc_bnn_last_layer_backward")

@@ -250,7 +250,19 @@ class BNNCost(object):
         n_layers = (len(params) - 1) // 2
         ws = self._buffers(params, B)
         hs, ds = ws["h"], ws["d"]
-        self._forward(params, X, hs)
+        L = n_layers - 1
+        single_out = params[2 * L].shape[1] == 1 and n_layers >= 2
+        # forward; a single-output last layer is a plain GEMV whose bias the loss head adds
+        h = X
+        for l in range(n_layers):
+            W, b = params[2 * l], params[2 * l + 1]
+            if l == L and single_out:
+                torch.mv(h, W.view(-1), out=hs[l].view(-1))
+            else:
+                torch.addmm(b, h, W, out=hs[l])
+            if l < L:
+                torch.tanh_(hs[l])
+            h = hs[l]
         n_params = float(sum(p.numel() for p in params))
         if theta_sumsq is None and theta_sumsq_partials is None:
             theta_sumsq = torch.zeros((), dtype=torch.float64, device=X.device)
@@ -259,43 +271,38 @@ class BNNCost(object):
         prior_coef = self.wdecay / ((n_params + 3e-16) * self.n_examples)
         self.grad_theta_coef = prior_coef if self.fold_prior else 0.0
         beta = 0.0 if self.fold_prior else prior_coef
-        single_out = params[2 * (n_layers - 1)].shape[1] == 1
         # loss head: delta_L, cost, d/d log_var, mse and (single-output net) the last bias gradient
-        kernels.bnn_head(hs[-1].view(-1), Y.reshape(-1), params[-1], theta_sumsq, self.batch_size, self.n_examples,
+        kernels.bnn_head(hs[L].view(-1), Y.reshape(-1), params[-1], theta_sumsq, self.batch_size, self.n_examples,
                          n_params, self.wdecay, self.prior_mean, self.prior_var,
-                         ds[-1].view(-1), ws["cost"], grad_views[-1], ws["mse"], fold_prior_grad=self.fold_prior,
+                         ds[L].view(-1), ws["cost"], grad_views[-1], ws["mse"], fold_prior_grad=self.fold_prior,
                          stats_workspace=theta_sumsq_partials,
-                         last_bias=params[2 * n_layers - 1] if single_out else None,
-                         grad_last_bias_out=grad_views[2 * n_layers - 1] if single_out else None)
+                         last_bias=params[2 * L + 1] if single_out else None,
+                         grad_last_bias_out=grad_views[2 * L + 1] if single_out else None,
+                         add_last_bias=single_out)
         self.last_mse = ws["mse"]
-        ones = ws["ones"]
-        for l in range(n_layers - 1, -1, -1):
+        for l in range(L, -1, -1):
             h_in = X if l == 0 else hs[l - 1]
             W, b = params[2 * l], params[2 * l + 1]
-            single = W.shape[1] == 1                 # one output unit: GEMV / outer product instead of N = 1 GEMMs
+            if l == L and single_out:
+                # gW_L, delta_{L-1} (incl. tanh') and gb_{L-1} in one launch
+                kernels.bnn_last_layer_backward(ds[l].view(-1), W.view(-1), hs[l - 1], ds[l - 1],
+                                                grad_views[2 * (l - 1) + 1], grad_views[2 * l].view(-1),
+                                                bias_prev=params[2 * (l - 1) + 1], beta=beta)
+                continue
             # gW_l = h_{l-1}^T delta_l written directly into the gradient arena. The weight-prior term
             # coef * theta is added by the update kernel (fold_prior) or rides in the GEMM epilogue (beta).
-            if single:
-                if self.fold_prior:
-                    torch.mv(h_in.t(), ds[l].view(-1), out=grad_views[2 * l].view(-1))
-                else:
-                    torch.addmv(W.view(-1), h_in.t(), ds[l].view(-1), beta=prior_coef, alpha=1.0,
-                                out=grad_views[2 * l].view(-1))
-            elif self.fold_prior:
+            if self.fold_prior:
                 torch.mm(h_in.t(), ds[l], out=grad_views[2 * l])
             else:
                 torch.addmm(W, h_in.t(), ds[l], beta=prior_coef, alpha=1.0, out=grad_views[2 * l])
-            if l == n_layers - 1 and not single_out:
+            if l == L:
                 # bias gradient of a multi-output last layer (hidden layers get theirs from the fused kernel below)
                 if self.fold_prior:
-                    torch.mv(ds[l].t(), ones, out=grad_views[2 * l + 1])
+                    torch.mv(ds[l].t(), ws["ones"], out=grad_views[2 * l + 1])
                 else:
-                    torch.addmv(b, ds[l].t(), ones, beta=prior_coef, alpha=1.0, out=grad_views[2 * l + 1])
+                    torch.addmv(b, ds[l].t(), ws["ones"], beta=prior_coef, alpha=1.0, out=grad_views[2 * l + 1])
             if l > 0:
-                if single:
-                    torch.mul(ds[l], W.view(1, -1), out=ds[l - 1])       # (B,1) x (1,H) outer product
-                else:
-                    torch.mm(ds[l], W.t(), out=ds[l - 1])
+                torch.mm(ds[l], W.t(), out=ds[l - 1])
                 # delta_{l-1} *= 1 - h_{l-1}^2, and gb_{l-1} = column sums of the result (+ beta * b_{l-1})
                 kernels.tanh_backward_colsum(ds[l - 1], hs[l - 1], grad_views[2 * (l - 1) + 1],
                                              bias=params[2 * (l - 1) + 1], beta=beta)
