@@ -255,8 +255,19 @@ class MCMCSampler(object):
     def _format_sample(self):
         fmt = self.sample_format
         if fmt == "numpy":
-            flat = self.arena.row("theta").detach().cpu().numpy()
-            out = [flat[o:o + s].reshape(shp).copy()
+            # ONE D2H copy of the flat theta row into a fresh host array; the per-parameter arrays are
+            # views of it (every step gets its own buffer, so earlier samples are never overwritten)
+            theta = self.arena.row("theta").detach()
+            if theta.is_cuda and theta.numel() * theta.element_size() >= (1 << 20):
+                # large chains: D2H into page-locked memory (PyTorch caches and recycles these blocks;
+                # 3-4x the rate of a pageable copy), the ndarray keeps the block alive
+                host = torch.empty(theta.shape, dtype=theta.dtype, pin_memory=True)
+                host.copy_(theta, non_blocking=True)
+                torch.cuda.current_stream(theta.device).synchronize()
+                flat = host.numpy()
+            else:
+                flat = theta.cpu().numpy()
+            out = [flat[o:o + s].reshape(shp)
                    for o, s, shp in zip(self.arena.offsets, self.arena.sizes, self.arena.shapes)]
         elif fmt == "device":
             out = [v.detach().clone() for v in self.arena.views("theta")]
