@@ -266,7 +266,8 @@ class MCMCSampler(object):
                 torch.cuda.current_stream(theta.device).synchronize()
                 flat = host.numpy()
             else:
-                flat = theta.cpu().numpy()
+                # .cpu() of a host tensor is the tensor itself: clone so the sample never aliases the arena
+                flat = (theta.cpu() if theta.is_cuda else theta.clone()).numpy()
             out = [flat[o:o + s].reshape(shp)
                    for o, s, shp in zip(self.arena.offsets, self.arena.sizes, self.arena.shapes)]
         elif fmt == "device":
