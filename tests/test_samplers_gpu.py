@@ -359,3 +359,18 @@ def test_torch_module_parameters_autograd_path(gpu):
     c2, mse2, th2 = run(3)
     assert torch.equal(th1, th2) and c1 == c2
     assert np.mean(c1[-200:]) < 0.05 * c1[0] and mse1 < 0.05
+
+
+def test_numpy_format_large_chain_uses_fresh_host_buffers(gpu):
+    """> 1 MiB chains copy through page-locked buffers: each sample owns its buffer (kept samples are never
+    overwritten by later steps) and equals the device state at that step."""
+    x = torch.zeros(600_000, device=gpu)
+    s = SGHMCSampler(params=[x], cost_fun=lambda p: 0.5 * (p[0] ** 2).sum(), session=gpu, dtype=torch.float32,
+                     seed=8, burn_in_steps=2)
+    kept, snaps = [], []
+    for sample, _ in islice(s, 5):
+        kept.append(sample)
+        snaps.append(s.arena.row("theta").cpu().numpy().copy())
+    for a, b in zip(kept, snaps):
+        assert isinstance(a, np.ndarray) and np.array_equal(a, b)
+    assert not np.array_equal(kept[0], kept[-1])
