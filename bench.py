@@ -221,10 +221,36 @@ def cpu_baseline(n, budget_s):
         O.c_sghmc_step(st, grad, 0.01, float(N_DATA), 0.05, False, xi)
         isteps += 1
     idt = time.perf_counter() - t2
+    # the FULL step on the CPU (same unit as `value`): numpy/BLAS forward + analytic backward of the same BNN
+    # on a window of the same synthetic data shape, then the fused C update with Philox noise
+    layers = WORKLOADS["bnn10m-sghmc"]["layers"]
+    sizes = list(layers) + [1]
+    params = []
+    for fi, fo in zip(sizes[:-1], sizes[1:]):
+        params.append((rng.standard_normal((fi, fo), dtype=np.float32) / np.sqrt(fi)).astype(np.float32))
+        params.append(np.zeros(fo, np.float32))
+    params.append(np.full((1, 1), np.log(1e-3), np.float32))
+    Xb = rng.standard_normal((BATCH, layers[0]), dtype=np.float32)
+    Yb = rng.standard_normal((BATCH, 1), dtype=np.float32)
+    fst = O.CState(np.concatenate([p.ravel() for p in params]), np.float32)
+    fst.minv[:] = st.minv[:fst.n] if st.n >= fst.n else 1.0
+    offs = np.cumsum([0] + [p.size for p in params])
+    t3 = time.perf_counter()
+    fsteps = 0
+    while fsteps < 20 and (time.perf_counter() - t3) < budget_s / 2:
+        views = [fst.theta[offs[k]:offs[k + 1]].reshape(params[k].shape) for k in range(len(params))]
+        _, grads = O.bnn_cost_and_grad(views, Xb, Yb, BATCH, N_DATA)
+        gflat = np.concatenate([g.ravel() for g in grads])
+        O.c_sghmc_step(fst, gflat, 0.01, float(N_DATA), 0.05, False, None, seed=1, step=fsteps)
+        fsteps += 1
+    fdt = time.perf_counter() - t3
     return {"value": round(steps / dt, 3), "unit": "update-steps/s", "cores": cores, "kind": "port",
             "sample": "%d frozen SGHMC update steps (update kernel only, no BNN gradient) of %d fp32 params, "
                       "fused C oracle + OpenMP on %d threads, Philox noise generated in the loop like the GPU "
                       "kernel, %.1f s" % (steps, n, cores, dt),
+            "full_step_samples_per_s": round(fsteps / fdt, 3) if fsteps else None,
+            "full_step_sample": "%d complete steps (numpy/BLAS BNN forward+backward at batch %d + fused C update), "
+                                "%.1f s" % (fsteps, BATCH, fdt),
             "injected_noise_steps_per_s": round(isteps / idt, 3) if isteps else None,
             "opbyop_numpy_steps_per_s": round(asteps / adt, 3) if asteps else None}
 

@@ -460,6 +460,45 @@ def bnn_negative_log_likelihood(params, X, Y, batch_size, n_examples):
     return -log_like, np.mean(mse)
 
 
+def bnn_cost_and_grad(params, X, Y, batch_size, n_examples, wdecay=1.0, prior_mean=1e-6, prior_var=0.01):
+    """NLL of bayesian_neural_network.py:365-388 and its analytic gradient w.r.t. every parameter, in the
+    dtype of ``params`` (numpy; BLAS matmuls). Used as the CPU full-step baseline and cross-checked against
+    autograd in tests. Returns (nll, [grad per parameter])."""
+    n_layers = (len(params) - 1) // 2
+    dt = params[0].dtype.type
+    hs, h = [], X
+    for l in range(n_layers):
+        a = h @ params[2 * l] + params[2 * l + 1]
+        h = np.tanh(a) if l < n_layers - 1 else a
+        hs.append(h)
+    mean = hs[-1]
+    s = float(params[-1].ravel()[0])
+    es = np.exp(s)
+    inv = 1.0 / (es + 1e-16)
+    resid = (Y - mean).astype(np.float64)
+    sse = float((resid * resid).sum())
+    B = X.shape[0]
+    n_params = float(sum(p.size for p in params))
+    wp_den, lvp_den = n_params + 3e-16, 2.0 * prior_var + 3e-16
+    sumsq = float(sum((p.astype(np.float64) ** 2).sum() for p in params))
+    log_like = (-(sse * 0.5 * inv) - 0.5 * s * B) / batch_size
+    lvp = -(s - np.log(prior_mean)) ** 2 / lvp_den - 0.5 * np.log(prior_var)
+    wp = -0.5 * wdecay * sumsq / wp_den
+    cost = -(log_like + lvp / n_examples + wp / n_examples)
+    coef = wdecay / (wp_den * n_examples)
+    grads = [None] * len(params)
+    ds = -((sse * 0.5 * es * inv * inv - 0.5 * B) / batch_size + (-2.0 * (s - np.log(prior_mean)) / lvp_den) / n_examples)
+    grads[-1] = np.full(params[-1].shape, ds + coef * s, dtype=params[-1].dtype)
+    delta = (resid * (-(inv / batch_size))).astype(params[0].dtype)
+    for l in range(n_layers - 1, -1, -1):
+        h_in = X if l == 0 else hs[l - 1]
+        grads[2 * l] = (h_in.T @ delta + dt(coef) * params[2 * l]).astype(params[2 * l].dtype)
+        grads[2 * l + 1] = (delta.sum(axis=0) + dt(coef) * params[2 * l + 1]).astype(params[2 * l + 1].dtype)
+        if l > 0:
+            delta = (delta @ params[2 * l].T) * (dt(1.0) - hs[l - 1] * hs[l - 1])
+    return cost, grads
+
+
 # --------------------------------------------------------------------------
 # Cross-chain diagnostics (SURVEY.md 8e; formulas of pymc3 3.1, unpinned)
 # --------------------------------------------------------------------------

@@ -49,6 +49,11 @@ def test_bnn_cost_matches_oracle_and_fused_path(oracle):
     assert np.isclose(float(cost2), want_nll, rtol=1e-13)
     for a, b in zip(grads, gv):
         assert torch.allclose(a, b, rtol=1e-10, atol=1e-14)
+    # the numpy analytic gradient of the oracle (CPU full-step baseline) agrees too
+    c_np, g_np = oracle.bnn_cost_and_grad([p.numpy() for p in params], X, Y, 20, 100)
+    assert np.isclose(c_np, want_nll, rtol=1e-13)
+    for a, b in zip(grads, g_np):
+        assert np.allclose(a.numpy(), b, rtol=1e-10, atol=1e-14)
 
 
 def test_init_seeding_and_shapes():
