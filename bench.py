@@ -288,7 +288,11 @@ def main():
     from pysgmcmc_amd import kernels
     if not args.no_gemm_tuning:
         from pysgmcmc_amd.models.bayesian_neural_network import enable_gemm_tuning
-        enable_gemm_tuning(True)                               # rocBLAS/hipBLASLt solution per shape, tuned in warm-up
+        try:
+            enable_gemm_tuning(True)                           # rocBLAS/hipBLASLt solution per shape, tuned in warm-up
+        except Exception as exc:                               # tuning is an optimisation, never a requirement
+            print("bench: GEMM tuning unavailable (%s); using the BLAS heuristics" % exc, file=sys.stderr)
+            args.no_gemm_tuning = True
     # burn-in (preconditioner adaptation) happens inside the warm-up so that every TIMED step is in one
     # phase: frozen if warmup >= 1, else (warmup = 0 -> burn_in_steps = 0) perpetual adaptation
     sampler = build_chain(dev, rank, args.workload, burn_in=min(8, max(args.warmup, 0)))
