@@ -218,6 +218,37 @@ int sgmcmc_tanh_backward_colsum_f32(float *delta, const float *h, size_t rows, s
 int sgmcmc_tanh_backward_colsum_f64(double *delta, const double *h, size_t rows, size_t cols, const double *bias,
                                     double beta, double *colsum, sgmcmc_stream_t stream);
 
+/* Fused small-model path: `n_steps` COMPLETE SGHMC steps of a tanh-MLP BNN with one output unit in ONE
+ * launch, one 1024-lane workgroup per chain (the launch-bound regime of the reference's default 3x50
+ * net). Per step and chain: minibatch window [start, start+batch) of the resident data set, forward,
+ * loss head (pysgmcmc/models/bayesian_neural_network.py:365-388), analytic backward into `grad`, the K1
+ * update (pysgmcmc/samplers/sghmc.py:165-251; same operator and Philox stream as
+ * sgmcmc_sghmc_step: noise of element i at step s is xi(seed_base + chain, s, i); the weight-prior
+ * gradient rides in as grad_decay), sum(theta^2) for the next cost.
+ *   rows theta..minv: n_params elements per chain, chain c at + c * chain_stride, 16-B aligned;
+ *     parameter order W1, b1, ..., WL, bL, log_var (W row-major in x out).
+ *   layer_sizes: HOST array [inputs, h1, ..., 1] of n_layers + 1 ints (n_layers <= 8).
+ *   X [n_data][inputs], y [n_data]: device; window_starts: device [n_chains][n_steps].
+ *   step index = first_step + t; adapt while step < burn_in_steps (always if burn_in_steps == 0).
+ *   xi: NULL or injected noise [n_steps][n_params] for chain 0. cost_out: device [n_chains][n_steps],
+ *     cost_out[c][t] = NLL at the parameters BEFORE step t.
+ * Activations live in LDS: batch * sum(layer sizes) * 2 elements must fit 160 KiB.                  */
+int sgmcmc_bnn_fused_sghmc_steps_f32(float *theta, float *V, float *grad, float *tau, float *g, float *v_hat, float *minv,
+                                     size_t n_params, size_t chain_stride, int n_chains, const int *layer_sizes,
+                                     int n_layers, const float *X, const float *y, size_t n_data,
+                                     const int *window_starts, int batch, double batch_size, double n_examples,
+                                     double wdecay, double prior_mean, double prior_var, float eps, float scale_grad,
+                                     float mdecay, uint64_t first_step, uint64_t n_steps, uint64_t burn_in_steps,
+                                     uint64_t seed_base, const float *xi, float *cost_out, sgmcmc_stream_t stream);
+int sgmcmc_bnn_fused_sghmc_steps_f64(double *theta, double *V, double *grad, double *tau, double *g, double *v_hat,
+                                     double *minv, size_t n_params, size_t chain_stride, int n_chains,
+                                     const int *layer_sizes, int n_layers, const double *X, const double *y,
+                                     size_t n_data, const int *window_starts, int batch, double batch_size,
+                                     double n_examples, double wdecay, double prior_mean, double prior_var, double eps,
+                                     double scale_grad, double mdecay, uint64_t first_step, uint64_t n_steps,
+                                     uint64_t burn_in_steps, uint64_t seed_base, const double *xi, double *cost_out,
+                                     sgmcmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

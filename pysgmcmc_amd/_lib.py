@@ -26,10 +26,11 @@ def lib_path():
 def build(force=False):
     """Compile ``csrc/libsgmcmc_hip.so`` for gfx950 with hipcc (no GPU needed)."""
     import subprocess
-    src = os.path.join(_CSRC, "sgmcmc_kernels.hip")
-    hdr = os.path.join(os.path.dirname(_HERE), "include", "sgmcmc_hip.h")
+    deps = [os.path.join(_CSRC, f) for f in ("sgmcmc_kernels.hip", "sgmcmc_bnn_fused.hip", "sgmcmc_device.hpp",
+                                             "sgmcmc_host.hpp")]
+    deps.append(os.path.join(os.path.dirname(_HERE), "include", "sgmcmc_hip.h"))
     stale = (not os.path.exists(_LIB_PATH)
-             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(d) for d in deps))
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _CSRC, "libsgmcmc_hip.so"])
     return _LIB_PATH
@@ -78,6 +79,10 @@ def _declare(lib):
         f.restype = _ci
         f = getattr(lib, "sgmcmc_tanh_backward_" + sfx)
         f.argtypes = [_vp, _vp, _sz, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_bnn_fused_sghmc_steps_" + sfx)
+        f.argtypes = ([_vp] * 7 + [_sz, _sz, _ci, ctypes.POINTER(_ci), _ci, _vp, _vp, _sz, _vp, _ci]
+                      + [ctypes.c_double] * 5 + [real, real, real, _u64, _u64, _u64, _u64, _vp, _vp, _vp])
         f.restype = _ci
         f = getattr(lib, "sgmcmc_summary_" + sfx)
         f.argtypes = [_vp, _sz, _vp, _vp, _vp]

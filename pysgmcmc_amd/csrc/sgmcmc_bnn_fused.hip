@@ -1,0 +1,315 @@
+// sgmcmc_bnn_fused.hip -- whole SGHMC steps of a SMALL tanh-MLP BNN in one kernel.
+//
+// BASELINE.json configs[1] (the reference's default model: 3x50 tanh net, 5 252 parameters,
+// minibatch 20) is launch-bound on any GPU: one `next(sampler)` is ~20 launches of ~3-5 us even
+// when replayed from a hipGraph. This kernel runs `n_steps` COMPLETE steps -- minibatch window,
+// forward, loss head (pysgmcmc/models/bayesian_neural_network.py:365-388), analytic backward into
+// the gradient row, fused SGHMC update (pysgmcmc/samplers/sghmc.py:165-251, the same quad operator
+// and the same Philox stream as kernel K1), sum(theta^2) for the next cost -- with ONE workgroup of
+// 1024 lanes per chain and `__syncthreads()` between phases. Activations and deltas live in LDS,
+// parameters and sampler state stay in their arena rows (L2-resident at this size). blockIdx.x is
+// the chain: independent chains (seed = seed_base + chain, own state rows, own window stream) run
+// concurrently on other CUs at no extra cost.
+//
+// The update arithmetic is the shared SghmcOp (bit-identical to K1 given the same gradient); the
+// matrix products are plain fp32/fp64 dot products in k order, so a fused chain tracks the
+// GEMM-based path to rounding (tests: 2e-4 relative over 12 steps, like the GEMM path itself
+// against the fp64 golden trajectory).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "sgmcmc_hip.h"
+
+#pragma clang fp contract(off)
+
+#include "sgmcmc_device.hpp"
+#include "sgmcmc_host.hpp"
+
+using namespace sgmcmc_host;
+
+namespace {
+
+constexpr int FUSED_MAX_LAYERS = 8;
+constexpr int FUSED_THREADS = 1024;
+
+template <typename T>
+struct FusedArgs {
+    T *theta, *V, *grad, *tau, *g, *vh, *minv;          // chain c at + c * chain_stride
+    size_t n_params, chain_stride;
+    int n_layers;                                        // number of weight layers L
+    int sizes[FUSED_MAX_LAYERS + 1];                     // sizes[0] = inputs, sizes[L] = 1
+    size_t off_w[FUSED_MAX_LAYERS + 1], off_b[FUSED_MAX_LAYERS + 1];   // parameter offsets of layer l (1-based)
+    size_t act_off[FUSED_MAX_LAYERS + 1], del_off[FUSED_MAX_LAYERS + 1];  // LDS element offsets
+    size_t lds_y;                                        // LDS element offset of the target window
+    const T *X, *y;
+    size_t n_data;
+    const int *starts;                                   // [n_chains][n_steps]
+    int batch;
+    double batch_size, n_examples, wp_den, lvp_den, ln_prior_mean, ln_prior_var, wdecay;
+    T eps_e2, c1, c3, e4, mdecay, grad_decay;            // host-derived scalars of K1
+    uint64_t first_step, n_steps, burn_in_steps, seed_base;
+    const T *xi;                                         // nullable: [n_steps][n_params], chain 0
+    T *cost_out;                                         // [n_chains][n_steps]
+};
+
+// block-wide sum of one double per lane; every lane returns the total. red: 17 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double *red)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum_dpp_lane63(v);
+    __syncthreads();                                      // red may still be read from the previous call
+    if (lane == 63) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        red[16] = t;
+    }
+    __syncthreads();
+    return red[16];
+}
+
+template <typename T, bool ADAPT, bool INJECT>
+__device__ __forceinline__ double update_phase(const FusedArgs<T> &a, T *theta, T *V, const T *grad, T *tau, T *g, T *vh,
+                                               T *minv, const T *xi, uint64_t seed, uint64_t step)
+{
+    NoiseKey nk;
+    nk.k0 = (uint32_t)seed; nk.k1 = (uint32_t)(seed >> 32);
+    nk.s0 = (uint32_t)step; nk.s1 = (uint32_t)(step >> 32);
+    nk.step_dev = nullptr;
+    SghmcOp<T, ADAPT, INJECT> op{theta, V, grad, tau, g, vh, minv, nullptr, xi,
+                                 a.eps_e2, a.c1, a.c3, a.e4, a.mdecay, a.grad_decay, nk, nullptr};
+    const size_t nq_full = a.n_params / 4;
+    const int tail = (int)(a.n_params % 4);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (size_t q = threadIdx.x; q < nq_full; q += blockDim.x) {
+        typename SghmcOp<T, ADAPT, INJECT>::Regs R;
+        op.template load_vec<false>(q, R);
+        op.compute(q, R);
+        op.template store_vec<false>(q, R);
+        op.accumulate(R, 4, acc);
+    }
+    if (tail && threadIdx.x == blockDim.x - 1) {
+        typename SghmcOp<T, ADAPT, INJECT>::Regs R;
+        op.load_part_(nq_full, tail, R);
+        op.compute(nq_full, R);
+        op.store_part_(nq_full, tail, R);
+        op.accumulate(R, tail, acc);
+    }
+    return acc[0];                                        // this lane's share of sum(theta'^2)
+}
+
+template <typename T>
+__global__ void __launch_bounds__(FUSED_THREADS) bnn_fused_sghmc_kernel(const FusedArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double *red = reinterpret_cast<double *>(smem_raw);           // 17 doubles (+ pad to 160 B)
+    T *lds = reinterpret_cast<T *>(smem_raw + 160);
+    const int chain = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const size_t cs = (size_t)chain * a.chain_stride;
+    T *theta = a.theta + cs, *V = a.V + cs, *grad = a.grad + cs;
+    T *tau = a.tau + cs, *g = a.g + cs, *vh = a.vh + cs, *minv = a.minv + cs;
+    const int L = a.n_layers, B = a.batch;
+    const uint64_t seed = a.seed_base + (uint64_t)chain;
+    T *yb = lds + a.lds_y;
+
+    // sum(theta^2) of the starting point (weight-prior value of the first cost)
+    double part = 0.0;
+    for (size_t i = tid; i < a.n_params; i += nt) { double v = (double)theta[i]; part += v * v; }
+    double tsq = block_sum(part, red);
+
+    for (uint64_t t = 0; t < a.n_steps; ++t) {
+        const uint64_t step = a.first_step + t;
+        const size_t start = (size_t)a.starts[(size_t)chain * a.n_steps + t];
+        // ---- minibatch window [start, start + B) (pysgmcmc/data_batches.py:118-123)
+        {
+            const int D = a.sizes[0];
+            T *x0 = lds + a.act_off[0];
+            for (int i = tid; i < B * D; i += nt) x0[i] = a.X[start * D + i];
+            for (int i = tid; i < B; i += nt) yb[i] = a.y[start + i];
+        }
+        __syncthreads();
+        // ---- forward
+        for (int l = 1; l <= L; ++l) {
+            const int nin = a.sizes[l - 1], nout = a.sizes[l];
+            const T *W = theta + a.off_w[l], *bias = theta + a.off_b[l];
+            const T *hin = lds + a.act_off[l - 1];
+            T *hout = lds + a.act_off[l];
+            for (int idx = tid; idx < B * nout; idx += nt) {
+                const int b = idx / nout, j = idx - b * nout;
+                T acc = bias[j];
+                for (int k = 0; k < nin; ++k) acc += hin[b * nin + k] * W[(size_t)k * nout + j];
+                hout[idx] = (l < L) ? (T)tanh((double)acc) : acc;
+            }
+            __syncthreads();
+        }
+        // ---- loss head (bayesian_neural_network.py:365-388)
+        const double s = (double)theta[a.n_params - 1];
+        const double es = exp(s), inv = 1.0 / (es + 1e-16), dscale = -(inv / a.batch_size);
+        {
+            const T *mean = lds + a.act_off[L];
+            T *dL = lds + a.del_off[L];
+            double sse = 0.0;
+            for (int i = tid; i < B; i += nt) {
+                double r = (double)yb[i] - (double)mean[i];
+                sse += r * r;
+                dL[i] = (T)(r * dscale);
+            }
+            const double tot = block_sum(sse, red);       // ends with a barrier: dL is visible
+            if (tid == 0) {
+                const double Bd = (double)B;
+                double log_like = (-(tot * (0.5 * inv)) - 0.5 * s * Bd) / a.batch_size;
+                double d = s - a.ln_prior_mean;
+                double lvp = -(d * d) / a.lvp_den - 0.5 * a.ln_prior_var;
+                double wp = (-0.5 * a.wdecay) * tsq / a.wp_den;
+                a.cost_out[(size_t)chain * a.n_steps + t] = (T)(-(log_like + lvp / a.n_examples + wp / a.n_examples));
+                // d NLL / d log_var; its weight-prior term is added by the update (grad_decay)
+                grad[a.n_params - 1] = (T)(-((tot * (0.5 * es * inv * inv) - 0.5 * Bd) / a.batch_size
+                                             + (-2.0 * d / a.lvp_den) / a.n_examples));
+            }
+        }
+        // ---- backward
+        for (int l = L; l >= 1; --l) {
+            const int nin = a.sizes[l - 1], nout = a.sizes[l];
+            const T *W = theta + a.off_w[l];
+            const T *hin = lds + a.act_off[l - 1];
+            const T *dl = lds + a.del_off[l];
+            T *gW = grad + a.off_w[l], *gb = grad + a.off_b[l];
+            for (int idx = tid; idx < nin * nout; idx += nt) {            // gW = h_{l-1}^T delta_l
+                const int k = idx / nout, j = idx - k * nout;
+                T acc = T(0);
+                for (int b = 0; b < B; ++b) acc += hin[b * nin + k] * dl[b * nout + j];
+                gW[idx] = acc;
+            }
+            for (int j = tid; j < nout; j += nt) {                        // gb = delta_l^T 1
+                T acc = T(0);
+                for (int b = 0; b < B; ++b) acc += dl[b * nout + j];
+                gb[j] = acc;
+            }
+            if (l > 1) {                                                  // delta_{l-1} = (delta_l W^T) (1 - h^2)
+                T *dprev = lds + a.del_off[l - 1];
+                for (int idx = tid; idx < B * nin; idx += nt) {
+                    const int b = idx / nin, k = idx - b * nin;
+                    T acc = T(0);
+                    for (int j = 0; j < nout; ++j) acc += dl[b * nout + j] * W[(size_t)k * nout + j];
+                    const T hv = hin[idx];
+                    dprev[idx] = acc * (T(1) - hv * hv);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- fused SGHMC update (K1's operator) + sum(theta'^2)
+        const bool adapt = step < a.burn_in_steps || a.burn_in_steps == 0;
+        const T *xi = (a.xi != nullptr && chain == 0) ? a.xi + (size_t)t * a.n_params : nullptr;
+        double share;
+        if (adapt) {
+            share = xi ? update_phase<T, true, true>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step)
+                       : update_phase<T, true, false>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step);
+        } else {
+            share = xi ? update_phase<T, false, true>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step)
+                       : update_phase<T, false, false>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step);
+        }
+        __threadfence_block();
+        tsq = block_sum(share, red);                      // barriers inside: the new theta is visible to the block
+    }
+}
+
+template <typename T>
+int bnn_fused_steps(T *theta, T *V, T *grad, T *tau, T *g, T *v_hat, T *minv, size_t n_params, size_t chain_stride,
+                    int n_chains, const int *layer_sizes, int n_layers, const T *X, const T *y, size_t n_data,
+                    const int *window_starts, int batch, double batch_size, double n_examples, double wdecay,
+                    double prior_mean, double prior_var, T eps, T scale_grad, T mdecay, uint64_t first_step,
+                    uint64_t n_steps, uint64_t burn_in_steps, uint64_t seed_base, const T *xi, T *cost_out, hipStream_t st)
+{
+    if (n_steps == 0 || n_chains == 0) return 0;
+    if (!theta || !V || !grad || !tau || !g || !v_hat || !minv || !layer_sizes || !X || !y || !window_starts || !cost_out)
+        return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: NULL argument");
+    if (n_layers < 1 || n_layers > FUSED_MAX_LAYERS) return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: 1..8 layers");
+    if (layer_sizes[n_layers] != 1) return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: the last layer must have one unit");
+    if (batch < 1 || (size_t)batch > n_data) return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: bad batch");
+    if (xi && (n_params % 4) != 0) return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: injected xi needs n_params %% 4 == 0");
+    if (n_chains > 1 && (chain_stride < n_params || (chain_stride % 4) != 0))
+        return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: chain_stride must be >= n_params and a multiple of 4");
+    T *rows[7] = {theta, V, grad, tau, g, v_hat, minv};
+    for (T *p : rows)
+        if (reinterpret_cast<uintptr_t>(p) & 15u) return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: rows must be 16-B aligned");
+    FusedArgs<T> a;
+    a.theta = theta; a.V = V; a.grad = grad; a.tau = tau; a.g = g; a.vh = v_hat; a.minv = minv;
+    a.n_params = n_params; a.chain_stride = chain_stride; a.n_layers = n_layers;
+    size_t off = 0, lds_elems = 0;
+    for (int l = 0; l <= n_layers; ++l) {
+        if (layer_sizes[l] < 1) return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: bad layer size");
+        a.sizes[l] = layer_sizes[l];
+    }
+    for (int l = 1; l <= n_layers; ++l) {                  // parameter order: W1, b1, ..., WL, bL, log_var
+        a.off_w[l] = off; off += (size_t)a.sizes[l - 1] * a.sizes[l];
+        a.off_b[l] = off; off += (size_t)a.sizes[l];
+    }
+    if (off + 1 != n_params) return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: n_params does not match the layer sizes");
+    for (int l = 0; l <= n_layers; ++l) { a.act_off[l] = lds_elems; lds_elems += (size_t)batch * a.sizes[l]; }
+    a.del_off[0] = 0;
+    for (int l = 1; l <= n_layers; ++l) { a.del_off[l] = lds_elems; lds_elems += (size_t)batch * a.sizes[l]; }
+    a.lds_y = lds_elems; lds_elems += (size_t)batch;
+    const size_t lds_bytes = 160 + lds_elems * sizeof(T);
+    if (lds_bytes > 160 * 1024) return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: activations need %zu B of LDS (> 160 KiB); "
+                                            "use the GEMM path", lds_bytes);
+    a.X = X; a.y = y; a.n_data = n_data; a.starts = window_starts; a.batch = batch;
+    a.batch_size = batch_size; a.n_examples = n_examples; a.wdecay = wdecay;
+    a.wp_den = (double)n_params + (2.0 * 1e-16 + 1e-16);
+    a.lvp_den = 2.0 * prior_var + (2.0 * 1e-16 + 1e-16);
+    a.ln_prior_mean = std::log(prior_mean); a.ln_prior_var = std::log(prior_var);
+    // K1's host-derived scalars (sghmc.py:111-117,211-217,235), same op order
+    T eps_s = eps / std::sqrt(scale_grad);
+    a.eps_e2 = std::pow(eps, T(2));
+    a.c1 = (T(2) * std::pow(eps_s, T(2))) * mdecay;
+    a.c3 = T(2) * std::pow(eps_s, T(3));
+    a.e4 = std::pow(eps_s, T(4));
+    a.mdecay = mdecay;
+    a.grad_decay = (T)(wdecay / (a.wp_den * n_examples));   // weight-prior gradient, folded into the update
+    a.first_step = first_step; a.n_steps = n_steps; a.burn_in_steps = burn_in_steps; a.seed_base = seed_base;
+    a.xi = xi; a.cost_out = cost_out;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&bnn_fused_sghmc_kernel<T>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e0 != hipSuccess) return hip_fail(e0, "hipFuncSetAttribute(bnn_fused_sghmc_kernel)");
+    }
+    hipLaunchKernelGGL((bnn_fused_sghmc_kernel<T>), dim3((unsigned)n_chains), dim3(FUSED_THREADS), lds_bytes, st, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch bnn_fused_sghmc_kernel");
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgmcmc_bnn_fused_sghmc_steps_f32(float *theta, float *V, float *grad, float *tau, float *g, float *v_hat, float *minv,
+                                     size_t n_params, size_t chain_stride, int n_chains, const int *layer_sizes,
+                                     int n_layers, const float *X, const float *y, size_t n_data,
+                                     const int *window_starts, int batch, double batch_size, double n_examples,
+                                     double wdecay, double prior_mean, double prior_var, float eps, float scale_grad,
+                                     float mdecay, uint64_t first_step, uint64_t n_steps, uint64_t burn_in_steps,
+                                     uint64_t seed_base, const float *xi, float *cost_out, sgmcmc_stream_t stream)
+{
+    return bnn_fused_steps<float>(theta, V, grad, tau, g, v_hat, minv, n_params, chain_stride, n_chains, layer_sizes,
+                                  n_layers, X, y, n_data, window_starts, batch, batch_size, n_examples, wdecay,
+                                  prior_mean, prior_var, eps, scale_grad, mdecay, first_step, n_steps, burn_in_steps,
+                                  seed_base, xi, cost_out, static_cast<hipStream_t>(stream));
+}
+int sgmcmc_bnn_fused_sghmc_steps_f64(double *theta, double *V, double *grad, double *tau, double *g, double *v_hat,
+                                     double *minv, size_t n_params, size_t chain_stride, int n_chains,
+                                     const int *layer_sizes, int n_layers, const double *X, const double *y,
+                                     size_t n_data, const int *window_starts, int batch, double batch_size,
+                                     double n_examples, double wdecay, double prior_mean, double prior_var, double eps,
+                                     double scale_grad, double mdecay, uint64_t first_step, uint64_t n_steps,
+                                     uint64_t burn_in_steps, uint64_t seed_base, const double *xi, double *cost_out,
+                                     sgmcmc_stream_t stream)
+{
+    return bnn_fused_steps<double>(theta, V, grad, tau, g, v_hat, minv, n_params, chain_stride, n_chains, layer_sizes,
+                                   n_layers, X, y, n_data, window_starts, batch, batch_size, n_examples, wdecay,
+                                   prior_mean, prior_var, eps, scale_grad, mdecay, first_step, n_steps, burn_in_steps,
+                                   seed_base, xi, cost_out, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

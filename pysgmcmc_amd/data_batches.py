@@ -17,7 +17,7 @@ import logging
 import numpy as np
 import torch
 
-__all__ = ["Placeholder", "generate_batches", "generate_shuffled_batches"]
+__all__ = ["Placeholder", "WindowBatches", "generate_batches", "generate_shuffled_batches"]
 
 
 class Placeholder(object):
@@ -95,15 +95,34 @@ def generate_batches(x, y, x_placeholder, y_placeholder, batch_size=20, seed=Non
 
     x_dev = _resident(x, x_placeholder)
     y_dev = _resident(y, y_placeholder).reshape(n_examples, -1)[:, :1]
+    return WindowBatches(x_dev, y_dev, x_placeholder, y_placeholder, batch_size, rng)
 
-    def batches():
-        while True:
-            start = rng.randint(0, (n_examples - batch_size + 1))
-            yield {
-                x_placeholder: x_dev[start:start + batch_size],
-                y_placeholder: y_dev[start:start + batch_size].reshape(-1, 1),
-            }
-    return batches()
+
+class WindowBatches(object):
+    """The infinite minibatch iterator behind :func:`generate_batches`: ``next()`` yields the feed dict of
+    one random contiguous window; ``next_starts(n)`` draws the start indices of the next ``n`` windows from
+    the SAME RandomState stream (for kernels that gather the windows themselves)."""
+
+    def __init__(self, x_dev, y_dev, x_placeholder, y_placeholder, batch_size, rng):
+        self.x_dev, self.y_dev = x_dev, y_dev
+        self.x_placeholder, self.y_placeholder = x_placeholder, y_placeholder
+        self.batch_size = int(batch_size)
+        self.n_examples = int(x_dev.shape[0])
+        self._rng = rng
+
+    def __iter__(self):
+        return self
+
+    def next_starts(self, n):
+        hi = self.n_examples - self.batch_size + 1
+        return np.asarray([self._rng.randint(0, hi) for _ in range(int(n))], dtype=np.int32)
+
+    def __next__(self):
+        start = int(self.next_starts(1)[0])
+        return {
+            self.x_placeholder: self.x_dev[start:start + self.batch_size],
+            self.y_placeholder: self.y_dev[start:start + self.batch_size].reshape(-1, 1),
+        }
 
 
 def generate_shuffled_batches(x, y, x_placeholder, y_placeholder, batch_size=20, seed=None):

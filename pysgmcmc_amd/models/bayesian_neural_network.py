@@ -419,6 +419,9 @@ class BayesianNeuralNetwork(object):
         # replay the ~25 launches of the cost/gradient pipeline from one hipGraph per step; the 3x50
         # default net is launch-bound (50x50 GEMMs), SURVEY.md 8(f).1
         self.use_hip_graph = True
+        # run whole steps of small nets inside one kernel (csrc/sgmcmc_bnn_fused.hip) when the model fits:
+        # the chain advances in chunks between the logging / sample-collection points of the loop below
+        self.use_fused_steps = True
 
     def _device(self):
         if isinstance(self.session, (torch.device, str)):
@@ -498,15 +501,39 @@ class BayesianNeuralNetwork(object):
                                                                   seconds_elapsed))
 
         logging_intervals = {"burn-in": 512, "sampling": self.sample_steps}
-        sample_chain = itertools.islice(self.sampler, self.n_iters)
-        for iteration_index, (parameter_values, _) in enumerate(sample_chain):
+        fused = bool(self.use_fused_steps and self.fused_cost and hasattr(self.sampler, "fused_bnn_available")
+                     and self.sampler.fused_bnn_available())
+        self.used_fused_steps = fused
+
+        def handle(iteration_index, parameter_values):
+            """Bookkeeping of the reference loop for the sample of iteration `iteration_index` (:514-531)."""
             burning_in = iteration_index <= self.burn_in_steps
             if burning_in and iteration_index % logging_intervals["burn-in"] == 0:
                 log_full_training_error(iteration_index=iteration_index, is_sampling=False)
             if not burning_in and iteration_index % logging_intervals["sampling"] == 0:
                 log_full_training_error(iteration_index=iteration_index, is_sampling=True)
                 self.samples.append([v.clone() for v in parameter_values])
-                if len(self.samples) == self.n_nets:
+                return len(self.samples) == self.n_nets
+            return False
+
+        if fused:
+            # same loop, advanced in chunks: only iterations that log or collect need the host
+            def is_event(i):
+                return (i <= self.burn_in_steps and i % logging_intervals["burn-in"] == 0) or \
+                       (i > self.burn_in_steps and i % logging_intervals["sampling"] == 0)
+            i = 0                                           # index of the next sample to produce
+            while i < self.n_iters:
+                e = i
+                while e < self.n_iters - 1 and not is_event(e):
+                    e += 1
+                self.sampler.fused_bnn_steps(e - i + 1)     # produces samples i .. e
+                if handle(e, self.sampler.arena.views("theta")):
+                    break
+                i = e + 1
+        else:
+            sample_chain = itertools.islice(self.sampler, self.n_iters)
+            for iteration_index, (parameter_values, _) in enumerate(sample_chain):
+                if handle(iteration_index, parameter_values):
                     break
         self.is_trained = True
 

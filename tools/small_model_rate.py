@@ -33,3 +33,14 @@ for dtype in (torch.float32, torch.float64):
         for _ in islice(s, n): pass
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print("%s use_hip_graph=%-5s : %8.0f samples/s  (%.1f us/step)" % (str(dtype).split(".")[1], mode, n / dt, dt / n * 1e6))
+
+    s = chain(False, dtype)
+    s.fused_bnn_steps(300)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(30): s.fused_bnn_steps(100)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("%s fused kernel, 100 steps/launch : %8.0f samples/s  (%.1f us/step)" % (str(dtype).split(".")[1], 3000 / dt, dt / 3000 * 1e6))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(1000): s.fused_bnn_steps(1)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("%s fused kernel, 1 step/launch    : %8.0f samples/s  (%.1f us/step)" % (str(dtype).split(".")[1], 1000 / dt, dt / 1000 * 1e6))
