@@ -232,7 +232,8 @@ int sgmcmc_tanh_backward_colsum_f64(double *delta, const double *h, size_t rows,
  *   step index = first_step + t; adapt while step < burn_in_steps (always if burn_in_steps == 0).
  *   xi: NULL or injected noise [n_steps][n_params] for chain 0. cost_out: device [n_chains][n_steps],
  *     cost_out[c][t] = NLL at the parameters BEFORE step t.
- * Activations live in LDS: batch * sum(layer sizes) * 2 elements must fit 160 KiB.                  */
+ * Activations and a copy of the parameters live in LDS: (2 * batch * sum(layer sizes) + n_params)
+ * elements must fit 160 KiB (else SGMCMC_EINVAL: use the GEMM path).                               */
 int sgmcmc_bnn_fused_sghmc_steps_f32(float *theta, float *V, float *grad, float *tau, float *g, float *v_hat, float *minv,
                                      size_t n_params, size_t chain_stride, int n_chains, const int *layer_sizes,
                                      int n_layers, const float *X, const float *y, size_t n_data,

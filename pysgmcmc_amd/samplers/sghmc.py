@@ -60,7 +60,7 @@ class SGHMCSampler(BurnInMCMCSampler):
         sizes = self._bnn_layer_sizes()
         if sizes is None or sizes[-1] != 1 or len(sizes) - 1 > 8:
             return False
-        lds = 160 + (2 * sum(sizes) + 1) * gen.batch_size * self.arena.row("theta").element_size()
+        lds = 160 + ((2 * sum(sizes) + 1) * gen.batch_size + self.arena.n + 4) * self.arena.row("theta").element_size()
         return lds <= 160 * 1024 and gen.x_dev.dtype == self._torch_dtype and gen.x_dev.is_contiguous()
 
     def _bnn_layer_sizes(self):
