@@ -250,6 +250,38 @@ int sgmcmc_bnn_fused_sghmc_steps_f64(double *theta, double *V, double *grad, dou
                                      uint64_t burn_in_steps, uint64_t seed_base, const double *xi, double *cost_out,
                                      sgmcmc_stream_t stream);
 
+/* ---- Stein variational gradient descent: pysgmcmc/samplers/svgd.py:118-181 -----------------------
+ * The n particles are the rows of a [n_particles x ld] device matrix (row pitch ld >= dim elements);
+ * grad[i] = d cost / d particle i (svgd.py:118), hist_grad = `historical_grad` (svgd.py:107-110).
+ * sgmcmc_svgd_step_* does one step in place:
+ *   D = squareform(pdist(X)) ** 2 (tensor_utils.py:397-408, 466-565; svgd.py:165-166),
+ *   h = sqrt(0.5 median(D) / log(n + 1)) (tensor_utils.py:197-209; svgd.py:169-171),
+ *   K = exp(-D / h^2 / 2), kgrad = (-K X + X * rowsum(K)) / h^2 (svgd.py:173-181),
+ *   grad_theta = (K grad + repulsion_sign * kgrad) / n (svgd.py:124-127),
+ *   hist = alpha hist + (1 - alpha) grad_theta^2; X -= eps grad_theta / (fudge + sqrt(hist)) (:129-143).
+ * repulsion_sign = +1 is the reference as written (its kernel-gradient term ATTRACTS the particles:
+ * it is added to a COST gradient and the sum is subtracted); -1 is Liu & Wang's repulsive update.
+ * workspace: sgmcmc_svgd_workspace_bytes(n_particles, sizeof element) bytes of device memory, 64-B
+ * aligned, owned by the caller; it holds D, K, the bandwidth and the partial sums between launches.
+ * n_particles <= sgmcmc_svgd_max_particles() (128), else SGMCMC_EINVAL.
+ * sgmcmc_svgd_kernel_* is `SVGDSampler.svgd_kernel(particles)` (svgd.py:149-181): kernel_out
+ * [n x n], kernel_grad_out [n x kernel_grad_ld] (already divided by h^2) and bandwidth_out
+ * {median, h, h^2} are device pointers, each may be NULL.                                          */
+size_t sgmcmc_svgd_workspace_bytes(size_t n_particles, size_t elem_bytes);
+int sgmcmc_svgd_max_particles(void);
+int sgmcmc_svgd_step_f32(float *particles, const float *grad, float *hist_grad, size_t n_particles, size_t dim, size_t ld,
+                         float eps, double alpha, float fudge_factor, int repulsion_sign, void *workspace,
+                         sgmcmc_stream_t stream);
+int sgmcmc_svgd_step_f64(double *particles, const double *grad, double *hist_grad, size_t n_particles, size_t dim,
+                         size_t ld, double eps, double alpha, double fudge_factor, int repulsion_sign, void *workspace,
+                         sgmcmc_stream_t stream);
+int sgmcmc_svgd_kernel_f32(const float *particles, size_t n_particles, size_t dim, size_t ld, void *workspace,
+                           float *kernel_out, float *kernel_grad_out, size_t kernel_grad_ld, float *bandwidth_out,
+                           sgmcmc_stream_t stream);
+int sgmcmc_svgd_kernel_f64(const double *particles, size_t n_particles, size_t dim, size_t ld, void *workspace,
+                           double *kernel_out, double *kernel_grad_out, size_t kernel_grad_ld, double *bandwidth_out,
+                           sgmcmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

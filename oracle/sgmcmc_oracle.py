@@ -537,3 +537,62 @@ def effective_n(chains):
             negative_autocorr = (rho[t - 1] + rho[t]) < 0
         t += 1
     return int(m * n / (1.0 + 2.0 * rho[1:t].sum()))
+
+
+# ---------------------------------------------------------------------------------------------
+# Stein variational gradient descent (pysgmcmc/samplers/svgd.py) -- op-by-op numpy restatement.
+# Parity UNPINNED against reference outputs (no TensorFlow here; the reference has no SVGD test).
+# ---------------------------------------------------------------------------------------------
+
+def svgd_median(values):
+    """pysgmcmc/tensor_utils.py:197-209: middle value of the flattened, sorted tensor; for an even
+    count the mean of the two middle values."""
+    v = np.sort(np.asarray(values).reshape(-1))
+    n = v.shape[0]
+    mid = n // 2
+    if n % 2 == 1:
+        return v[mid]
+    return (v[mid - 1] + v[mid]) / v.dtype.type(2)
+
+
+def svgd_pairwise_sqdist(X):
+    """``squareform(pdist(X)) ** 2`` (pysgmcmc/samplers/svgd.py:165-166): pdist is
+    ``tf.norm(X[i] - X[j])`` for every i < j (tensor_utils.py:397-408), squareform mirrors it into a
+    symmetric matrix with a zero diagonal (tensor_utils.py:466-565), then the element-wise square."""
+    X = np.asarray(X)
+    n = X.shape[0]
+    dist = np.zeros((n, n), X.dtype)
+    for i in range(n):
+        diff = X[i][None, :] - X[i + 1:]
+        dist[i, i + 1:] = np.sqrt(np.sum(diff * diff, axis=1, dtype=X.dtype))
+    dist = dist + dist.T
+    return dist * dist
+
+
+def svgd_kernel(X):
+    """RBF kernel with the median bandwidth and its summed gradients, pysgmcmc/samplers/svgd.py:149-181.
+    Returns (kernel_matrix, kernel_gradients, h, pairwise_sq_distances), all in X.dtype."""
+    X = np.asarray(X)
+    T = X.dtype.type
+    n = X.shape[0]
+    D = svgd_pairwise_sqdist(X)
+    h = np.sqrt(T(0.5) * svgd_median(D) / np.log(T(n) + T(1.0)))       # :169-171
+    K = np.exp(-D / (h * h) / T(2))                                     # :173
+    ksum = np.sum(K, axis=1, dtype=X.dtype)                             # :174
+    kgrad = -(K @ X) + X * ksum[:, None]                                # :176-179
+    return K, kgrad / (h * h), h, D                                     # :181
+
+
+def svgd_step(X, G, hist, eps, alpha=0.9, fudge=1e-6, repulsion_sign=1.0):
+    """One SVGD step in place on (X, hist), pysgmcmc/samplers/svgd.py:118-147. G[i] = d cost / d X[i].
+    ``repulsion_sign = +1`` is the reference as written: the kernel-gradient term is ADDED to
+    ``K @ grad(cost)`` and the sum is SUBTRACTED from the particles, which makes the term attract
+    particles instead of repelling them (quirk Q10); ``-1`` is Liu & Wang's update."""
+    T = X.dtype.type
+    n = X.shape[0]
+    K, kgrad, h, _ = svgd_kernel(X)
+    gt = (K @ G + T(repulsion_sign) * kgrad) / T(n)                     # :124-127
+    hist[...] = T(alpha) * hist + T(1. - alpha) * (gt * gt)             # :129-132
+    adj = gt / (T(fudge) + np.sqrt(hist))                               # :134-137
+    X -= T(eps) * adj                                                   # :139-143
+    return K, h

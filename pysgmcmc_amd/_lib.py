@@ -26,7 +26,7 @@ def lib_path():
 def build(force=False):
     """Compile ``csrc/libsgmcmc_hip.so`` for gfx950 with hipcc (no GPU needed)."""
     import subprocess
-    deps = [os.path.join(_CSRC, f) for f in ("sgmcmc_kernels.hip", "sgmcmc_bnn_fused.hip", "sgmcmc_device.hpp",
+    deps = [os.path.join(_CSRC, f) for f in ("sgmcmc_kernels.hip", "sgmcmc_bnn_fused.hip", "sgmcmc_svgd.hip", "sgmcmc_device.hpp",
                                              "sgmcmc_host.hpp")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "sgmcmc_hip.h"))
     stale = (not os.path.exists(_LIB_PATH)
@@ -84,6 +84,12 @@ def _declare(lib):
         f.argtypes = ([_vp] * 7 + [_sz, _sz, _ci, ctypes.POINTER(_ci), _ci, _vp, _vp, _sz, _vp, _ci]
                       + [ctypes.c_double] * 5 + [real, real, real, _u64, _u64, _u64, _u64, _vp, _vp, _vp])
         f.restype = _ci
+        f = getattr(lib, "sgmcmc_svgd_step_" + sfx)
+        f.argtypes = [_vp, _vp, _vp, _sz, _sz, _sz, real, ctypes.c_double, real, _ci, _vp, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_svgd_kernel_" + sfx)
+        f.argtypes = [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _sz, _vp, _vp]
+        f.restype = _ci
         f = getattr(lib, "sgmcmc_summary_" + sfx)
         f.argtypes = [_vp, _sz, _vp, _vp, _vp]
         f.restype = _ci
@@ -96,6 +102,9 @@ def _declare(lib):
     lib.sgmcmc_rhat_finish_f32.argtypes = [_vp, _sz, _ci, _u64, _vp, _vp]
     lib.sgmcmc_rhat_finish_f32.restype = _ci
     lib.sgmcmc_summary_workspace_bytes.restype = _sz
+    lib.sgmcmc_svgd_workspace_bytes.argtypes = [_sz, _sz]
+    lib.sgmcmc_svgd_workspace_bytes.restype = _sz
+    lib.sgmcmc_svgd_max_particles.restype = _ci
     lib.sgmcmc_step_stats_workspace_bytes.argtypes = [_sz]
     lib.sgmcmc_step_stats_workspace_bytes.restype = _sz
     lib.sgmcmc_step_stats_finish.argtypes = [_vp, _vp, _vp]

@@ -16,6 +16,7 @@ __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
     "set_launch_config", "get_launch_config", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
+    "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
 ]
 
 _SFX = {torch.float32: "f32", torch.float64: "f64"}
@@ -268,3 +269,47 @@ def bnn_fused_sghmc_steps(theta, V, grad, tau, g, v_hat, minv, layer_sizes, X, y
                _stream(theta))
     check(rc, "sgmcmc_bnn_fused_sghmc_steps")
     return cost_out
+
+
+def svgd_max_particles():
+    return int(lib().sgmcmc_svgd_max_particles())
+
+
+def svgd_workspace(n_particles, like):
+    """Device workspace of the SVGD kernels for ``n_particles`` particles in ``like``'s dtype/device."""
+    nbytes = int(lib().sgmcmc_svgd_workspace_bytes(int(n_particles), like.element_size()))
+    if nbytes == 0:
+        raise ValueError("pysgmcmc_amd: SVGD supports 1..%d particles, got %d" % (svgd_max_particles(), n_particles))
+    if not like.is_cuda:
+        _ptr(like)                       # raises the no-CPU-path error
+    return torch.empty(nbytes // like.element_size(), dtype=like.dtype, device=like.device)
+
+
+def svgd_step(particles, grad, hist_grad, n_particles, dim, eps, alpha, fudge_factor, workspace, ld=None,
+              repulsion_sign=1):
+    """One SVGD step in place on the ``[n_particles x ld]`` matrices (``sgmcmc_svgd_step_*``)."""
+    f = getattr(lib(), "sgmcmc_svgd_step_" + _sfx(particles))
+    ld = int(dim if ld is None else ld)
+    for t in (particles, grad, hist_grad):
+        if t.numel() < (n_particles - 1) * ld + dim:
+            raise ValueError("pysgmcmc_amd: SVGD matrix shorter than (n_particles - 1) * ld + dim")
+    with _on(particles):
+        rc = f(_ptr(particles), _ptr(grad), _ptr(hist_grad), int(n_particles), int(dim), ld, float(eps), float(alpha),
+               float(fudge_factor), int(repulsion_sign), _ptr(workspace), _stream(particles))
+    check(rc, "sgmcmc_svgd_step")
+
+
+def svgd_kernel(particles, n_particles, dim, workspace, ld=None, kernel_gradients=True):
+    """``svgd_kernel(particles)`` of the reference: returns (kernel_matrix [n, n], kernel_gradients [n, dim]
+    or None, bandwidth tensor {median, h, h^2}) as fresh device tensors."""
+    f = getattr(lib(), "sgmcmc_svgd_kernel_" + _sfx(particles))
+    ld = int(dim if ld is None else ld)
+    n = int(n_particles)
+    K = torch.empty((n, n), dtype=particles.dtype, device=particles.device)
+    kg = torch.empty((n, int(dim)), dtype=particles.dtype, device=particles.device) if kernel_gradients else None
+    bw = torch.empty(3, dtype=particles.dtype, device=particles.device)
+    with _on(particles):
+        rc = f(_ptr(particles), n, int(dim), ld, _ptr(workspace), _ptr(K), _ptr(kg), int(dim), _ptr(bw),
+               _stream(particles))
+    check(rc, "sgmcmc_svgd_kernel")
+    return K, kg, bw

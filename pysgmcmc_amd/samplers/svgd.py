@@ -1,0 +1,133 @@
+"""Stein variational gradient descent (Liu & Wang, NIPS 2016; mirror of
+``pysgmcmc/samplers/svgd.py``).
+
+The reference stacks the particles into an ``(n, d)`` tensor, builds one TF op per
+particle PAIR for the distances (``tensor_utils.py:397-408``), sorts all ``n*n``
+distances for the median bandwidth and runs two dense matmuls per step
+(``svgd.py:118-181``). Here the particles are the rows of the arena's theta row
+(``[n x d]``, contiguous), their cost gradients the rows of the grad row, and one
+step is ``sgmcmc_svgd_step_{f32,f64}``: four launches that read the particles twice
+and the gradients once (csrc/sgmcmc_svgd.hip).
+
+Sign of the kernel-gradient term (quirk Q10). The reference adds
+``kernel_gradients`` to ``K @ grad(cost)`` and SUBTRACTS the sum from the particles
+(``svgd.py:124-127,139-143``). The driving term is right (``-K grad(cost) = K grad log p``)
+but the kernel-gradient term enters with the wrong sign: it pulls particles together
+instead of pushing them apart, and the particle cloud collapses onto the mode. That
+is a bug; it is fixed here by default (Liu & Wang's update). Set
+``STRICT_REFERENCE_QUIRKS = True`` to reproduce the reference's arithmetic exactly.
+"""
+import torch
+
+from pysgmcmc_amd import kernels
+from pysgmcmc_amd.samplers.base_classes import MCMCSampler
+from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+
+__all__ = ("SVGDSampler", "STRICT_REFERENCE_QUIRKS")
+
+STRICT_REFERENCE_QUIRKS = False
+
+
+class SVGDSampler(MCMCSampler):
+    """Stein Variational Gradient Descent sampler (keywords/defaults as ``svgd.py:24-27``).
+
+    Parameters
+    ----------
+    particles : list of torch.Tensor
+        The particles, each a (different) guess of the target parameters; all of one size.
+    cost_fun : callable
+        Takes ONE particle and returns its scalar cost (``svgd.py:37-40``). A cost function
+        with the attribute ``batched = True`` is instead called once with the ``[n, d]``
+        matrix of all particles and must return the ``n`` costs (one backward pass for all
+        particles instead of ``n``).
+    alpha, fudge_factor : float
+        Decay of the running mean of squared updates and the constant added to its square
+        root (``svgd.py:129-137``; AdaGrad with momentum, as in Liu & Wang's code).
+
+    ``next(sampler)`` returns ``(particles, costs)``: the list of updated particles and the
+    vector of the ``n`` costs at the particles before the step.
+    """
+
+    _STATE_ROWS = ("historical_grad",)
+
+    def __init__(self, particles, cost_fun, batch_generator=None,
+                 stepsize_schedule=ConstantStepsizeSchedule(0.1),
+                 alpha=0.9, fudge_factor=1e-6, session=None,
+                 dtype=torch.float64, seed=None):
+        assert isinstance(alpha, (int, float))
+        assert isinstance(fudge_factor, (int, float))
+        assert callable(cost_fun)
+
+        particles = list(particles)
+        assert len(particles) >= 1, "SVGDSampler needs at least one particle"
+        sizes = {int(p.numel()) for p in particles}
+        assert len(sizes) == 1, "all particles must have the same number of elements"
+
+        self._particle_cost_fun = cost_fun
+        batched = bool(getattr(cost_fun, "batched", False))
+
+        def cost_fun_wrapper(params):
+            # svgd.py:86-87: the cost of every particle (tf.map_fn over the stacked particles)
+            if batched:
+                return cost_fun(self.particles)
+            return torch.stack([cost_fun(p).reshape(()) for p in params])
+
+        cost_fun_wrapper.__name__ = getattr(cost_fun, "__name__", "cost_fun")
+
+        super().__init__(
+            params=particles, cost_fun=cost_fun_wrapper, batch_generator=batch_generator,
+            session=session, seed=seed, dtype=dtype, stepsize_schedule=stepsize_schedule
+        )
+        self.alpha = float(alpha)
+        self.fudge_factor = float(fudge_factor)
+        self.n_particles = len(particles)
+        self.particle_dim = sizes.pop()
+        self.repulsion_sign = 1 if STRICT_REFERENCE_QUIRKS else -1
+        # the particles as one [n, d] matrix: the theta row of the arena (svgd.py:84 tf.stack)
+        self.particles = self.arena.row("theta").view(self.n_particles, self.particle_dim)
+        if batched:
+            self.particles.requires_grad_(True)
+        self._batched = batched
+        self._workspace = None
+        self.collect_stats = False
+
+    # the base class differentiates `cost_fun(self.params)`; a batched cost differentiates the matrix
+    def _cost_and_grad(self):
+        if not self._batched:
+            return super()._cost_and_grad()
+        self._grad_decay = 0.0
+        with torch.enable_grad():
+            cost = self.cost_fun(self.params)
+            if not isinstance(cost, torch.Tensor) or not cost.requires_grad:
+                raise ValueError("cost_fun(particles) must return a torch tensor that depends on the particles")
+            grad, = torch.autograd.grad(cost, [self.particles], grad_outputs=torch.ones_like(cost))
+        with torch.no_grad():
+            self.arena.row("grad").view(self.n_particles, self.particle_dim).copy_(grad)
+        return cost.detach()
+
+    def _ws(self):
+        if self._workspace is None:
+            self._workspace = kernels.svgd_workspace(self.n_particles, self.arena.row("theta"))
+        return self._workspace
+
+    def _kernel_step(self, eps, xi):
+        a = self.arena
+        kernels.svgd_step(a.row("theta"), a.row("grad"), a.row("historical_grad"),
+                          self.n_particles, self.particle_dim, eps, self.alpha, self.fudge_factor,
+                          self._ws(), repulsion_sign=self.repulsion_sign)
+
+    def svgd_kernel(self, particles=None):
+        """Kernel matrix and summed kernel gradients of the current particles (``svgd.py:149-181``):
+        ``(kernel_matrix [n, n], kernel_gradients [n, d])`` as device tensors. ``particles`` may be
+        an ``[n, d]`` device tensor to evaluate instead."""
+        if particles is None:
+            x, n, d = self.arena.row("theta"), self.n_particles, self.particle_dim
+            ws = self._ws()
+        else:
+            x = torch.as_tensor(particles).to(device=self.device, dtype=self._torch_dtype).contiguous()
+            assert x.dim() == 2, "svgd_kernel: a 2-d tensor must be passed."
+            n, d = int(x.shape[0]), int(x.shape[1])
+            ws = kernels.svgd_workspace(n, x)
+        K, kg, bw = kernels.svgd_kernel(x.reshape(-1), n, d, ws)
+        self.bandwidth = bw
+        return K, kg

@@ -21,9 +21,9 @@ def _sampler_class(method):
     if method == Sampler.RelativisticSGHMC:
         from pysgmcmc_amd.samplers.relativistic_sghmc import RelativisticSGHMCSampler
         return RelativisticSGHMCSampler
-    # SVGD is an enum member of the reference but a dense particle method outside
-    # the SG-MCMC update path this package implements; like any unknown method it
-    # gets the reference's "missing import" error (sampling.py:186-193).
+    if method == Sampler.SVGD:
+        from pysgmcmc_amd.samplers.svgd import SVGDSampler
+        return SVGDSampler
     raise ValueError(
         "Sampling method {sampler} is supported, but function "
         "'pysgmcmc.sampling.get_sampler' is missing an `import` "

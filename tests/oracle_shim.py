@@ -47,6 +47,26 @@ def rsghmc_step(theta, p_, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, s
     calls.append(("rsghmc", False, float(eps), int(step)))
 
 
+def svgd_workspace(n_particles, like):
+    return torch.empty(1, dtype=like.dtype)
+
+
+def svgd_step(particles, grad, hist_grad, n_particles, dim, eps, alpha, fudge_factor, workspace, ld=None,
+              repulsion_sign=1):
+    X = particles.detach().numpy()[:n_particles * dim].reshape(n_particles, dim)
+    G = grad.detach().numpy()[:n_particles * dim].reshape(n_particles, dim)
+    H = hist_grad.numpy()[:n_particles * dim].reshape(n_particles, dim)
+    O.svgd_step(X, G, H, eps, alpha, fudge_factor, repulsion_sign)
+    calls.append(("svgd", False, float(eps), int(repulsion_sign)))
+
+
+def svgd_kernel(particles, n_particles, dim, workspace, ld=None, kernel_gradients=True):
+    X = particles.detach().numpy()[:n_particles * dim].reshape(n_particles, dim)
+    K, kg, h, D = O.svgd_kernel(X)
+    bw = torch.tensor([O.svgd_median(D), h, h * h], dtype=particles.dtype)
+    return torch.from_numpy(K), (torch.from_numpy(kg) if kernel_gradients else None), bw
+
+
 calls = []
 
 
@@ -57,6 +77,9 @@ def install(monkeypatch):
     monkeypatch.setattr(kernels, "sghmc_step", sghmc_step)
     monkeypatch.setattr(kernels, "sgld_step", sgld_step)
     monkeypatch.setattr(kernels, "rsghmc_step", rsghmc_step)
+    monkeypatch.setattr(kernels, "svgd_workspace", svgd_workspace)
+    monkeypatch.setattr(kernels, "svgd_step", svgd_step)
+    monkeypatch.setattr(kernels, "svgd_kernel", svgd_kernel)
     return calls
 
 

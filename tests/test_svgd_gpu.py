@@ -1,0 +1,208 @@
+"""GPU parity tests of the SVGD kernels (``sgmcmc_svgd_*``, csrc/sgmcmc_svgd.hip) against the numpy
+oracle of ``pysgmcmc/samplers/svgd.py`` (oracle/sgmcmc_oracle.py: svgd_kernel / svgd_step).
+
+Sums over columns and particles (tf.norm, tf.reduce_sum, tf.matmul) have no reference rounding order, so
+the bar is a floating-point tolerance, written at each assert: f64 kernels against the f64 oracle at
+1e-10, f32 kernels against the f64 oracle evaluated on the same f32 inputs at ~1e-5 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sgmcmc_oracle as O
+from pysgmcmc_amd import kernels
+from pysgmcmc_amd._lib import SgmcmcLibraryError
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = {np.float32: dict(rtol=3e-5, atol=3e-6), np.float64: dict(rtol=1e-10, atol=1e-12)}
+
+
+def _cloud(n, d, dtype, seed=0, offset=0.0, scale=1.0):
+    rng = np.random.default_rng(seed)
+    return (offset + scale * rng.normal(size=(n, d))).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,d", [(2, 1), (3, 2), (10, 2), (7, 3), (16, 5252), (50, 100), (64, 1000), (100, 3),
+                                 (128, 257), (5, 70001), (33, 64), (1, 4)])
+def test_svgd_kernel_matches_oracle(n, d, dtype):
+    X = _cloud(n, d, dtype, seed=n * 1000 + d, scale=1.0 / np.sqrt(d))
+    K_ref, kg_ref, h_ref, D_ref = O.svgd_kernel(X.astype(np.float64))
+    x = torch.from_numpy(X).to(DEV)
+    ws = kernels.svgd_workspace(n, x)
+    K, kg, bw = kernels.svgd_kernel(x.reshape(-1), n, d, ws)
+    torch.cuda.synchronize()
+    K, kg, bw = K.cpu().numpy(), kg.cpu().numpy(), bw.cpu().numpy()
+    if n == 1:
+        # one particle: median 0, h 0, K = exp(-0/0) = nan in the reference too
+        assert bw[0] == 0 and bw[1] == 0
+        return
+    tol = TOL[dtype]
+    np.testing.assert_allclose(bw[0], O.svgd_median(D_ref), rtol=tol["rtol"])
+    np.testing.assert_allclose(bw[1], h_ref, rtol=tol["rtol"])
+    np.testing.assert_allclose(bw[2], h_ref * h_ref, rtol=2 * tol["rtol"])
+    np.testing.assert_allclose(K, K_ref, **tol)
+    assert np.array_equal(K, K.T) and np.all(np.diag(K) == 1)           # exact structure
+    # kernel gradients: a difference of two O(|x| * rowsum) sums, tolerance relative to that scale
+    scale = np.abs(X).max() * K_ref.sum(axis=1).max() / (h_ref * h_ref)
+    np.testing.assert_allclose(kg, kg_ref, rtol=tol["rtol"], atol=tol["rtol"] * scale * 4)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("sign", [1, -1])
+@pytest.mark.parametrize("n,d", [(10, 2), (20, 300), (64, 129), (128, 40), (4, 20000), (17, 1)])
+def test_svgd_single_step_matches_oracle(n, d, sign, dtype):
+    """One step from a random state (particles, gradients, running squared updates), both signs of the
+    kernel-gradient term."""
+    rng = np.random.default_rng(n * 31 + d)
+    X = _cloud(n, d, dtype, seed=7 + n + d, offset=0.3, scale=1.0 / np.sqrt(d))
+    G = rng.normal(size=(n, d)).astype(dtype)
+    H = rng.uniform(0.05, 1.0, size=(n, d)).astype(dtype)
+    x, g, h = (torch.from_numpy(a.copy()).to(DEV).reshape(-1) for a in (X, G, H))
+    ws = kernels.svgd_workspace(n, x)
+    eps, alpha, fudge = 0.05, 0.9, 1e-6
+    kernels.svgd_step(x, g, h, n, d, eps, alpha, fudge, ws, repulsion_sign=sign)
+    Xo, Ho = X.astype(np.float64), H.astype(np.float64)
+    O.svgd_step(Xo, G.astype(np.float64), Ho, eps, alpha, fudge, float(sign))
+    torch.cuda.synchronize()
+    rtol = 2e-5 if dtype == np.float32 else 1e-10
+    np.testing.assert_allclose(x.cpu().numpy().reshape(n, d), Xo, rtol=rtol, atol=rtol)
+    np.testing.assert_allclose(h.cpu().numpy().reshape(n, d), Ho, rtol=10 * rtol, atol=rtol * 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_svgd_free_running_trajectory(dtype):
+    """12 steps of the repulsive update on a quadratic cost, starting from zero running statistics."""
+    n, d = 12, 3
+    X = _cloud(n, d, dtype, seed=21, offset=0.3)
+    Xo, Ho = X.astype(np.float64), np.zeros((n, d))
+    x = torch.from_numpy(X.copy()).to(DEV).reshape(-1)
+    h = torch.zeros_like(x)
+    ws = kernels.svgd_workspace(n, x)
+    for t in range(12):
+        g = (x * 1.5).contiguous()                                          # d/dx 0.75 |x|^2
+        kernels.svgd_step(x, g, h, n, d, 0.05, 0.9, 1e-6, ws, repulsion_sign=-1)
+        O.svgd_step(Xo, 1.5 * Xo, Ho, 0.05, 0.9, 1e-6, -1.0)
+    rtol = 5e-4 if dtype == np.float32 else 1e-9
+    np.testing.assert_allclose(x.cpu().numpy().reshape(n, d), Xo, rtol=rtol, atol=rtol)
+
+
+def test_svgd_elementwise_tail_is_op_for_op():
+    """With ONE far-apart pair the sums have a single term each, so the whole step must equal the f32 oracle
+    up to the last bit of exp/log (checked at 4 ulp)."""
+    X = np.array([[0.0, 1.0], [3.0, -2.0]], np.float32)
+    G = np.array([[0.5, -1.0], [2.0, 0.25]], np.float32)
+    H = np.array([[0.1, 0.2], [0.3, 0.4]], np.float32)
+    x, g, h = (torch.from_numpy(a.copy()).to(DEV).reshape(-1) for a in (X, G, H))
+    ws = kernels.svgd_workspace(2, x)
+    kernels.svgd_step(x, g, h, 2, 2, 0.1, 0.9, 1e-6, ws, repulsion_sign=1)
+    Xo, Ho = X.copy(), H.copy()
+    O.svgd_step(Xo, G, Ho, 0.1, 0.9, 1e-6, 1.0)
+    np.testing.assert_allclose(x.cpu().numpy().reshape(2, 2), Xo, rtol=5e-7)
+    np.testing.assert_allclose(h.cpu().numpy().reshape(2, 2), Ho, rtol=5e-7)
+
+
+def test_svgd_median_ties_zeros_and_reproducibility():
+    # duplicated particles: many exact zeros in D, the median falls inside the tie
+    base = _cloud(6, 40, np.float32, seed=5)
+    X = np.concatenate([base, base, base[:3]], axis=0)                       # 15 particles, odd n*n
+    x = torch.from_numpy(X).to(DEV)
+    ws = kernels.svgd_workspace(15, x)
+    K, kg, bw = kernels.svgd_kernel(x.reshape(-1), 15, 40, ws)
+    _, _, h_ref, D_ref = O.svgd_kernel(X.astype(np.float64))
+    np.testing.assert_allclose(bw[0].item(), O.svgd_median(D_ref), rtol=1e-5)
+    assert np.all(K.cpu().numpy()[np.arange(6), np.arange(6) + 6] == 1.0)   # identical particles: K = 1
+    # bit-reproducible run to run (fixed-order partial sums, no atomics) at a multi-workgroup size
+    X = _cloud(24, 300000, np.float32, seed=9)
+    outs = []
+    for _ in range(2):
+        x = torch.from_numpy(X.copy()).to(DEV).reshape(-1)
+        g = (0.5 * x).contiguous()
+        h = torch.zeros_like(x)
+        ws = kernels.svgd_workspace(24, x)
+        for _ in range(2):
+            kernels.svgd_step(x, g, h, 24, 300000, 0.1, 0.9, 1e-6, ws, repulsion_sign=-1)
+        outs.append((x.cpu().numpy(), h.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_svgd_row_pitch_and_large_dim_properties():
+    """ld > dim leaves the padding untouched; at 16 particles x 2 M parameters the kernel matrix is invariant
+    under a common translation of all particles and K of a scaled cloud equals K of the cloud (the median
+    bandwidth scales with it)."""
+    n, d, ld = 5, 37, 64
+    buf = torch.full((n * ld,), 7.0, device=DEV)
+    X = _cloud(n, d, np.float32, seed=2)
+    buf.view(n, ld)[:, :d] = torch.from_numpy(X).to(DEV)
+    g = torch.zeros_like(buf)
+    h = torch.zeros_like(buf)
+    ws = kernels.svgd_workspace(n, buf)
+    kernels.svgd_step(buf, g, h, n, d, 0.1, 0.9, 1e-6, ws, ld=ld, repulsion_sign=-1)
+    out = buf.view(n, ld).cpu().numpy()
+    assert np.all(out[:, d:] == 7.0) and np.all(h.view(n, ld)[:, d:].cpu().numpy() == 0)
+    Xo, Ho = X.astype(np.float64), np.zeros((n, d))
+    O.svgd_step(Xo, np.zeros((n, d)), Ho, 0.1, 0.9, 1e-6, -1.0)
+    np.testing.assert_allclose(out[:, :d], Xo, rtol=2e-5, atol=2e-6)
+
+    n, d = 16, 2_000_003
+    x = torch.randn(n, d, device=DEV) * (1.0 / d ** 0.5)
+    ws = kernels.svgd_workspace(n, x)
+    K0, _, bw0 = kernels.svgd_kernel(x.reshape(-1), n, d, ws, kernel_gradients=False)
+    K1, _, bw1 = kernels.svgd_kernel((x * 4.0).reshape(-1), n, d, ws, kernel_gradients=False)
+    K2, _, _ = kernels.svgd_kernel((x + 0.125).reshape(-1), n, d, ws, kernel_gradients=False)
+    torch.testing.assert_close(K1, K0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bw1[1], 4.0 * bw0[1], rtol=1e-5, atol=0)
+    torch.testing.assert_close(K2, K0, rtol=1e-3, atol=1e-4)
+    ref = torch.cdist(x.double(), x.double()) ** 2
+    h2 = 0.5 * ref.flatten().sort().values[[n * n // 2 - 1, n * n // 2]].mean() / np.log(n + 1.0)
+    torch.testing.assert_close(K0.double(), torch.exp(-ref / h2 / 2), rtol=1e-4, atol=1e-5)
+
+
+def test_svgd_fails_loudly():
+    x = torch.zeros(129 * 4, device=DEV)
+    with pytest.raises(ValueError):
+        kernels.svgd_workspace(129, x)
+    ws = kernels.svgd_workspace(128, x)
+    with pytest.raises(SgmcmcLibraryError):
+        kernels.svgd_step(x, x.clone(), x.clone(), 129, 4, 0.1, 0.9, 1e-6, ws)
+    with pytest.raises(SgmcmcLibraryError):
+        kernels.svgd_step(x, x.clone(), x.clone(), 4, 4, 0.1, 0.9, 1e-6, ws, repulsion_sign=0)
+    with pytest.raises(SgmcmcLibraryError):
+        kernels.svgd_workspace(4, torch.zeros(4))                          # CPU tensor: no CPU path
+
+
+def test_svgd_sampler_on_gpu_fits_a_gaussian_and_reference_sign_collapses():
+    import pysgmcmc_amd.samplers.svgd as svgd_mod
+    from pysgmcmc_amd.sampling import Sampler
+    rng = np.random.RandomState(0)
+    x0 = rng.normal(size=(50, 2)) * 0.1 + 3.0
+    mu = torch.tensor([1.0, -2.0], device=DEV)
+
+    def cost(p):
+        return 0.5 * ((p - mu) ** 2 / torch.tensor([1.0, 4.0], device=DEV)).sum()
+
+    s = Sampler.get_sampler(Sampler.SVGD, particles=[torch.tensor(r, device=DEV) for r in x0], cost_fun=cost,
+                            dtype=torch.float32)
+    s.sample_format = "device"
+    for _ in range(600):
+        sample, costs = next(s)
+    P = torch.stack(sample).cpu().numpy()
+    assert costs.shape == (50,)
+    np.testing.assert_allclose(P.mean(axis=0), [1.0, -2.0], atol=0.15)
+    np.testing.assert_allclose(P.std(axis=0), [1.0, 2.0], rtol=0.3)
+    K, kg = s.svgd_kernel()
+    K_ref, kg_ref, _, _ = O.svgd_kernel(P.astype(np.float64))
+    np.testing.assert_allclose(K.cpu().numpy(), K_ref, rtol=1e-4, atol=1e-5)
+
+    svgd_mod.STRICT_REFERENCE_QUIRKS = True
+    try:
+        s = Sampler.get_sampler(Sampler.SVGD, particles=[torch.tensor(r, device=DEV) for r in x0], cost_fun=cost,
+                                dtype=torch.float32)
+    finally:
+        svgd_mod.STRICT_REFERENCE_QUIRKS = False
+    s.sample_format = "device"
+    for _ in range(600):
+        sample, _ = next(s)
+    assert torch.stack(sample).std(dim=0).max().item() < 0.3             # quirk Q10: the cloud collapses
