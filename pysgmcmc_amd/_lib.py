@@ -32,7 +32,7 @@ def build(force=False):
     stale = (not os.path.exists(_LIB_PATH)
              or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(d) for d in deps))
     if force or stale:
-        subprocess.check_call(["make", "-s", "-C", _CSRC, "libsgmcmc_hip.so"])
+        subprocess.check_call(["make", "-s", "-j4", "-C", _CSRC, "libsgmcmc_hip.so"])
     return _LIB_PATH
 
 

@@ -39,7 +39,7 @@ namespace {
 
 constexpr int SVGD_MAX_PARTICLES = 128;
 constexpr int SVGD_THREADS = 256;
-constexpr int SVGD_MAX_PARTS = 512;          // column-range workgroups of S1
+constexpr int SVGD_MAX_PARTS = 1024;         // column-range workgroups of S1
 constexpr int SVGD_TILE_BYTES = 32 * 1024;   // LDS tile of S1
 constexpr int SVGD_HDR = 16;                 // workspace header elements: median, h, h^2
 constexpr int SVGD_ITILE = 16;               // output rows per pass of S4
@@ -87,7 +87,8 @@ inline SvgdWs svgd_ws(int n) {
     w.D = off; off += (size_t)n * n; off = (off + 15) & ~(size_t)15;
     w.K = off; off += (size_t)g.np16 * g.np16;
     w.ksum = off; off += g.np16;
-    w.parts = off; off += (size_t)SVGD_MAX_PARTS * g.npb * 16;
+    const size_t per_part = (size_t)g.npb * 16 > 120 ? (size_t)g.npb * 16 : 120;   // S1 or S1s layout
+    w.parts = off; off += (size_t)SVGD_MAX_PARTS * per_part;
     w.total = off;
     return w;
 }
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_sqdist_kernel(const T *__re
     const int tc = 1 << tc_log2;
     const int t = threadIdx.x;
     const int S = (g.npb >= SVGD_THREADS) ? 1 : (SVGD_THREADS / g.npb);   // column slices per pair block
+    const bool vec4 = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & (4 * sizeof(T) - 1)) == 0);
 
     int bi[MAXPB], bj[MAXPB];
     bool have[MAXPB];
@@ -142,10 +144,48 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_sqdist_kernel(const T *__re
     const size_t n_tiles = (dim + (size_t)tc - 1) >> tc_log2;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t c0 = tile << tc_log2;
-        for (int idx = t; idx < (n << tc_log2); idx += SVGD_THREADS) {
-            const int i = idx >> tc_log2, c = idx & (tc - 1);
-            const size_t col = c0 + (size_t)c;
-            xs[c * NP + i] = (col < dim) ? X[(size_t)i * ld + col] : (T)0;
+        if (vec4 && c0 + (size_t)tc <= dim) {
+            // interior tile, rows 4-element aligned: one 4-wide load per lane, 4 in flight
+            const int q_log2 = tc_log2 - 2, total = n << q_log2;
+            for (int base = 0; base < total; base += SVGD_THREADS * 4) {
+                Vec4<T> v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = base + u * SVGD_THREADS + t;
+                    if (idx < total) {
+                        const int i = idx >> q_log2, cq = idx & ((1 << q_log2) - 1);
+                        v[u] = *reinterpret_cast<const Vec4<T> *>(X + (size_t)i * ld + c0 + 4 * (size_t)cq);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = base + u * SVGD_THREADS + t;
+                    if (idx < total) {
+                        const int i = idx >> q_log2, cq = idx & ((1 << q_log2) - 1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xs[(4 * cq + e) * NP + i] = v[u].v[e];
+                    }
+                }
+            }
+        } else {
+            const int total = n << tc_log2;
+            for (int base = 0; base < total; base += SVGD_THREADS * 8) {
+                T v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * SVGD_THREADS + t;
+                    v[u] = (T)0;
+                    if (idx < total) {
+                        const size_t col = c0 + (size_t)(idx & (tc - 1));
+                        if (col < dim) v[u] = X[(size_t)(idx >> tc_log2) * ld + col];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * SVGD_THREADS + t;
+                    if (idx < total) xs[(idx & (tc - 1)) * NP + (idx >> tc_log2)] = v[u];
+                }
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -194,14 +234,36 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_sqdist_kernel(const T *__re
 // ---------------------------------------------------------------------------------------------
 // S2: D[i][j] = (sqrt(sum_parts))^2, symmetric, zero diagonal
 // ---------------------------------------------------------------------------------------------
+// 64 outputs x 16 part-slices per workgroup: every lane adds its slice of the partials (independent loads),
+// the slices are then added in slice order -- a fixed summation tree, bit-reproducible.
+constexpr int SVGD_RED_SLICES = 16;
+
 template <typename T>
-__global__ __launch_bounds__(SVGD_THREADS) void svgd_reduce_kernel(const T *__restrict__ parts, int n_parts, int n,
-                                                                    T *__restrict__ D) {
-    const SvgdGeom g = svgd_geom(n);
-    const int idx = blockIdx.x * SVGD_THREADS + threadIdx.x;
-    if (idx >= g.npb * 16) return;
+__device__ __forceinline__ bool reduce_parts(const T *__restrict__ parts, int n_parts, int n_out, T &total, int &idx) {
+    __shared__ T red[SVGD_RED_SLICES][64];
+    const int l = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    idx = blockIdx.x * 64 + l;
     T s = (T)0;
-    for (int p = 0; p < n_parts; ++p) s += parts[(size_t)p * g.npb * 16 + idx];
+    if (idx < n_out) {
+#pragma unroll 4
+        for (int q = slice; q < n_parts; q += SVGD_RED_SLICES) s += parts[(size_t)q * n_out + idx];
+    }
+    red[slice][l] = s;
+    __syncthreads();
+    if (slice != 0 || idx >= n_out) return false;
+    total = red[0][l];
+#pragma unroll
+    for (int k = 1; k < SVGD_RED_SLICES; ++k) total += red[k][l];
+    return true;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64 * SVGD_RED_SLICES) void svgd_reduce_kernel(const T *__restrict__ parts, int n_parts,
+                                                                            int n, T *__restrict__ D) {
+    const SvgdGeom g = svgd_geom(n);
+    T s;
+    int idx;
+    if (!reduce_parts(parts, n_parts, g.npb * 16, s, idx)) return;
     int bi, bj;
     decode_pair_block(idx >> 4, g.nb, bi, bj);
     const int i = 4 * bi + ((idx & 15) >> 2), j = 4 * bj + (idx & 3);
@@ -228,9 +290,11 @@ template <> struct KeyOf<double> {
 };
 
 // value of rank `rank` (0-based, ascending) among the N non-negative values v[]: most significant
-// byte first, 256-bin LDS histogram per pass (non-negative IEEE values order like their bit patterns)
+// byte first, 256-bin LDS histogram per pass (non-negative IEEE values order like their bit patterns);
+// the digit is located by wave 0 with a shuffle scan over 4 bins per lane
 template <typename T>
-__device__ T radix_select(const T *__restrict__ v, int N, int rank, unsigned int *hist, unsigned long long *bcast) {
+__device__ typename KeyOf<T>::type radix_select(const T *__restrict__ v, int N, int rank, unsigned int *hist,
+                                                unsigned long long *bcast) {
     using Key = typename KeyOf<T>::type;
     Key prefix = 0, mask = 0;
     int remaining = rank;
@@ -242,41 +306,67 @@ __device__ T radix_select(const T *__restrict__ v, int N, int rank, unsigned int
             if ((k & mask) == prefix) atomicAdd(&hist[(unsigned)((k >> shift) & (Key)255)], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int cum = 0, digit = 255;
-            for (int b = 0; b < 256; ++b) {
-                const int h = (int)hist[b];
-                if (cum + h > remaining) { digit = b; break; }
-                cum += h;
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            const int h0 = (int)hist[4 * l], h1 = (int)hist[4 * l + 1], h2 = (int)hist[4 * l + 2], h3 = (int)hist[4 * l + 3];
+            const int mine = h0 + h1 + h2 + h3;
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off, 64);
+                if (l >= off) incl += up;
             }
-            bcast[0] = (unsigned long long)digit;
-            bcast[1] = (unsigned long long)cum;
+            int cum = incl - mine;                       // entries in bins below 4l
+            if (cum <= remaining && remaining < incl) {  // exactly one lane
+                int digit = 4 * l;
+                if (remaining >= cum + h0) { cum += h0; ++digit;
+                    if (remaining >= cum + h1) { cum += h1; ++digit;
+                        if (remaining >= cum + h2) { cum += h2; ++digit; } } }
+                bcast[0] = (unsigned long long)digit;
+                bcast[1] = (unsigned long long)cum;
+            }
         }
         __syncthreads();
         const Key digit = (Key)bcast[0];
         remaining -= (int)bcast[1];
         prefix |= digit << shift;
         mask |= (Key)255 << shift;
-        __syncthreads();
     }
-    return KeyOf<T>::value(prefix);
+    return prefix;
 }
 
 template <typename T>
-__global__ __launch_bounds__(1024) void svgd_bandwidth_kernel(const T *__restrict__ D, int n, T *__restrict__ hdr,
-                                                               T *__restrict__ K, T *__restrict__ ksum) {
+__global__ __launch_bounds__(512) void svgd_bandwidth_kernel(const T *__restrict__ D, int n, T *__restrict__ hdr,
+                                                              T *__restrict__ K, T *__restrict__ ksum) {
+    using Key = typename KeyOf<T>::type;
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long bcast[2];
+    __shared__ unsigned long long next_key;
+    __shared__ unsigned int count_le;
     const SvgdGeom g = svgd_geom(n);
     const int N = n * n;
     const int mid = N / 2;
     T med;
     if (N & 1) {
-        med = radix_select(D, N, mid, hist, bcast);                     // tensor_utils.py:205-206
+        med = KeyOf<T>::value(radix_select(D, N, mid, hist, bcast));    // tensor_utils.py:205-206
     } else {
-        const T lo = radix_select(D, N, mid - 1, hist, bcast);
-        const T hi = radix_select(D, N, mid, hist, bcast);
-        med = (lo + hi) / (T)2;                                         // tensor_utils.py:208
+        // the two middle values: rank mid-1 by radix select, rank mid = the same value if it repeats,
+        // else the smallest larger entry
+        const Key lo = radix_select(D, N, mid - 1, hist, bcast);
+        if (threadIdx.x == 0) { next_key = ~0ull; count_le = 0u; }
+        __syncthreads();
+        unsigned int c_le = 0;
+        unsigned long long mn = ~0ull;
+        for (int idx = threadIdx.x; idx < N; idx += blockDim.x) {
+            const Key k = KeyOf<T>::bits(D[idx]);
+            if (k <= lo) ++c_le;
+            else if ((unsigned long long)k < mn) mn = (unsigned long long)k;
+        }
+        atomicAdd(&count_le, c_le);
+        atomicMin(&next_key, mn);
+        __syncthreads();
+        const Key hi = ((int)count_le > mid) ? lo : (Key)next_key;
+        med = (KeyOf<T>::value(lo) + KeyOf<T>::value(hi)) / (T)2;       // tensor_utils.py:208
     }
     const T h = sqrt_t((T)0.5 * med / log_t((T)n + (T)1));              // svgd.py:169-171
     const T h2 = h * h;
@@ -360,6 +450,274 @@ __global__ __launch_bounds__(SVGD_UCOLS) void svgd_update_kernel(T *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// n <= 16: the memory-bound regime (a few particles of a large model). No LDS tiles: a lane owns CPL
+// adjacent columns (one 8/16-byte access per row), keeps every particle's values in registers, and
+//   S1s accumulates all n (n - 1) / 2 squared differences per lane, reduced once per workgroup;
+//   S4s forms A = K G, B = K X for its columns with K rows as scalar operands, then the element-wise tail.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NPAD, int CPL>
+__device__ __forceinline__ void load_rows(const T *__restrict__ A, size_t ld, size_t c, size_t dim, int n, bool vec,
+                                          T (&out)[NPAD][CPL]) {
+#pragma unroll
+    for (int j = 0; j < NPAD; ++j) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) out[j][k] = (T)0;
+        if (j < n) {
+            if (vec) {
+                // the address is made opaque so the compiler cannot merge this access with the element-wise
+                // path below and split it into a 1-wide plus a 3-wide access
+                const T *pa = A + (size_t)j * ld + c;
+                asm volatile("" : "+v"(pa));
+                typedef T VecT __attribute__((ext_vector_type(CPL)));
+                typedef const __attribute__((address_space(1))) VecT *GlobalVecPtr;   // global_load, not flat
+                const VecT v = *(GlobalVecPtr)(reinterpret_cast<const VecT *>(pa));
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) out[j][k] = v[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < CPL; ++k)
+                    if (c + k < dim) out[j][k] = A[(size_t)j * ld + c + k];
+            }
+        }
+    }
+}
+
+template <typename T, int NPAD, int CPL>
+__device__ __forceinline__ void store_rows(T *__restrict__ A, size_t ld, size_t c, size_t dim, int n, bool vec,
+                                           const T (&in)[NPAD][CPL]) {
+#pragma unroll
+    for (int j = 0; j < NPAD; ++j) {
+        if (j < n) {
+            if (vec) {
+                typedef T VecT __attribute__((ext_vector_type(CPL)));
+                typedef __attribute__((address_space(1))) VecT *GlobalVecPtr;
+                VecT v;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) v[k] = in[j][k];
+                T *pa = A + (size_t)j * ld + c;
+                asm volatile("" : "+v"(pa));
+                *(GlobalVecPtr)(reinterpret_cast<VecT *>(pa)) = v;
+            } else {
+#pragma unroll
+                for (int k = 0; k < CPL; ++k)
+                    if (c + k < dim) A[(size_t)j * ld + c + k] = in[j][k];
+            }
+        }
+    }
+}
+
+template <typename T, int NPAD, int CPL>
+__global__ __launch_bounds__(SVGD_THREADS) void svgd_sqdist_small_kernel(const T *__restrict__ X, size_t dim, size_t ld,
+                                                                          int n, T *__restrict__ parts) {
+    constexpr int NPAIR = NPAD * (NPAD - 1) / 2;
+    __shared__ T red[SVGD_THREADS / 64][NPAIR];
+    const bool aligned = (ld % CPL == 0) && ((reinterpret_cast<uintptr_t>(X) & (CPL * sizeof(T) - 1)) == 0);
+    T acc[NPAIR];
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) acc[p] = (T)0;
+    const size_t chunks = (dim + CPL - 1) / CPL;
+    for (size_t q = (size_t)blockIdx.x * SVGD_THREADS + threadIdx.x; q < chunks; q += (size_t)gridDim.x * SVGD_THREADS) {
+        const size_t c = q * CPL;
+        T xv[NPAD][CPL];
+        load_rows<T, NPAD, CPL>(X, ld, c, dim, n, aligned && c + CPL <= dim, xv);
+        int p = 0;
+#pragma unroll
+        for (int i = 0; i < NPAD; ++i)
+#pragma unroll
+            for (int j = i + 1; j < NPAD; ++j, ++p) {
+                if (j < n) {
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) {
+                        const T d = xv[i][k] - xv[j][k];
+                        acc[p] = fma_t(d, d, acc[p]);
+                    }
+                }
+            }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+        T v = acc[p];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[wave][p] = v;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < NPAIR; p += SVGD_THREADS) {
+        T v = red[0][p];
+#pragma unroll
+        for (int w = 1; w < SVGD_THREADS / 64; ++w) v += red[w][p];
+        parts[(size_t)blockIdx.x * NPAIR + p] = v;
+    }
+}
+
+// S2 for the dense pair layout of S1s
+template <typename T, int NPAD>
+__global__ __launch_bounds__(64 * SVGD_RED_SLICES) void svgd_reduce_small_kernel(const T *__restrict__ parts,
+                                                                                  int n_parts, int n,
+                                                                                  T *__restrict__ D) {
+    constexpr int NPAIR = NPAD * (NPAD - 1) / 2;
+    T s;
+    int p;
+    if (blockIdx.x == 0 && threadIdx.x < n) D[(size_t)threadIdx.x * n + threadIdx.x] = (T)0;
+    if (!reduce_parts(parts, n_parts, NPAIR, s, p)) return;
+    int i = 0, rem = p;                            // p = i * NPAD - i (i + 1) / 2 + (j - i - 1)
+    while (rem >= NPAD - 1 - i) { rem -= NPAD - 1 - i; ++i; }
+    const int j = i + 1 + rem;
+    if (j >= n) return;
+    const T dist = sqrt_t(s);                      // tf.norm, tensor_utils.py:399
+    const T sq = dist * dist;                      // `** 2`, svgd.py:166
+    D[(size_t)i * n + j] = sq;
+    D[(size_t)j * n + i] = sq;
+}
+
+template <typename T, int NPAD, int CPL, bool UPDATE>
+__global__ __launch_bounds__(SVGD_THREADS) void svgd_update_small_kernel(T *__restrict__ X, const T *__restrict__ G,
+                                                                          T *__restrict__ H, T *__restrict__ kgrad_out,
+                                                                          size_t dim, size_t ld, size_t out_ld, int n,
+                                                                          const T *__restrict__ hdr,
+                                                                          const T *__restrict__ K,
+                                                                          const T *__restrict__ ksum, T eps, T alpha,
+                                                                          T one_minus_alpha, T fudge, T sign) {
+    const SvgdGeom g = svgd_geom(n);
+    const T h2 = hdr[2];
+    const T n_t = (T)n;
+    const size_t c = ((size_t)blockIdx.x * SVGD_THREADS + threadIdx.x) * CPL;
+    if (c >= dim) return;
+    const bool full = c + CPL <= dim;
+    const bool vec = full && (ld % CPL == 0) && ((reinterpret_cast<uintptr_t>(X) & (CPL * sizeof(T) - 1)) == 0) &&
+                     (!UPDATE || (((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(H)) &
+                                   (CPL * sizeof(T) - 1)) == 0));
+    const bool vec_out = full && (out_ld % CPL == 0) &&
+                         ((reinterpret_cast<uintptr_t>(kgrad_out) & (CPL * sizeof(T) - 1)) == 0);
+    T xv[NPAD][CPL], gv[NPAD][CPL], hv[NPAD][CPL];
+    load_rows<T, NPAD, CPL>(X, ld, c, dim, n, vec, xv);
+    if (UPDATE) {
+        load_rows<T, NPAD, CPL>(G, ld, c, dim, n, vec, gv);
+        load_rows<T, NPAD, CPL>(H, ld, c, dim, n, vec, hv);
+    }
+    T ks[NPAD];
+#pragma unroll
+    for (int i = 0; i < NPAD; ++i) ks[i] = ksum[i];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        T accg[NPAD], accx[NPAD];
+#pragma unroll
+        for (int i = 0; i < NPAD; ++i) { accg[i] = (T)0; accx[i] = (T)0; }
+        // rows n..15 of K are zero: no guard, the scalar loads stream ahead of the FMAs
+#pragma unroll
+        for (int j = 0; j < NPAD; ++j) {
+            const T *krow = K + (size_t)j * g.np16;                  // K symmetric: row j, columns 0..NPAD-1
+#pragma unroll
+            for (int i = 0; i < NPAD; ++i) {
+                const T kij = krow[i];
+                accx[i] = fma_t(kij, xv[j][k], accx[i]);
+                if (UPDATE) accg[i] = fma_t(kij, gv[j][k], accg[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NPAD; ++i) {
+            const T x = xv[i][k];
+            const T kg = (-accx[i] + x * ks[i]) / h2;                        // svgd.py:176-181
+            if (UPDATE) {
+                const T gt = (accg[i] + sign * kg) / n_t;                    // svgd.py:124-127
+                const T hnew = alpha * hv[i][k] + one_minus_alpha * (gt * gt);   // svgd.py:129-132
+                const T adj = gt / (fudge + sqrt_t(hnew));                   // svgd.py:134-137
+                hv[i][k] = hnew;
+                gv[i][k] = x - eps * adj;                                    // svgd.py:139-143 (gv is free now)
+            } else {
+                gv[i][k] = kg;
+            }
+        }
+    }
+    if (UPDATE) {
+        store_rows<T, NPAD, CPL>(X, ld, c, dim, n, vec, gv);
+        store_rows<T, NPAD, CPL>(H, ld, c, dim, n, vec, hv);
+    } else {
+        store_rows<T, NPAD, CPL>(kgrad_out, out_ld, c, dim, n, vec_out, gv);
+    }
+}
+
+// S4 for n <= NPAD <= 64: no LDS. A lane owns ONE column and keeps {G[j][c], X[j][c]} of all particles in
+// registers (2 NPAD VGPRs, all loads in flight at once); every output row costs n packed FMAs
+// {A_i, B_i} += K[i][j] * {g_j, x_j} (v_pk_fma_f32: fp32 VALU at the MFMA rate) with K[i][j] a scalar operand.
+template <typename T> using Pair = T __attribute__((ext_vector_type(2)));
+
+template <typename T, int NPAD, bool UPDATE>
+__global__ __launch_bounds__(SVGD_THREADS) void svgd_update_reg_kernel(T *__restrict__ X, const T *__restrict__ G,
+                                                                        T *__restrict__ H, T *__restrict__ kgrad_out,
+                                                                        size_t dim, size_t ld, size_t out_ld, int n,
+                                                                        const T *__restrict__ hdr,
+                                                                        const T *__restrict__ K,
+                                                                        const T *__restrict__ ksum, T eps, T alpha,
+                                                                        T one_minus_alpha, T fudge, T sign) {
+    const SvgdGeom g = svgd_geom(n);
+    const T h2 = hdr[2];
+    const T n_t = (T)n;
+    const size_t c = (size_t)blockIdx.x * SVGD_THREADS + threadIdx.x;
+    if (c >= dim) return;
+    Pair<T> m[NPAD];
+#pragma unroll
+    for (int j = 0; j < NPAD; ++j) {
+        m[j] = Pair<T>{(T)0, (T)0};
+        if (j < n) {
+            m[j].y = X[(size_t)j * ld + c];
+            if (UPDATE) m[j].x = G[(size_t)j * ld + c];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NPAD / SVGD_ITILE; ++it) {
+        const int i0 = it * SVGD_ITILE;
+        if (i0 >= n) break;
+        T hold[SVGD_ITILE];
+        if (UPDATE) {
+#pragma unroll
+            for (int a = 0; a < SVGD_ITILE; ++a) hold[a] = (i0 + a < n) ? H[(size_t)(i0 + a) * ld + c] : (T)0;
+        }
+        Pair<T> acc[SVGD_ITILE];
+#pragma unroll
+        for (int a = 0; a < SVGD_ITILE; ++a) acc[a] = Pair<T>{(T)0, (T)0};
+        // rows n..np16-1 of K are zero, so a group of 16 j needs no per-row guard (the scalar loads of the
+        // next rows are issued under the FMAs of the current one); at NPAD = 64 that schedule spills, so
+        // rows are guarded one by one there
+#pragma unroll
+        for (int jg = 0; jg < NPAD / 16; ++jg) {
+            if (16 * jg >= n) break;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = 16 * jg + jj;
+                if (NPAD <= 32 || j < n) {
+                    const T *krow = K + (size_t)j * g.np16 + i0;   // K symmetric: row j, columns i0..i0+15
+#pragma unroll
+                    for (int a = 0; a < SVGD_ITILE; ++a) {
+                        const T k = krow[a];
+                        acc[a] = __builtin_elementwise_fma(Pair<T>{k, k}, m[j], acc[a]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < SVGD_ITILE; ++a) {
+            const int i = i0 + a;
+            if (i < n) {
+                const T x = m[i0 + a].y;
+                const T kg = (-acc[a].y + x * ksum[i]) / h2;                 // svgd.py:176-181
+                if (UPDATE) {
+                    const size_t at = (size_t)i * ld + c;
+                    const T gt = (acc[a].x + sign * kg) / n_t;               // svgd.py:124-127
+                    const T hnew = alpha * hold[a] + one_minus_alpha * (gt * gt);    // svgd.py:129-132
+                    const T adj = gt / (fudge + sqrt_t(hnew));               // svgd.py:134-137
+                    H[at] = hnew;
+                    X[at] = x - eps * adj;                                   // svgd.py:139-143
+                } else {
+                    kgrad_out[(size_t)i * out_ld + c] = kg;
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ void svgd_copy_kernel(const T *__restrict__ K, int n, int np16, T *__restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -374,45 +732,110 @@ int svgd_check(const void *X, size_t n, size_t dim, size_t ld, const void *ws, c
     return 0;
 }
 
+template <typename T> struct SmallCfg {                    // columns per lane of the n <= 16 kernels
+    static constexpr int CPL8 = 16 / sizeof(T);            // 16-byte accesses
+    static constexpr int CPL16 = 8 / sizeof(T);            // 8-byte accesses (register budget)
+};
+
+template <typename T, int NPAD, int CPL>
+int svgd_sqdist_small(const T *X, size_t n, size_t dim, size_t ld, T *parts, T *D, hipStream_t st) {
+    const size_t chunks = (dim + CPL - 1) / CPL;
+    const size_t blocks = (chunks + SVGD_THREADS - 1) / SVGD_THREADS;
+    const int n_parts = (int)(blocks < (size_t)SVGD_MAX_PARTS ? blocks : (size_t)SVGD_MAX_PARTS);
+    hipLaunchKernelGGL((svgd_sqdist_small_kernel<T, NPAD, CPL>), dim3(n_parts), dim3(SVGD_THREADS), 0, st, X, dim, ld,
+                       (int)n, parts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch svgd_sqdist_small_kernel");
+    constexpr int NPAIR = NPAD * (NPAD - 1) / 2;
+    hipLaunchKernelGGL((svgd_reduce_small_kernel<T, NPAD>), dim3((NPAIR + 63) / 64), dim3(64 * SVGD_RED_SLICES), 0, st,
+                       parts, n_parts, (int)n, D);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_reduce_small_kernel");
+}
+
 template <typename T>
 int svgd_kernel_matrix_impl(const T *X, size_t n, size_t dim, size_t ld, T *ws, hipStream_t st) {
     const SvgdGeom g = svgd_geom((int)n);
     const SvgdWs w = svgd_ws((int)n);
-    const int NP = g.np + 4;
-    int tc_log2 = 4;
-    while (tc_log2 < 10 && (size_t)(2 << tc_log2) * NP * sizeof(T) <= (size_t)SVGD_TILE_BYTES) ++tc_log2;
-    const size_t tc = (size_t)1 << tc_log2;
-    size_t lds_elems = tc * NP;
-    if (lds_elems < 4096) lds_elems = 4096;                 // slice-reduction scratch
-    const size_t n_tiles = (dim + tc - 1) / tc;
-    const int n_parts = (int)(n_tiles < (size_t)SVGD_MAX_PARTS ? n_tiles : (size_t)SVGD_MAX_PARTS);
     T *parts = ws + w.parts;
-    const size_t lds_bytes = lds_elems * sizeof(T);
-    if (g.npb <= SVGD_THREADS)
-        hipLaunchKernelGGL((svgd_sqdist_kernel<T, 1>), dim3(n_parts), dim3(SVGD_THREADS), lds_bytes, st, X, dim, ld,
-                           (int)n, tc_log2, parts);
-    else if (g.npb <= 2 * SVGD_THREADS)
-        hipLaunchKernelGGL((svgd_sqdist_kernel<T, 2>), dim3(n_parts), dim3(SVGD_THREADS), lds_bytes, st, X, dim, ld,
-                           (int)n, tc_log2, parts);
-    else
-        hipLaunchKernelGGL((svgd_sqdist_kernel<T, 3>), dim3(n_parts), dim3(SVGD_THREADS), lds_bytes, st, X, dim, ld,
-                           (int)n, tc_log2, parts);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "launch svgd_sqdist_kernel");
-    const int red_blocks = (g.npb * 16 + SVGD_THREADS - 1) / SVGD_THREADS;
-    hipLaunchKernelGGL((svgd_reduce_kernel<T>), dim3(red_blocks), dim3(SVGD_THREADS), 0, st, parts, n_parts, (int)n,
-                       ws + w.D);
-    e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "launch svgd_reduce_kernel");
-    hipLaunchKernelGGL((svgd_bandwidth_kernel<T>), dim3(1), dim3(1024), 0, st, ws + w.D, (int)n, ws + w.hdr, ws + w.K,
+    hipError_t e;
+    if (n <= 16) {
+        const int rc = (n <= 8) ? svgd_sqdist_small<T, 8, SmallCfg<T>::CPL8>(X, n, dim, ld, parts, ws + w.D, st)
+                                : svgd_sqdist_small<T, 16, SmallCfg<T>::CPL16>(X, n, dim, ld, parts, ws + w.D, st);
+        if (rc) return rc;
+    } else {
+        const int NP = g.np + 4;
+        int tc_log2 = 4;
+        while (tc_log2 < 10 && (size_t)(2 << tc_log2) * NP * sizeof(T) <= (size_t)SVGD_TILE_BYTES) ++tc_log2;
+        const size_t tc = (size_t)1 << tc_log2;
+        size_t lds_elems = tc * NP;
+        if (lds_elems < 4096) lds_elems = 4096;                 // slice-reduction scratch
+        const size_t n_tiles = (dim + tc - 1) / tc;
+        const int n_parts = (int)(n_tiles < (size_t)SVGD_MAX_PARTS ? n_tiles : (size_t)SVGD_MAX_PARTS);
+        const size_t lds_bytes = lds_elems * sizeof(T);
+        if (g.npb <= SVGD_THREADS)
+            hipLaunchKernelGGL((svgd_sqdist_kernel<T, 1>), dim3(n_parts), dim3(SVGD_THREADS), lds_bytes, st, X, dim, ld,
+                               (int)n, tc_log2, parts);
+        else if (g.npb <= 2 * SVGD_THREADS)
+            hipLaunchKernelGGL((svgd_sqdist_kernel<T, 2>), dim3(n_parts), dim3(SVGD_THREADS), lds_bytes, st, X, dim, ld,
+                               (int)n, tc_log2, parts);
+        else
+            hipLaunchKernelGGL((svgd_sqdist_kernel<T, 3>), dim3(n_parts), dim3(SVGD_THREADS), lds_bytes, st, X, dim, ld,
+                               (int)n, tc_log2, parts);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "launch svgd_sqdist_kernel");
+        const int red_blocks = (g.npb * 16 + 63) / 64;
+        hipLaunchKernelGGL((svgd_reduce_kernel<T>), dim3(red_blocks), dim3(64 * SVGD_RED_SLICES), 0, st, parts, n_parts,
+                           (int)n, ws + w.D);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "launch svgd_reduce_kernel");
+    }
+    hipLaunchKernelGGL((svgd_bandwidth_kernel<T>), dim3(1), dim3(512), 0, st, ws + w.D, (int)n, ws + w.hdr, ws + w.K,
                        ws + w.ksum);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_bandwidth_kernel");
 }
 
+template <typename T, int NPAD, int CPL, bool UPDATE>
+int svgd_apply_small(T *X, const T *G, T *H, T *kgrad_out, size_t out_ld, size_t n, size_t dim, size_t ld, T eps,
+                     double alpha, T fudge, T sign, const T *ws, hipStream_t st) {
+    const SvgdWs w = svgd_ws((int)n);
+    const size_t chunks = (dim + CPL - 1) / CPL;
+    const size_t blocks = (chunks + SVGD_THREADS - 1) / SVGD_THREADS;
+    if (blocks > 0x7fffffffull) return fail(SGMCMC_EINVAL, "sgmcmc_svgd: dim too large");
+    hipLaunchKernelGGL((svgd_update_small_kernel<T, NPAD, CPL, UPDATE>), dim3((unsigned)blocks), dim3(SVGD_THREADS), 0, st,
+                       X, G, H, kgrad_out, dim, ld, out_ld, (int)n, ws + w.hdr, ws + w.K, ws + w.ksum, eps, (T)alpha,
+                       (T)(1.0 - alpha), fudge, sign);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_update_small_kernel");
+}
+
+template <typename T, int NPAD, bool UPDATE>
+int svgd_apply_reg(T *X, const T *G, T *H, T *kgrad_out, size_t out_ld, size_t n, size_t dim, size_t ld, T eps,
+                   double alpha, T fudge, T sign, const T *ws, hipStream_t st) {
+    const SvgdWs w = svgd_ws((int)n);
+    const size_t blocks = (dim + SVGD_THREADS - 1) / SVGD_THREADS;
+    if (blocks > 0x7fffffffull) return fail(SGMCMC_EINVAL, "sgmcmc_svgd: dim too large");
+    hipLaunchKernelGGL((svgd_update_reg_kernel<T, NPAD, UPDATE>), dim3((unsigned)blocks), dim3(SVGD_THREADS), 0, st, X, G,
+                       H, kgrad_out, dim, ld, out_ld, (int)n, ws + w.hdr, ws + w.K, ws + w.ksum, eps, (T)alpha,
+                       (T)(1.0 - alpha), fudge, sign);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_update_reg_kernel");
+}
+
 template <typename T, bool UPDATE>
 int svgd_apply_impl(T *X, const T *G, T *H, T *kgrad_out, size_t out_ld, size_t n, size_t dim, size_t ld, T eps,
                     double alpha, T fudge, T sign, const T *ws, hipStream_t st) {
+    if (n <= 8)
+        return svgd_apply_small<T, 8, SmallCfg<T>::CPL8, UPDATE>(X, G, H, kgrad_out, out_ld, n, dim, ld, eps, alpha, fudge,
+                                                                 sign, ws, st);
+    if (n <= 16)
+        return svgd_apply_small<T, 16, SmallCfg<T>::CPL16, UPDATE>(X, G, H, kgrad_out, out_ld, n, dim, ld, eps, alpha,
+                                                                   fudge, sign, ws, st);
+    if (n <= 32)
+        return svgd_apply_reg<T, 32, UPDATE>(X, G, H, kgrad_out, out_ld, n, dim, ld, eps, alpha, fudge, sign, ws, st);
+    if (n <= 64 && sizeof(T) == 4)                              // 64 f64 pairs would not fit the register file
+        return svgd_apply_reg<T, 64, UPDATE>(X, G, H, kgrad_out, out_ld, n, dim, ld, eps, alpha, fudge, sign, ws, st);
     const SvgdWs w = svgd_ws((int)n);
     const size_t lds_bytes = (size_t)2 * n * SVGD_UCOLS * sizeof(T);
     if (lds_bytes > 64 * 1024) {
