@@ -17,6 +17,10 @@ Sources of truth
         pysgmcmc/data_batches.py:118, gradients by torch-CPU fp64 autograd of the
         NLL restated from pysgmcmc/models/bayesian_neural_network.py:365-388,
         update by the numpy oracle.
+  * svgd.npz .............. SVGD particle trajectories (pysgmcmc/samplers/svgd.py:118-181) from the numpy
+        restatement oracle/sgmcmc_oracle.py:svgd_step on the reference's toy targets (banana, 3-mode
+        mixture), both signs of the kernel-gradient term (+1 = the reference as written), f32 and f64;
+        plus kernel matrix, kernel gradients and bandwidth of the initial particles. Oracle-pinned only.
 """
 import os
 import sys
@@ -194,6 +198,37 @@ def make_bnn_trajectory():
     print("bnn_trajectory.npz: %d params x %d steps" % (theta0.size, n_steps))
 
 
+def make_svgd():
+    out = {}
+    cases = []
+    rng = np.random.default_rng(2024)
+    for target, n, d, steps in (("banana", 10, 2, 30), ("gmm1", 20, 1, 30)):
+        x0 = rng.normal(size=(n, d)) * 0.5 + (np.array([0.0, 6.0]) if target == "banana" else 0.0)
+        cost_grad = O.banana_cost_grad if target == "banana" else O.gmm_cost_grad
+        for dt in (np.float32, np.float64):
+            for sign in (1, -1):
+                key = "%s|%d|%s|%d" % (target, n, np.dtype(dt).name, sign)
+                cases.append(key)
+                X = x0.astype(dt)
+                H = np.zeros_like(X)
+                K, kg, h, D = O.svgd_kernel(X)
+                out[key + "|x0"] = X.copy()
+                out[key + "|K0"], out[key + "|kgrad0"] = K, kg
+                out[key + "|bw0"] = np.array([O.svgd_median(D), h, h * h], dt)
+                traj, grads = [], []
+                for t in range(steps):
+                    G = np.stack([np.asarray(cost_grad(x.astype(np.float64))[1], np.float64).reshape(d) for x in X]).astype(dt)
+                    grads.append(G)
+                    O.svgd_step(X, G, H, 0.1, 0.9, 1e-6, float(sign))
+                    traj.append(X.copy())
+                out[key + "|grad"] = np.stack(grads)
+                out[key + "|x"] = np.stack(traj)
+                out[key + "|hist"] = H.copy()
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "svgd.npz"), **out)
+    print("svgd.npz: %d cases" % len(cases))
+
+
 if __name__ == "__main__":
     if os.path.isdir(REF_PRIORS):
         make_priors()
@@ -201,3 +236,4 @@ if __name__ == "__main__":
         print("reference not mounted: keeping committed bnn_priors.npz")
     make_trajectories()
     make_bnn_trajectory()
+    make_svgd()

@@ -186,3 +186,38 @@ def test_welford_and_rhat_formulas(oracle):
     for t in range(1, 2000):
         ar[:, t] = 0.9 * ar[:, t - 1] + rng.normal(size=4)
     assert oracle.effective_n(ar) < 1200          # ~ 8000 * (1-0.9)/(1+0.9) = 421
+
+
+def test_svgd_oracle_known_answers_and_golden(oracle):
+    """SVGD restatement (pysgmcmc/samplers/svgd.py): the reference's doctest answers for `median`
+    (tensor_utils.py:183-194) and `pdist`/`squareform` (tensor_utils.py:352-364,442-451: equal to scipy's),
+    structural properties of the kernel, and the committed trajectories."""
+    from scipy.spatial.distance import pdist, squareform
+    assert oracle.svgd_median(np.array([1., 3., 5.])) == 3.0
+    assert oracle.svgd_median(np.array([1., 3., 5., 7.])) == 4.0
+    X = np.array([[0.77228064, 0.09543156], [0.3918973, 0.96806584], [0.66008144, 0.22163063]])
+    np.testing.assert_allclose(oracle.svgd_pairwise_sqdist(X), squareform(pdist(X)) ** 2, rtol=1e-14)
+    K, kg, h, D = oracle.svgd_kernel(X)
+    assert np.array_equal(K, K.T) and np.all(np.diag(K) == 1)
+    np.testing.assert_allclose(h, np.sqrt(0.5 * np.median(D) / np.log(4.0)), rtol=1e-15)
+    # kernel gradients are sum_j K_ij (x_i - x_j) / h^2
+    ref = np.stack([sum(K[i, j] * (X[i] - X[j]) for j in range(3)) for i in range(3)]) / h ** 2
+    np.testing.assert_allclose(kg, ref, rtol=1e-12, atol=1e-14)
+    d = np.load(os.path.join(GOLDEN, "svgd.npz"))
+    for key in d["cases"]:
+        key = str(key)
+        target, n, dtname, sign = key.split("|")
+        dt = np.dtype(dtname)
+        Xc, H = d[key + "|x0"].copy(), np.zeros_like(d[key + "|x0"])
+        assert Xc.dtype == dt
+        tol = 1e-5 if dt == np.float32 else 1e-12          # BLAS summation order may differ between hosts
+        K0, kg0, h0, D0 = oracle.svgd_kernel(Xc)
+        np.testing.assert_allclose(K0, d[key + "|K0"], rtol=tol, atol=tol)
+        np.testing.assert_allclose(h0, d[key + "|bw0"][1], rtol=tol)
+        for t in range(d[key + "|x"].shape[0]):
+            oracle.svgd_step(Xc, d[key + "|grad"][t], H, 0.1, 0.9, 1e-6, float(sign))
+            np.testing.assert_allclose(Xc, d[key + "|x"][t], rtol=100 * tol, atol=100 * tol)
+            Xc[...] = d[key + "|x"][t]                      # re-anchor: one-step pins, no drift
+        # the reference's sign contracts the cloud, the repulsive sign keeps it spread
+    spread = {s: d["banana|10|float64|%d|x" % s][-1].std(axis=0).max() for s in (1, -1)}
+    assert spread[1] < spread[-1]

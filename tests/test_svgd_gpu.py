@@ -206,3 +206,34 @@ def test_svgd_sampler_on_gpu_fits_a_gaussian_and_reference_sign_collapses():
     for _ in range(600):
         sample, _ = next(s)
     assert torch.stack(sample).std(dim=0).max().item() < 0.3             # quirk Q10: the cloud collapses
+
+
+def test_svgd_golden_trajectories():
+    """Committed oracle trajectories (tests/golden/svgd.npz: banana and 3-mode mixture, both signs, f32/f64):
+    every step is replayed from the fixture's state with the fixture's gradients."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "svgd.npz"))
+    for key in d["cases"]:
+        key = str(key)
+        target, n, dtname, sign = key.split("|")
+        n, sign, dt = int(n), int(sign), np.dtype(dtname)
+        X0 = d[key + "|x0"]
+        dim = X0.shape[1]
+        x = torch.from_numpy(X0.copy()).to(DEV).reshape(-1)
+        h = torch.zeros_like(x)
+        ws = kernels.svgd_workspace(n, x)
+        K, kg, bw = kernels.svgd_kernel(x, n, dim, ws)
+        tol = 3e-5 if dt == np.float32 else 1e-10
+        np.testing.assert_allclose(K.cpu().numpy(), d[key + "|K0"], rtol=tol, atol=tol)
+        np.testing.assert_allclose(bw.cpu().numpy(), d[key + "|bw0"], rtol=tol)
+        for t in range(d[key + "|x"].shape[0]):
+            g = torch.from_numpy(d[key + "|grad"][t]).to(DEV).reshape(-1)
+            kernels.svgd_step(x, g, h, n, dim, 0.1, 0.9, 1e-6, ws, repulsion_sign=sign)
+            want = d[key + "|x"][t]
+            got = x.cpu().numpy().reshape(n, dim)
+            # the first steps divide by sqrt(0.1 g^2) = a sign function of g: allow the step size on elements
+            # whose update direction is numerically undetermined, tight everywhere else
+            close = np.isclose(got, want, rtol=30 * tol, atol=30 * tol)
+            assert close.mean() > 0.9 and np.abs(got - want).max() < 0.7, (key, t)
+            x.copy_(torch.from_numpy(want).to(DEV).reshape(-1))             # re-anchor on the fixture
+        torch.cuda.synchronize()
