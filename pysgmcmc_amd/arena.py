@@ -31,9 +31,12 @@ class FlatArena(object):
     rows : iterable of str
         Names of the state rows to allocate besides ``theta`` and ``grad``.
     dtype, device : torch dtype / device of the arena.
+    param_align : int
+        Start every parameter at a multiple of this many elements (default 1 = dense). The SVGD
+        sampler uses 64 so that its particles form an ``[n x ld]`` matrix with 256-byte aligned rows.
     """
 
-    def __init__(self, params, rows, dtype, device):
+    def __init__(self, params, rows, dtype, device, param_align=1):
         self.dtype = dtype
         self.device = torch.device(device)
         self.shapes = [tuple(p.shape) for p in params]
@@ -42,7 +45,7 @@ class FlatArena(object):
         off = 0
         for s in self.sizes:
             self.offsets.append(off)
-            off += s
+            off += ((s + param_align - 1) // param_align) * param_align   # param_align = 1: densely packed
         self.n = off
         names = ["theta", "grad"] + [r for r in rows if r not in ("theta", "grad")]
         self.row_names = names

@@ -80,6 +80,8 @@ class MCMCSampler(object):
 
     # state rows (besides theta and grad) the subclass's kernel needs
     _STATE_ROWS = ()
+    # every parameter starts at a multiple of this many elements in the arena rows (1 = dense)
+    _PARAM_ALIGN = 1
 
     def __init__(self, params, cost_fun, batch_generator=None,
                  stepsize_schedule=ConstantStepsizeSchedule(0.01),
@@ -109,7 +111,8 @@ class MCMCSampler(object):
             assert isinstance(p, torch.Tensor), "params must be torch tensors"
         self.params = params
         self.device = _pick_device(session, params)
-        self.arena = FlatArena(params, self._STATE_ROWS, self._torch_dtype, self.device)
+        self.arena = FlatArena(params, self._STATE_ROWS, self._torch_dtype, self.device,
+                               param_align=self._PARAM_ALIGN)
         for p in self.params:
             p.requires_grad_(True)
 

@@ -49,6 +49,8 @@ class SVGDSampler(MCMCSampler):
     """
 
     _STATE_ROWS = ("historical_grad",)
+    # particle rows start 64 elements (256 B) aligned: the kernels then use 16-byte accesses throughout
+    _PARAM_ALIGN = 64
 
     def __init__(self, particles, cost_fun, batch_generator=None,
                  stepsize_schedule=ConstantStepsizeSchedule(0.1),
@@ -84,7 +86,8 @@ class SVGDSampler(MCMCSampler):
         self.particle_dim = sizes.pop()
         self.repulsion_sign = 1 if STRICT_REFERENCE_QUIRKS else -1
         # the particles as one [n, d] matrix: the theta row of the arena (svgd.py:84 tf.stack)
-        self.particles = self.arena.row("theta").view(self.n_particles, self.particle_dim)
+        self.particle_pitch = ((self.particle_dim + 63) // 64) * 64
+        self.particles = self._matrix("theta")
         if batched:
             self.particles.requires_grad_(True)
         self._batched = batched
@@ -102,8 +105,13 @@ class SVGDSampler(MCMCSampler):
                 raise ValueError("cost_fun(particles) must return a torch tensor that depends on the particles")
             grad, = torch.autograd.grad(cost, [self.particles], grad_outputs=torch.ones_like(cost))
         with torch.no_grad():
-            self.arena.row("grad").view(self.n_particles, self.particle_dim).copy_(grad)
+            self._matrix("grad").copy_(grad)
         return cost.detach()
+
+    def _matrix(self, row):
+        """``[n, d]`` view of an arena row (row pitch ``particle_pitch`` elements)."""
+        flat = self.arena.row(row)
+        return torch.as_strided(flat, (self.n_particles, self.particle_dim), (self.particle_pitch, 1))
 
     def _ws(self):
         if self._workspace is None:
@@ -114,20 +122,21 @@ class SVGDSampler(MCMCSampler):
         a = self.arena
         kernels.svgd_step(a.row("theta"), a.row("grad"), a.row("historical_grad"),
                           self.n_particles, self.particle_dim, eps, self.alpha, self.fudge_factor,
-                          self._ws(), repulsion_sign=self.repulsion_sign)
+                          self._ws(), ld=self.particle_pitch, repulsion_sign=self.repulsion_sign)
 
     def svgd_kernel(self, particles=None):
         """Kernel matrix and summed kernel gradients of the current particles (``svgd.py:149-181``):
         ``(kernel_matrix [n, n], kernel_gradients [n, d])`` as device tensors. ``particles`` may be
         an ``[n, d]`` device tensor to evaluate instead."""
+        ld = None
         if particles is None:
-            x, n, d = self.arena.row("theta"), self.n_particles, self.particle_dim
+            x, n, d, ld = self.arena.row("theta"), self.n_particles, self.particle_dim, self.particle_pitch
             ws = self._ws()
         else:
             x = torch.as_tensor(particles).to(device=self.device, dtype=self._torch_dtype).contiguous()
             assert x.dim() == 2, "svgd_kernel: a 2-d tensor must be passed."
             n, d = int(x.shape[0]), int(x.shape[1])
             ws = kernels.svgd_workspace(n, x)
-        K, kg, bw = kernels.svgd_kernel(x.reshape(-1), n, d, ws)
+        K, kg, bw = kernels.svgd_kernel(x.reshape(-1), n, d, ws, ld=ld)
         self.bandwidth = bw
         return K, kg

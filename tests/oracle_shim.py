@@ -51,17 +51,25 @@ def svgd_workspace(n_particles, like):
     return torch.empty(1, dtype=like.dtype)
 
 
+def _rows(t, n, dim, ld):
+    """Writable [n, dim] numpy view of a flat tensor holding rows of pitch ld."""
+    a = t.detach().numpy()
+    ld = dim if ld is None else ld
+    return np.lib.stride_tricks.as_strided(a, shape=(n, dim), strides=(ld * a.itemsize, a.itemsize))
+
+
 def svgd_step(particles, grad, hist_grad, n_particles, dim, eps, alpha, fudge_factor, workspace, ld=None,
               repulsion_sign=1):
-    X = particles.detach().numpy()[:n_particles * dim].reshape(n_particles, dim)
-    G = grad.detach().numpy()[:n_particles * dim].reshape(n_particles, dim)
-    H = hist_grad.numpy()[:n_particles * dim].reshape(n_particles, dim)
-    O.svgd_step(X, G, H, eps, alpha, fudge_factor, repulsion_sign)
+    X, G, H = (_rows(t, n_particles, dim, ld) for t in (particles, grad, hist_grad))
+    Xc, Hc = np.ascontiguousarray(X), np.ascontiguousarray(H)
+    O.svgd_step(Xc, np.ascontiguousarray(G), Hc, eps, alpha, fudge_factor, repulsion_sign)
+    X[...] = Xc
+    H[...] = Hc
     calls.append(("svgd", False, float(eps), int(repulsion_sign)))
 
 
 def svgd_kernel(particles, n_particles, dim, workspace, ld=None, kernel_gradients=True):
-    X = particles.detach().numpy()[:n_particles * dim].reshape(n_particles, dim)
+    X = np.ascontiguousarray(_rows(particles, n_particles, dim, ld))
     K, kg, h, D = O.svgd_kernel(X)
     bw = torch.tensor([O.svgd_median(D), h, h * h], dtype=particles.dtype)
     return torch.from_numpy(K), (torch.from_numpy(kg) if kernel_gradients else None), bw

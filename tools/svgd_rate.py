@@ -16,21 +16,22 @@ if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
 for dt in (torch.float32,):
     for n, d in shapes:
-        x = (torch.randn(n * d, device=dev, dtype=dt) * (1.0 / d ** 0.5)).contiguous()
-        g = torch.randn(n * d, device=dev, dtype=dt) * 0.01
+        ld = d if os.environ.get("SVGD_DENSE_PITCH") else (d + 63) // 64 * 64    # the sampler pads rows to 64 elements
+        x = (torch.randn(n * ld, device=dev, dtype=dt) * (1.0 / d ** 0.5)).contiguous()
+        g = torch.randn(n * ld, device=dev, dtype=dt) * 0.01
         h = torch.zeros_like(x)
         ws = kernels.svgd_workspace(n, x)
         for _ in range(3):
-            kernels.svgd_step(x, g, h, n, d, 1e-3, 0.9, 1e-6, ws, repulsion_sign=-1)
+            kernels.svgd_step(x, g, h, n, d, 1e-3, 0.9, 1e-6, ws, ld=ld, repulsion_sign=-1)
         torch.cuda.synchronize()
         reps = 20 if n * d > 1e7 else 200
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
         for _ in range(reps):
-            kernels.svgd_kernel(x, n, d, ws, kernel_gradients=False)
+            kernels.svgd_kernel(x, n, d, ws, ld=ld, kernel_gradients=False)
         e1.record()
         for _ in range(reps):
-            kernels.svgd_step(x, g, h, n, d, 1e-3, 0.9, 1e-6, ws, repulsion_sign=-1)
+            kernels.svgd_step(x, g, h, n, d, 1e-3, 0.9, 1e-6, ws, ld=ld, repulsion_sign=-1)
         e2.record()
         torch.cuda.synchronize()
         t_k = e0.elapsed_time(e1) / reps * 1e3
