@@ -88,7 +88,10 @@ inline SvgdWs svgd_ws(int n) {
     w.K = off; off += (size_t)g.np16 * g.np16;
     w.ksum = off; off += g.np16;
     const size_t per_part = (size_t)g.npb * 16 > 120 ? (size_t)g.npb * 16 : 120;   // S1 or S1s layout
-    w.parts = off; off += (size_t)SVGD_MAX_PARTS * per_part;
+    size_t parts_elems = (size_t)SVGD_MAX_PARTS * per_part;
+    const size_t gram_elems = n < 17 ? 0 : n <= 32 ? (size_t)2048 * 1024 : n <= 64 ? (size_t)1024 * 3072 : (size_t)512 * 10240;
+    if (parts_elems < gram_elems) parts_elems = gram_elems;           // partial Gram blocks of the matrix-core S1
+    w.parts = off; off += parts_elems;
     w.total = off;
     return w;
 }
@@ -336,8 +339,8 @@ __device__ typename KeyOf<T>::type radix_select(const T *__restrict__ v, int N, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(512) void svgd_bandwidth_kernel(const T *__restrict__ D, int n, T *__restrict__ hdr,
-                                                              T *__restrict__ K, T *__restrict__ ksum) {
+__global__ __launch_bounds__(512) void svgd_bandwidth_kernel(T *__restrict__ D, int n, T *__restrict__ hdr,
+                                                              T *__restrict__ K, T *__restrict__ ksum, int from_gram) {
     using Key = typename KeyOf<T>::type;
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long bcast[2];
@@ -346,6 +349,24 @@ __global__ __launch_bounds__(512) void svgd_bandwidth_kernel(const T *__restrict
     const SvgdGeom g = svgd_geom(n);
     const int N = n * n;
     const int mid = N / 2;
+    if (from_gram) {
+        // the matrix-core path left the Gram matrix of the (column-centred) particles in K's storage:
+        // |x_i - x_j|^2 = G_ii + G_jj - 2 G_ij, then tf.norm's sqrt and the `** 2` as on the other paths
+        for (int idx = threadIdx.x; idx < N; idx += blockDim.x) {
+            const int i = idx / n, j = idx % n;
+            T sq = (T)0;
+            if (i != j) {
+                const int lo_i = i < j ? i : j, hi_j = i < j ? j : i;     // one rounding sequence for (i,j) and (j,i)
+                T s = (K[(size_t)lo_i * g.np16 + lo_i] + K[(size_t)hi_j * g.np16 + hi_j]) -
+                      (T)2 * K[(size_t)lo_i * g.np16 + hi_j];
+                s = s > (T)0 ? s : (T)0;
+                const T dist = sqrt_t(s);
+                sq = dist * dist;
+            }
+            D[idx] = sq;
+        }
+        __syncthreads();
+    }
     T med;
     if (N & 1) {
         med = KeyOf<T>::value(radix_select(D, N, mid, hist, bcast));    // tensor_utils.py:205-206
@@ -719,7 +740,7 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_update_reg_kernel(T *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// S4 on the matrix cores (f32, 17 <= n <= 64): A = K G and B = K X with v_mfma_f32_32x32x2_f32 (exact f32,
+// S4 on the matrix cores (f32, 9 <= n <= 128): A = K G and B = K X with v_mfma_f32_32x32x2_f32 (exact f32,
 // an fmaf chain per output). A workgroup owns a tile of 128 columns:
 //   phase 1  all 256 lanes fetch the tile's G, X (into LDS, row-major) and H (registers) with 16-byte
 //            accesses -- 512 contiguous bytes per particle row per wave instruction. With up to 192 row
@@ -734,19 +755,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int SVGD_MT = 128;                 // tile columns of the MFMA update kernel
 
-template <int IB>
-__global__ __launch_bounds__(SVGD_THREADS) void svgd_update_mfma_kernel(float *__restrict__ X, const float *__restrict__ G,
+template <int IB, int MT>
+__global__ __launch_bounds__(SVGD_THREADS, (IB <= 2 ? 2 : 1)) void svgd_update_mfma_kernel(float *__restrict__ X, const float *__restrict__ G,
                                                                          float *__restrict__ H, size_t dim, size_t ld,
                                                                          int n, const float *__restrict__ hdr,
                                                                          const float *__restrict__ K,
                                                                          const float *__restrict__ ksum, float eps,
                                                                          float alpha, float one_minus_alpha, float fudge,
                                                                          float sign) {
-    constexpr int KSMAX = 16 * IB, NR = 32 * IB, RPT = NR / 8;      // rows per lane in the row-major phases
+    constexpr int KSMAX = 16 * IB, NR = 32 * IB;
+    constexpr int QPR = MT / 4, RSTEP = SVGD_THREADS / QPR, RPT = NR / RSTEP;   // row-major phases: quads per row, rows per lane
+    constexpr int STRIPS = MT / 32, WPS = (SVGD_THREADS / 64) / STRIPS, IBW = IB / WPS;   // waves per strip, blocks per wave
+    static_assert(IBW >= 1 && IBW * WPS == IB, "particle blocks must divide among the waves of a strip");
     extern __shared__ __align__(16) unsigned char svgd_lds_raw[];
     float *kfs = reinterpret_cast<float *>(svgd_lds_raw);           // [IB][KSMAX][64]
-    float *gs = kfs + IB * KSMAX * 64;                              // [NR][SVGD_MT]
-    float *xs = gs + NR * SVGD_MT;                                  // [NR][SVGD_MT]
+    float *gs = kfs + IB * KSMAX * 64;                              // [NR][MT]
+    float *xs = gs + NR * MT;                                  // [NR][MT]
     const SvgdGeom g = svgd_geom(n);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int col = lane & 31, half = lane >> 5;
@@ -762,17 +786,17 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_update_mfma_kernel(float *_
         kfs[idx] = (i < g.np16 && j < g.np16) ? K[(size_t)i * g.np16 + j] : 0.0f;         // zero beyond n
     }
 
-    const int q = t & 31, r0 = t >> 5;                              // row-major phases: 4 columns 4q.., rows r0 + 8 k
-    const size_t n_tiles = (dim + SVGD_MT - 1) / SVGD_MT;
+    const int q = t % QPR, r0 = t / QPR;                            // row-major phases: 4 columns 4q.., rows r0 + RSTEP k
+    const size_t n_tiles = (dim + MT - 1) / MT;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const size_t c0 = tile * SVGD_MT;
+        const size_t c0 = tile * MT;
         const size_t cq = c0 + 4 * (size_t)q;
         const bool fullq = vec && cq + 4 <= dim;
         // ---- phase 1
         f32x4 gv[RPT], xv[RPT], hv[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const int r = r0 + 8 * k;
+            const int r = r0 + RSTEP * k;
             gv[k] = f32x4{0, 0, 0, 0};
             xv[k] = gv[k];
             hv[k] = gv[k];
@@ -791,38 +815,40 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_update_mfma_kernel(float *_
         }
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const int r = r0 + 8 * k;
-            *reinterpret_cast<f32x4 *>(gs + r * SVGD_MT + 4 * q) = gv[k];
-            *reinterpret_cast<f32x4 *>(xs + r * SVGD_MT + 4 * q) = xv[k];
+            const int r = r0 + RSTEP * k;
+            *reinterpret_cast<f32x4 *>(gs + r * MT + 4 * q) = gv[k];
+            *reinterpret_cast<f32x4 *>(xs + r * MT + 4 * q) = xv[k];
         }
         __syncthreads();
-        // ---- phase 2: this wave's 32-column strip
+        // ---- phase 2: this wave's 32-column strip (and, when two waves share a strip, its half of the blocks)
         {
-            const int sc = wave * 32 + col;
-            f32x16 ag[IB], ax[IB];
+            const int sc = (WPS == 1 ? wave : wave % STRIPS) * 32 + col;
+            const int ib0 = WPS == 1 ? 0 : (wave / STRIPS) * IBW;
+            f32x16 ag[IBW], ax[IBW];
 #pragma unroll
-            for (int ib = 0; ib < IB; ++ib)
+            for (int ib = 0; ib < IBW; ++ib)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { ag[ib][r] = 0.0f; ax[ib][r] = 0.0f; }
             for (int ks = 0; ks < KS; ++ks) {
-                const float bg = gs[(2 * ks + half) * SVGD_MT + sc];
-                const float bx = xs[(2 * ks + half) * SVGD_MT + sc];
+                const float bg = gs[(2 * ks + half) * MT + sc];
+                const float bx = xs[(2 * ks + half) * MT + sc];
 #pragma unroll
-                for (int ib = 0; ib < IB; ++ib) {
-                    const float kf = kfs[(ib * KSMAX + ks) * 64 + lane];
+                for (int ib = 0; ib < IBW; ++ib) {
+                    const float kf = kfs[((ib0 + ib) * KSMAX + ks) * 64 + lane];
                     ag[ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, bg, ag[ib], 0, 0, 0);
                     ax[ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, bx, ax[ib], 0, 0, 0);
                 }
             }
+            if (WPS > 1) __syncthreads();                           // the strip's other wave still reads G rows
 #pragma unroll
-            for (int ib = 0; ib < IB; ++ib)
+            for (int ib = 0; ib < IBW; ++ib)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int i = 32 * ib + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int i = 32 * (ib0 + ib) + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (i < n) {
-                        const float x = xs[i * SVGD_MT + sc];
+                        const float x = xs[i * MT + sc];
                         const float kg = (-ax[ib][r] + x * ksum[i]) / h2;          // svgd.py:176-181
-                        gs[i * SVGD_MT + sc] = (ag[ib][r] + sign * kg) / n_t;      // svgd.py:124-127
+                        gs[i * MT + sc] = (ag[ib][r] + sign * kg) / n_t;           // svgd.py:124-127
                     }
                 }
         }
@@ -830,10 +856,10 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_update_mfma_kernel(float *_
         // ---- phase 3
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const int r = r0 + 8 * k;
+            const int r = r0 + RSTEP * k;
             if (r < n && cq < dim) {
-                const f32x4 gt = *reinterpret_cast<const f32x4 *>(gs + r * SVGD_MT + 4 * q);
-                const f32x4 xo = *reinterpret_cast<const f32x4 *>(xs + r * SVGD_MT + 4 * q);   // not kept in registers
+                const f32x4 gt = *reinterpret_cast<const f32x4 *>(gs + r * MT + 4 * q);
+                const f32x4 xo = *reinterpret_cast<const f32x4 *>(xs + r * MT + 4 * q);   // not kept in registers
                 f32x4 xn, hn;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -855,6 +881,117 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_update_mfma_kernel(float *_
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S1 on the matrix cores (f32, 17 <= n <= 128): Gram matrix of the particles, G = X~ X~^T, accumulated over
+// 128-column tiles with v_mfma_f32_32x32x2_f32; |x_i - x_j|^2 = G_ii + G_jj - 2 G_ij afterwards (S3).
+// Every tile is first CENTRED per column (x~_ic = x_ic - mean_i x_ic; distances do not change): the Gram
+// entries are then of the size of the cloud's spread, not of |x|^2, and the subtraction loses nothing that
+// matters for K = exp(-D / 2h^2) (relative error ~1e-6 in f32). Tile in LDS row-major (16-byte global
+// loads); operand for particle block ib and k-step ks: lane l reads x~[32 ib + (l & 31)][2 ks + (l >> 5)];
+// both MFMA operands come from the same registers (A block ib, B block jb), block pairs ib <= jb only.
+// The 4 waves split the k-steps of a tile; their accumulators are added through LDS at the end.
+// ---------------------------------------------------------------------------------------------
+constexpr int SVGD_GP = SVGD_MT + 4;          // LDS row pitch of the Gram tile
+
+template <int IB>
+__global__ __launch_bounds__(SVGD_THREADS) void svgd_gram_mfma_kernel(const float *__restrict__ X, size_t dim, size_t ld,
+                                                                       int n, float *__restrict__ parts) {
+    constexpr int NR = 32 * IB, RPT = NR / 8, NPAIRB = IB * (IB + 1) / 2;
+    extern __shared__ __align__(16) unsigned char svgd_lds_raw[];
+    float *xs = reinterpret_cast<float *>(svgd_lds_raw);            // [NR][SVGD_GP]; later the reduction buffer
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int q = t & 31, r0 = t >> 5;
+    const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const float inv_n = 1.0f / (float)n;
+
+    f32x16 acc[NPAIRB];
+#pragma unroll
+    for (int p = 0; p < NPAIRB; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+
+    const size_t n_tiles = (dim + SVGD_MT - 1) / SVGD_MT;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t cq = tile * SVGD_MT + 4 * (size_t)q;
+        const bool fullq = vec && cq + 4 <= dim;
+        f32x4 xv[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = r0 + 8 * k;
+            xv[k] = f32x4{0, 0, 0, 0};
+            if (r < n) {
+                const size_t at = (size_t)r * ld + cq;
+                if (fullq) {
+                    xv[k] = *reinterpret_cast<const f32x4 *>(X + at);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (cq + e < dim) xv[k][e] = X[at + e];
+                }
+            }
+        }
+        __syncthreads();                                            // the previous tile's operands are consumed
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) *reinterpret_cast<f32x4 *>(xs + (r0 + 8 * k) * SVGD_GP + 4 * q) = xv[k];
+        __syncthreads();
+        if (t < SVGD_MT) {                                          // centre column t of the tile
+            float s = 0.0f;
+            for (int r = 0; r < n; ++r) s += xs[r * SVGD_GP + t];
+            const float m = s * inv_n;
+            for (int r = 0; r < n; ++r) xs[r * SVGD_GP + t] -= m;
+        }
+        __syncthreads();
+        for (int ks = wave; ks < SVGD_MT / 2; ks += SVGD_THREADS / 64) {
+            float a[IB];
+#pragma unroll
+            for (int ib = 0; ib < IB; ++ib) a[ib] = xs[(32 * ib + col) * SVGD_GP + 2 * ks + half];
+            int p = 0;
+#pragma unroll
+            for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+                for (int jb = ib; jb < IB; ++jb, ++p)
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ib], a[jb], acc[p], 0, 0, 0);
+        }
+    }
+    // add the 4 waves' accumulators in wave order, then one coalesced store of the workgroup's partial
+    __syncthreads();
+    for (int w = 0; w < SVGD_THREADS / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int p = 0; p < NPAIRB; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float *slot = xs + (p * 16 + r) * 64 + lane;
+                    *slot = (w == 0) ? acc[p][r] : (*slot + acc[p][r]);
+                }
+        }
+        __syncthreads();
+    }
+    float *out = parts + (size_t)blockIdx.x * (NPAIRB * 1024);
+    for (int idx = t; idx < NPAIRB * 1024; idx += SVGD_THREADS) out[idx] = xs[idx];
+}
+
+// S2 for the Gram partials: fixed-order sum, scatter into the [n x n] Gram matrix (row pitch np16)
+template <int IB>
+__global__ __launch_bounds__(64 * SVGD_RED_SLICES) void svgd_reduce_gram_kernel(const float *__restrict__ parts,
+                                                                                 int n_parts, int n,
+                                                                                 float *__restrict__ gram) {
+    constexpr int NPAIRB = IB * (IB + 1) / 2;
+    const SvgdGeom g = svgd_geom(n);
+    float s;
+    int idx;
+    if (!reduce_parts(parts, n_parts, NPAIRB * 1024, s, idx)) return;
+    int p = idx >> 10, ib = 0;
+    while (p >= IB - ib) { p -= IB - ib; ++ib; }
+    const int jb = ib + p;
+    const int r = (idx >> 6) & 15, l = idx & 63;
+    const int i = 32 * ib + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = 32 * jb + (l & 31);
+    if (i >= n || j >= n) return;
+    gram[(size_t)i * g.np16 + j] = s;
+    if (ib != jb) gram[(size_t)j * g.np16 + i] = s;
 }
 
 template <typename T>
@@ -892,13 +1029,54 @@ int svgd_sqdist_small(const T *X, size_t n, size_t dim, size_t ld, T *parts, T *
     return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_reduce_small_kernel");
 }
 
+template <int IB>
+int svgd_gram_launch_ib(const float *X, size_t n, size_t dim, size_t ld, float *parts, float *gram, hipStream_t st) {
+    constexpr int NPAIRB = IB * (IB + 1) / 2;
+    size_t lds_bytes = (size_t)32 * IB * SVGD_GP * sizeof(float);
+    const size_t red_bytes = (size_t)NPAIRB * 1024 * sizeof(float);
+    if (lds_bytes < red_bytes) lds_bytes = red_bytes;
+    const size_t n_tiles = (dim + SVGD_MT - 1) / SVGD_MT;
+    // partial buffers of NPAIRB * 1024 floats each must fit the workspace's partial area
+    const size_t cap = IB == 1 ? 2048 : IB == 2 ? 1024 : 512;      // resident workgroups (LDS-limited: 8 / 4 / 2 per CU)
+    const int n_parts = (int)(n_tiles < cap ? n_tiles : cap);
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&svgd_gram_mfma_kernel<IB>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e0 != hipSuccess) return hip_fail(e0, "hipFuncSetAttribute(svgd_gram_mfma_kernel)");
+    }
+    hipLaunchKernelGGL((svgd_gram_mfma_kernel<IB>), dim3(n_parts), dim3(SVGD_THREADS), lds_bytes, st, X, dim, ld, (int)n,
+                       parts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch svgd_gram_mfma_kernel");
+    hipLaunchKernelGGL((svgd_reduce_gram_kernel<IB>), dim3(NPAIRB * 1024 / 64), dim3(64 * SVGD_RED_SLICES), 0, st, parts,
+                       n_parts, (int)n, gram);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_reduce_gram_kernel");
+}
+
+inline int svgd_gram_launch(const float *X, size_t n, size_t dim, size_t ld, float *parts, float *gram, hipStream_t st) {
+    if (n <= 32) return svgd_gram_launch_ib<1>(X, n, dim, ld, parts, gram, st);
+    if (n <= 64) return svgd_gram_launch_ib<2>(X, n, dim, ld, parts, gram, st);
+    return svgd_gram_launch_ib<4>(X, n, dim, ld, parts, gram, st);
+}
+[[maybe_unused]] inline int svgd_gram_launch(const double *, size_t, size_t, size_t, double *, double *, hipStream_t) { return 0; }
+
 template <typename T>
 int svgd_kernel_matrix_impl(const T *X, size_t n, size_t dim, size_t ld, T *ws, hipStream_t st) {
     const SvgdGeom g = svgd_geom((int)n);
     const SvgdWs w = svgd_ws((int)n);
     T *parts = ws + w.parts;
     hipError_t e;
-    if (n <= 16) {
+    int from_gram = 0;
+    if constexpr (sizeof(T) == 4) {
+        if (n >= 17) {                                           // n <= 16: the register kernel S1s is faster
+            const int rc = svgd_gram_launch(X, n, dim, ld, parts, ws + w.K, st);
+            if (rc) return rc;
+            from_gram = 1;
+        }
+    }
+    if (from_gram) {
+    } else if (n <= 16) {
         const int rc = (n <= 8) ? svgd_sqdist_small<T, 8, SmallCfg<T>::CPL8>(X, n, dim, ld, parts, ws + w.D, st)
                                 : svgd_sqdist_small<T, 16, SmallCfg<T>::CPL16>(X, n, dim, ld, parts, ws + w.D, st);
         if (rc) return rc;
@@ -930,7 +1108,7 @@ int svgd_kernel_matrix_impl(const T *X, size_t n, size_t dim, size_t ld, T *ws, 
         if (e != hipSuccess) return hip_fail(e, "launch svgd_reduce_kernel");
     }
     hipLaunchKernelGGL((svgd_bandwidth_kernel<T>), dim3(1), dim3(512), 0, st, ws + w.D, (int)n, ws + w.hdr, ws + w.K,
-                       ws + w.ksum);
+                       ws + w.ksum, from_gram);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_bandwidth_kernel");
 }
@@ -973,28 +1151,25 @@ int svgd_apply_impl(T *X, const T *G, T *H, T *kgrad_out, size_t out_ld, size_t 
         return svgd_apply_small<T, 16, SmallCfg<T>::CPL16, UPDATE>(X, G, H, kgrad_out, out_ld, n, dim, ld, eps, alpha,
                                                                    fudge, sign, ws, st);
     if constexpr (UPDATE && sizeof(T) == 4) {
-        if (n <= 64) {
+        {
             const SvgdWs w = svgd_ws((int)n);
-            const size_t n_tiles = (dim + SVGD_MT - 1) / SVGD_MT;
-            const int ib = n <= 32 ? 1 : 2;
-            const size_t lds_bytes = ((size_t)ib * 16 * ib * 64 + (size_t)2 * 32 * ib * SVGD_MT) * sizeof(float);
-            const size_t cap = ib == 1 ? 1024 : 512;               // resident workgroups: K fragments staged once each
+            const int ib = n <= 32 ? 1 : n <= 64 ? 2 : 4;
+            const int mt = ib == 4 ? 64 : SVGD_MT;                 // 128 particles: 64-column tiles (LDS budget)
+            const size_t n_tiles = (dim + mt - 1) / mt;
+            const size_t lds_bytes = ((size_t)ib * 16 * ib * 64 + (size_t)2 * 32 * ib * mt) * sizeof(float);
+            const size_t cap = ib == 1 ? 1024 : ib == 2 ? 512 : 256;   // resident workgroups: K fragments staged once each
             const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
+            const void *fn = ib == 1   ? reinterpret_cast<const void *>(&svgd_update_mfma_kernel<1, SVGD_MT>)
+                             : ib == 2 ? reinterpret_cast<const void *>(&svgd_update_mfma_kernel<2, SVGD_MT>)
+                                       : reinterpret_cast<const void *>(&svgd_update_mfma_kernel<4, 64>);
             hipError_t e = hipSuccess;
-            if (ib == 1) {
-                hipLaunchKernelGGL((svgd_update_mfma_kernel<1>), dim3(grid), dim3(SVGD_THREADS), lds_bytes, st, X, G, H, dim,
-                                   ld, (int)n, ws + w.hdr, ws + w.K, ws + w.ksum, eps, (float)alpha, (float)(1.0 - alpha),
-                                   fudge, sign);
-            } else {
-                if (lds_bytes > 64 * 1024)
-                    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&svgd_update_mfma_kernel<2>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-                if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(svgd_update_mfma_kernel)");
-                hipLaunchKernelGGL((svgd_update_mfma_kernel<2>), dim3(grid), dim3(SVGD_THREADS), lds_bytes, st, X, G, H, dim,
-                                   ld, (int)n, ws + w.hdr, ws + w.K, ws + w.ksum, eps, (float)alpha, (float)(1.0 - alpha),
-                                   fudge, sign);
-            }
-            e = hipGetLastError();
+            if (lds_bytes > 64 * 1024) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(svgd_update_mfma_kernel)");
+            float a32 = (float)alpha, oma32 = (float)(1.0 - alpha), eps32 = eps, fudge32 = fudge, sign32 = sign;
+            int n_i = (int)n;
+            const float *hdr = ws + w.hdr, *Kp = ws + w.K, *ksum = ws + w.ksum;
+            void *args[] = {&X, &G, &H, &dim, &ld, &n_i, &hdr, &Kp, &ksum, &eps32, &a32, &oma32, &fudge32, &sign32};
+            e = hipLaunchKernel(fn, dim3(grid), dim3(SVGD_THREADS), args, lds_bytes, st);
             return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_update_mfma_kernel");
         }
     }

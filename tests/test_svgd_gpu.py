@@ -113,7 +113,12 @@ def test_svgd_median_ties_zeros_and_reproducibility():
     K, kg, bw = kernels.svgd_kernel(x.reshape(-1), 15, 40, ws)
     _, _, h_ref, D_ref = O.svgd_kernel(X.astype(np.float64))
     np.testing.assert_allclose(bw[0].item(), O.svgd_median(D_ref), rtol=1e-5)
-    assert np.all(K.cpu().numpy()[np.arange(6), np.arange(6) + 6] == 1.0)   # identical particles: K = 1
+    # identical particles: K = 1 (to Gram-form rounding on the matrix-core path, n >= 9 in f32)
+    np.testing.assert_allclose(K.cpu().numpy()[np.arange(6), np.arange(6) + 6], 1.0, atol=2e-6)
+    Xs = X[:8]                                                               # n <= 8: difference form, exact zeros
+    ws8 = kernels.svgd_workspace(8, x)
+    K8, _, _ = kernels.svgd_kernel(torch.from_numpy(Xs).to(DEV).reshape(-1), 8, 40, ws8)
+    assert np.all(K8.cpu().numpy()[np.arange(2), np.arange(2) + 6] == 1.0)
     # bit-reproducible run to run (fixed-order partial sums, no atomics) at a multi-workgroup size
     X = _cloud(24, 300000, np.float32, seed=9)
     outs = []
