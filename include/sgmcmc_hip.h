@@ -251,7 +251,8 @@ int sgmcmc_bnn_fused_sghmc_steps_f64(double *theta, double *V, double *grad, dou
                                      sgmcmc_stream_t stream);
 
 /* ---- Stein variational gradient descent: pysgmcmc/samplers/svgd.py:118-181 -----------------------
- * The n particles are the rows of a [n_particles x ld] device matrix (row pitch ld >= dim elements);
+ * The n particles are the rows of a [n_particles x ld] device matrix (row pitch ld >= dim elements; with
+ * ld a multiple of 4 and 16-byte aligned bases every access is 16 bytes wide -- the sampler pads ld to 64);
  * grad[i] = d cost / d particle i (svgd.py:118), hist_grad = `historical_grad` (svgd.py:107-110).
  * sgmcmc_svgd_step_* does one step in place:
  *   D = squareform(pdist(X)) ** 2 (tensor_utils.py:397-408, 466-565; svgd.py:165-166),

@@ -1,24 +1,29 @@
 // sgmcmc_svgd.hip -- Stein variational gradient descent step (pysgmcmc/samplers/svgd.py:118-181).
 //
-// n particles of `dim` parameters each live as rows of one [n x ld] matrix X (the theta row of the
-// sampler's arena); G holds d cost / d X, H the running mean of squared updates ("historical_grad").
-// One step is four launches:
-//   S1 svgd_sqdist_kernel     partial sums of sum_c (X[i][c] - X[j][c])^2 over column ranges: a tile of
-//                             columns is staged TRANSPOSED in LDS ([c][i]) and every lane owns a 4x4
-//                             block of (i, j) pairs in registers (2 ds_read_b128 per 32 VALU ops); only
-//                             pair blocks on or above the diagonal are computed. Reads X once.
-//   S2 svgd_reduce_kernel     adds the partials in fixed order (bit-reproducible, no atomics), applies
-//                             tf.norm's sqrt and the `** 2` of svgd.py:166, writes the symmetric D.
-//   S3 svgd_bandwidth_kernel  one workgroup: median of all n*n entries of D by radix select
-//                             (tensor_utils.py:197-209), h = sqrt(0.5 median / log(n + 1)),
-//                             K = exp(-D / h^2 / 2), row sums (svgd.py:169-174).
-//   S4 svgd_update_kernel     streams X, G, H once: one wave per 64-column tile, the tile staged in LDS,
-//                             A = K G and B = K X accumulated with v_fma (K read through scalar loads,
-//                             16 output rows per pass), then the element-wise tail of svgd.py:124-143
-//                             with one rounding per reference op. R{X,G,H} W{X,H} = 20 B per element.
-// The contractions are n x n x dim with n <= 128: fp32 MFMA and fp32 VALU have the SAME peak on gfx950
-// (157 TFLOP/s) and S4 is HBM-bound up to n ~ 64 (2n FMA per 20 bytes), so the VALU form with scalar
-// K operands is used; there is no precision mode to trade (the reference computes in fp32/fp64).
+// n <= 128 particles of `dim` parameters each live as rows of one [n x ld] matrix X (the theta row of the
+// sampler's arena, row pitch padded to 64 elements); G holds d cost / d X, H the running mean of squared
+// updates ("historical_grad"). One step is four launches:
+//   S1  pairwise squared distances, partial sums per column range. Reads X once (4 B / element).
+//         n <= 16 (any dtype): svgd_sqdist_small_kernel -- registers only, 8/16-byte loads;
+//         17..128, f32:        svgd_gram_mfma_kernel    -- Gram matrix of column-centred tiles on the
+//                                                          matrix cores (v_mfma_f32_32x32x2_f32);
+//         17..128, f64:        svgd_sqdist_kernel       -- difference form, transposed LDS tile, 4x4 pair
+//                                                          blocks per lane.
+//   S2  svgd_reduce_*_kernel   adds the partials in a fixed order (bit-reproducible, no atomics).
+//   S3  svgd_bandwidth_kernel  one workgroup: (D from the Gram matrix,) median of all n*n entries of D by
+//                              radix select (tensor_utils.py:197-209), h = sqrt(0.5 median / log(n + 1)),
+//                              K = exp(-D / h^2 / 2), row sums (svgd.py:169-174).
+//   S4  A = K G, B = K X, then the element-wise tail of svgd.py:124-143 with one rounding per reference
+//       op. R{X,G,H} W{X,H} = 20 B / element.
+//         n <= 8 (f32), <= 16 (f64): svgd_update_small_kernel -- registers, K rows as scalar operands;
+//         9..128, f32:               svgd_update_mfma_kernel  -- matrix cores, cooperative 128-column tiles,
+//                                                                16-byte row-major global accesses;
+//         f64 up to 32:              svgd_update_reg_kernel   -- packed register pairs {g_j, x_j};
+//         f64 beyond:                svgd_update_kernel       -- pair tile in LDS, one wave per 64 columns.
+// fp32 MFMA and packed fp32 VALU have the same peak on gfx950 (157 TFLOP/s; 155 measured for
+// v_mfma_f32_32x32x2_f32, tools/mfma_f32_probe.hip) and the f32 MFMA is exact f32, so there is no precision
+// to trade; the matrix-core forms win because K lives in LDS/registers instead of stalling on scalar loads and
+// because the VALU stays free for the tail (3 IEEE divisions + sqrt per element).
 //
 // Sums over columns / particles have no reference rounding order (tf.reduce_sum / tf.matmul), so
 // parity with the oracle is to accumulated-rounding tolerance; everything after them is op-for-op.
