@@ -39,7 +39,8 @@ class SVGDSampler(MCMCSampler):
         Takes ONE particle and returns its scalar cost (``svgd.py:37-40``). A cost function
         with the attribute ``batched = True`` is instead called once with the ``[n, d]``
         matrix of all particles and must return the ``n`` costs (one backward pass for all
-        particles instead of ``n``).
+        particles instead of ``n``). A plain per-particle cost is batched automatically with
+        ``torch.func.vmap`` when that reproduces the particle-by-particle costs and gradients.
     alpha, fudge_factor : float
         Decay of the running mean of squared updates and the constant added to its square
         root (``svgd.py:129-137``; AdaGrad with momentum, as in Liu & Wang's code).
@@ -91,22 +92,57 @@ class SVGDSampler(MCMCSampler):
         if batched:
             self.particles.requires_grad_(True)
         self._batched = batched
+        self._vmapped = None
         self._workspace = None
         self.collect_stats = False
 
-    # the base class differentiates `cost_fun(self.params)`; a batched cost differentiates the matrix
+    # the base class differentiates `cost_fun(self.params)` particle by particle (n backward passes); a batched
+    # cost differentiates the [n, d] matrix in one pass, and a plain per-particle cost is batched with
+    # torch.func.vmap when that reproduces the loop's costs and gradients on the first step
     def _cost_and_grad(self):
-        if not self._batched:
-            return super()._cost_and_grad()
+        if self._batched:
+            return self._cost_and_grad_matrix(self.cost_fun)
+        if self._vmapped is None:
+            self._vmapped = self._try_vmap()
+        if self._vmapped:
+            return self._cost_and_grad_matrix(self._vmapped)
+        return super()._cost_and_grad()
+
+    def _cost_and_grad_matrix(self, fun):
         self._grad_decay = 0.0
         with torch.enable_grad():
-            cost = self.cost_fun(self.params)
+            cost = fun(self.params)
             if not isinstance(cost, torch.Tensor) or not cost.requires_grad:
                 raise ValueError("cost_fun(particles) must return a torch tensor that depends on the particles")
             grad, = torch.autograd.grad(cost, [self.particles], grad_outputs=torch.ones_like(cost))
         with torch.no_grad():
             self._matrix("grad").copy_(grad)
         return cost.detach()
+
+    def _try_vmap(self):
+        """Batched form of the per-particle cost, or False. Only for particles that share one shape; checked
+        against the particle-by-particle evaluation before it is trusted."""
+        if len({tuple(p.shape) for p in self.params}) != 1 or not hasattr(torch, "func"):
+            return False
+        shape = tuple(self.params[0].shape)
+        cost_fun = self._particle_cost_fun
+        try:
+            batched = torch.func.vmap(lambda row: cost_fun(row.reshape(shape)).reshape(()))
+            self.particles.requires_grad_(True)
+            fun = lambda params: batched(self.particles)
+            with torch.enable_grad():
+                c_b = fun(self.params)
+                g_b, = torch.autograd.grad(c_b, [self.particles], grad_outputs=torch.ones_like(c_b))
+                c_l = self.cost_fun(self.params)
+                g_l = torch.autograd.grad(c_l, self.params, grad_outputs=torch.ones_like(c_l), allow_unused=True)
+            g_l = torch.stack([torch.zeros(shape, dtype=c_l.dtype, device=c_l.device) if g is None else g
+                               for g in g_l]).reshape(self.n_particles, -1)
+            tol = 1e-5 if self._torch_dtype == torch.float32 else 1e-11
+            ok = (torch.allclose(c_b, c_l, rtol=tol, atol=tol)
+                  and torch.allclose(g_b, g_l.to(g_b.dtype), rtol=tol, atol=tol * (1.0 + float(g_l.abs().max()))))
+            return fun if ok else False
+        except Exception:                          # data-dependent control flow, in-place ops, feeds ... : keep the loop
+            return False
 
     def _matrix(self, row):
         """``[n, d]`` view of an arena row (row pitch ``particle_pitch`` elements)."""
