@@ -761,7 +761,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int SVGD_MT = 128;                 // tile columns of the MFMA update kernel
 
 template <int IB, int MT>
-__global__ __launch_bounds__(SVGD_THREADS, (IB <= 2 ? 2 : 1)) void svgd_update_mfma_kernel(float *__restrict__ X, const float *__restrict__ G,
+__global__ __launch_bounds__(SVGD_THREADS, (IB == 2 && MT == 64 ? 3 : IB <= 2 ? 2 : 1)) void svgd_update_mfma_kernel(float *__restrict__ X, const float *__restrict__ G,
                                                                          float *__restrict__ H, size_t dim, size_t ld,
                                                                          int n, const float *__restrict__ hdr,
                                                                          const float *__restrict__ K,
@@ -1159,13 +1159,15 @@ int svgd_apply_impl(T *X, const T *G, T *H, T *kgrad_out, size_t out_ld, size_t 
         {
             const SvgdWs w = svgd_ws((int)n);
             const int ib = n <= 32 ? 1 : n <= 64 ? 2 : 4;
-            const int mt = ib == 4 ? 64 : SVGD_MT;                 // 128 particles: 64-column tiles (LDS budget)
+            // n > 32: 64-column tiles, two waves per 32-column strip with half of the particle blocks each -- 48 KB of
+            // LDS and 94 registers per lane at n <= 64 (3 workgroups per CU; 3.57 vs 4.20 ms at 64 x 10 M with 128 columns)
+            const int mt = ib == 1 ? SVGD_MT : 64;
             const size_t n_tiles = (dim + mt - 1) / mt;
             const size_t lds_bytes = ((size_t)ib * 16 * ib * 64 + (size_t)2 * 32 * ib * mt) * sizeof(float);
-            const size_t cap = ib == 1 ? 1024 : ib == 2 ? 512 : 256;   // resident workgroups: K fragments staged once each
+            const size_t cap = ib == 1 ? 1024 : ib == 2 ? 768 : 256;   // resident workgroups: K fragments staged once each
             const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
             const void *fn = ib == 1   ? reinterpret_cast<const void *>(&svgd_update_mfma_kernel<1, SVGD_MT>)
-                             : ib == 2 ? reinterpret_cast<const void *>(&svgd_update_mfma_kernel<2, SVGD_MT>)
+                             : ib == 2 ? reinterpret_cast<const void *>(&svgd_update_mfma_kernel<2, 64>)
                                        : reinterpret_cast<const void *>(&svgd_update_mfma_kernel<4, 64>);
             hipError_t e = hipSuccess;
             if (lds_bytes > 64 * 1024) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -14,7 +14,7 @@ shapes = [(50, 2), (16, 5252), (8, 10_002_434), (16, 10_002_434), (32, 10_002_43
           (20, 50_000_000)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
-for dt in (torch.float32,):
+for dt in ((torch.float64,) if os.environ.get("SVGD_F64") else (torch.float32,)):
     for n, d in shapes:
         ld = d if os.environ.get("SVGD_DENSE_PITCH") else (d + 63) // 64 * 64    # the sampler pads rows to 64 elements
         x = (torch.randn(n * ld, device=dev, dtype=dt) * (1.0 / d ** 0.5)).contiguous()
