@@ -48,6 +48,8 @@ WORKLOADS = {
     "bnn10m-sghmc": dict(sampler="sghmc", layers=(784, 2048, 2048, 2048)),        # 10 002 434 params
     "bnn50m-sgld": dict(sampler="sgld", layers=(512, 4864, 4864, 4864)),          # 49 826 818 params
     "bnn50m-rsghmc": dict(sampler="rsghmc", layers=(512, 4864, 4864, 4864)),
+    # SVGD update path on 16 particles of the same 10 M-parameter model (synthetic gradients)
+    "svgd16-10m": dict(sampler="svgd", layers=(784, 2048, 2048, 2048), particles=16),
 }
 LAYERS = WORKLOADS["bnn10m-sghmc"]["layers"]
 
@@ -264,6 +266,101 @@ def cpu_baseline(n, budget_s):
             "opbyop_numpy_steps_per_s": round(asteps / adt, 3) if asteps else None}
 
 
+def svgd_cpu_baseline(n_particles, dim, budget_s):
+    """The numpy restatement of pysgmcmc/samplers/svgd.py (oracle/, kind "port") on a column sample of the
+    same workload; its cost is linear in the number of columns, so the rate is scaled to the full width."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import sgmcmc_oracle as O
+    d_s = min(dim, 200_000)
+    rng = np.random.default_rng(0)
+    X = (rng.normal(size=(n_particles, d_s)) / np.sqrt(dim)).astype(np.float32)
+    G = (rng.normal(size=(n_particles, d_s)) * 0.1).astype(np.float32)
+    H = np.zeros_like(X)
+    cores = usable_cores()
+    O.svgd_step(X, G, H, 1e-3, 0.9, 1e-6, -1.0)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < budget_s and reps < 200:
+        O.svgd_step(X, G, H, 1e-3, 0.9, 1e-6, -1.0)
+        reps += 1
+    dt = (time.perf_counter() - t0) / max(reps, 1)
+    return {"value": round(1.0 / (dt * dim / d_s), 3), "unit": "update-steps/s", "cores": cores, "kind": "port",
+            "sample": "numpy op-by-op restatement (oracle/sgmcmc_oracle.py svgd_step), %d particles x %d of the %d "
+                      "columns, %d steps; seconds per step scaled by %d / %d (the cost is linear in the columns); "
+                      "numpy/BLAS threads as configured on the host" % (n_particles, d_s, dim, reps, dim, d_s)}
+
+
+def run_svgd(args, dev, rank, world, dist):
+    """`--workload svgd16-10m`: one step = sgmcmc_svgd_step_f32 (kernel matrix + update, 4 launches) on
+    n particles x 10 002 434 parameters with fixed synthetic gradients. Particles never leave HBM."""
+    from pysgmcmc_amd import kernels
+    spec = WORKLOADS[args.workload]
+    layers = spec["layers"]
+    n = spec["particles"]
+    dim = sum(a * b + b for a, b in zip(layers, layers[1:] + (1,))) + 1
+    ld = (dim + 63) // 64 * 64                                  # the sampler's row pitch
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    x = torch.randn(n * ld, device=dev, generator=g) * (1.0 / dim ** 0.5)
+    grad = torch.randn(n * ld, device=dev, generator=g) * 0.1
+    hist = torch.zeros_like(x)
+    ws = kernels.svgd_workspace(n, x)
+    step = lambda: kernels.svgd_step(x, grad, hist, n, dim, 1e-3, 0.9, 1e-6, ws, ld=ld, repulsion_sign=-1)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    pairs = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        step()
+        e1.record()
+        pairs.append((e0, e1))
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(x).all()
+    if rank == 0:
+        us = float(np.mean([a.elapsed_time(b) for a, b in pairs])) * 1e3
+        alg_bytes = 24 * n * dim                                # S1 reads X (4 B), S4 R{X,G,H} W{X,H} (20 B) per element
+        achieved = alg_bytes / (us * 1e-6) / 1e9
+        line = {
+            "metric": "SVGD update-steps/sec + HBM GB/s (%% roofline), %d particles x BNN 10M params" % n,
+            "value": round(world * args.steps / elapsed, 2), "unit": "update-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: SVGD step (pairwise distances, median bandwidth, kernel matrix, K[G|X] + AdaGrad "
+                                   "update) on %d particles x %d parameters, row pitch %d, fixed synthetic gradients; "
+                                   "1 particle set per GPU" % (args.workload, n, dim, ld),
+                       "particles": n, "params": dim, "chains": world},
+            "roofline": {"bound": "hbm", "kernel": "sgmcmc_svgd_step_f32 (svgd_sqdist_small_kernel + svgd_update_mfma_kernel; "
+                                                   "per-kernel times in profiles/r01_svgd_kernel_stats.md)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch_mean": round(us, 2),
+                         "launches_timed": len(pairs),
+                         "timing": "hipEvent pair around every step (4 launches) of the timed region"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = svgd_cpu_baseline(n, dim, args.cpu_seconds)
+        print(json.dumps(line))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -285,6 +382,8 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    if WORKLOADS[args.workload]["sampler"] == "svgd":
+        return run_svgd(args, dev, rank, world, dist)
     from pysgmcmc_amd import kernels
     if not args.no_gemm_tuning:
         from pysgmcmc_amd.models.bayesian_neural_network import enable_gemm_tuning
