@@ -337,15 +337,16 @@ class MCMCSampler(object):
                 self._static_feeds[placeholder] = buf
                 self._graphs.clear()
             else:
-                buf.copy_(value)
+                buf.copy_(value)                  # (one torch._foreach_copy_ for all feeds measured slower: 246 vs 236 us/step)
             placeholder.value = buf
         self._ensure_stats()
+        full = self.use_hip_graph == "full"
         if self._step_ctr is None:
             self._step_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
-        if self._ctr_value != self.n_iterations:
+        if full and self._ctr_value != self.n_iterations:
+            # only the fully captured step reads the device counter (the direct launch gets the step by value)
             self._step_ctr.fill_(self.n_iterations)
             self._ctr_value = self.n_iterations
-        full = self.use_hip_graph == "full"
         key = self._graph_key(eps) if full else ("cost",)
         entry = self._graphs.get(key)
         if entry is None:
