@@ -270,3 +270,27 @@ def test_svgd_sampler_vmap_and_hip_graph_modes_agree():
     a, _ = chain(graph="full")
     b, _ = chain(graph="full")
     assert np.array_equal(a, b)                        # and reproducible bit for bit
+
+
+@pytest.mark.parametrize("n", [12, 32, 64, 100])
+def test_svgd_tight_cloud_far_from_origin(n):
+    """Particles 0.01 apart around 100: the matrix-core path forms distances from a Gram matrix, which only works
+    because every tile is centred per column first (|x|^2 = 1e4 d would swallow distances of 1e-4 d in f32)."""
+    d = 3000
+    rng = np.random.default_rng(n)
+    X = (100.0 + 0.01 * rng.normal(size=(n, d))).astype(np.float32)
+    K_ref, kg_ref, h_ref, _ = O.svgd_kernel(X.astype(np.float64))
+    x = torch.from_numpy(X).to(DEV)
+    ws = kernels.svgd_workspace(n, x)
+    K, kg, bw = kernels.svgd_kernel(x.reshape(-1), n, d, ws)
+    np.testing.assert_allclose(bw[1].item(), h_ref, rtol=2e-4)
+    np.testing.assert_allclose(K.cpu().numpy(), K_ref, rtol=2e-3, atol=2e-4)
+    G = rng.normal(size=(n, d)).astype(np.float32)
+    H = np.full((n, d), 0.5, np.float32)
+    g, h = torch.from_numpy(G).to(DEV).reshape(-1), torch.from_numpy(H.copy()).to(DEV).reshape(-1)
+    xs = x.clone().reshape(-1)
+    kernels.svgd_step(xs, g, h, n, d, 1e-3, 0.9, 1e-6, ws, repulsion_sign=-1)
+    Xo, Ho = X.astype(np.float64), H.astype(np.float64)
+    O.svgd_step(Xo, G.astype(np.float64), Ho, 1e-3, 0.9, 1e-6, -1.0)
+    # the update itself is tiny next to 100: compare the displacement
+    np.testing.assert_allclose(xs.cpu().numpy().reshape(n, d).astype(np.float64) - X, Xo - X, rtol=0.05, atol=2e-5)
