@@ -55,6 +55,7 @@ class FlatArena(object):
         self._rows = {}
         for k, name in enumerate(names):
             self._rows[name] = self.storage[k * stride:k * stride + self.n]
+        self._params = list(params)
         # adopt the parameters: copy values in, alias p.data to the arena
         theta = self._rows["theta"]
         with torch.no_grad():
@@ -62,6 +63,23 @@ class FlatArena(object):
                 seg = theta[o:o + s].view(shp)
                 seg.copy_(p.detach().to(device=self.device, dtype=dtype))
                 p.data = seg
+        self.grad_views = [self._rows["grad"][o:o + s].view(shp)
+                           for o, s, shp in zip(self.offsets, self.sizes, self.shapes)]
+
+    def rebind(self, storage):
+        """Move the arena into ``storage`` (same length, dtype and device; e.g. a slice of one allocation that
+        holds several chains back to back): values are copied, the rows, gradient views and the parameters'
+        ``.data`` then alias the new memory."""
+        assert storage.numel() == self.storage.numel() and storage.dtype == self.storage.dtype
+        assert storage.device == self.storage.device and storage.is_contiguous()
+        with torch.no_grad():
+            storage.copy_(self.storage)
+            self.storage = storage
+            for k, name in enumerate(self.row_names):
+                self._rows[name] = storage[k * self.stride:k * self.stride + self.n]
+            theta = self._rows["theta"]
+            for p, o, s, shp in zip(self._params, self.offsets, self.sizes, self.shapes):
+                p.data = theta[o:o + s].view(shp)
         self.grad_views = [self._rows["grad"][o:o + s].view(shp)
                            for o, s, shp in zip(self.offsets, self.sizes, self.shapes)]
 

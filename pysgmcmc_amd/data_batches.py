@@ -115,7 +115,8 @@ class WindowBatches(object):
 
     def next_starts(self, n):
         hi = self.n_examples - self.batch_size + 1
-        return np.asarray([self._rng.randint(0, hi) for _ in range(int(n))], dtype=np.int32)
+        # one vectorised draw = the same values as n successive scalar randint calls (same RandomState stream)
+        return self._rng.randint(0, hi, size=int(n)).astype(np.int32)
 
     def __next__(self):
         start = int(self.next_starts(1)[0])

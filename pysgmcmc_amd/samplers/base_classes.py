@@ -141,6 +141,15 @@ class MCMCSampler(object):
         self._capturing = False
         self._grad_decay = 0.0
 
+    def _rebind_arena(self, storage):
+        """Re-home this chain's state in ``storage`` (see ``FlatArena.rebind``) and refresh the cached views."""
+        self.arena.rebind(storage)
+        self.vectorized_params = [v.view(-1, 1) for v in self.arena.views("theta")]
+        self.theta_t = self.arena.views("theta")
+        self._graphs.clear()
+        self._static_feeds.clear()
+        self._stats_valid = False
+
     # ------------------------------------------------------------------ feeds
     def _next_batch(self):
         """Next ``{placeholder: value}`` dict, or ``{}`` without a generator."""

@@ -140,3 +140,35 @@ def test_bnn_train_uses_the_fused_path(gpu):
         assert np.mean((yt - m) ** 2) < 0.1
     assert res[True][1] == res[False][1]                       # same number of sampler iterations
     assert np.abs(res[True][0] - res[False][0]).max() < 0.2    # chaotic divergence over 2 000 steps, same posterior
+
+
+def test_fused_chain_group_equals_individual_chains(gpu):
+    """FusedBNNChains: 6 SGHMC chains re-homed in one allocation and advanced by ONE launch per chunk are, bit
+    for bit, the 6 chains advanced one by one; each member stays a working sampler afterwards."""
+    from pysgmcmc_amd.samplers.fused_chains import FusedBNNChains
+    rng = np.random.RandomState(1)
+    X = rng.rand(100, 1)
+    y = np.sinc(X * 10 - 5).sum(axis=1)
+    kw = dict(hidden=(50, 50, 50), batch_size=20, seed=40, dtype=torch.float32, device=gpu, burn_in_steps=7)
+    group = FusedBNNChains.for_dataset(X, y, 6, **kw)
+    solo = FusedBNNChains.for_dataset(X, y, 6, **kw).samplers       # same construction, stepped individually
+    assert group.n_chains == 6 and group.theta().shape == (6, 5252)
+    costs = torch.cat([group.steps(5), group.steps(9)], dim=1)      # burn-in switch inside the second chunk
+    for c, s in enumerate(solo):
+        c1 = torch.cat([s.fused_bnn_steps(5), s.fused_bnn_steps(9)])
+        assert torch.equal(group.samplers[c].arena.row("theta"), s.arena.row("theta"))
+        assert torch.equal(group.samplers[c].arena.row("minv"), s.arena.row("minv"))
+        assert torch.equal(costs[c], c1)
+        assert torch.equal(group.theta()[c], s.arena.row("theta"))
+    assert group.n_iterations == 14 and not group.samplers[0].is_burning_in
+    assert not torch.equal(group.theta()[0], group.theta()[1])
+    # members keep working as ordinary samplers on the shared memory (GEMM path), and so do their parameters
+    a, b = group.samplers[2], solo[2]
+    a.sample_format = b.sample_format = "view"
+    next(a); next(b)
+    assert torch.allclose(a.arena.row("theta"), b.arena.row("theta"), rtol=1e-5, atol=1e-6)
+    assert a.params[0].data_ptr() == a.arena.row("theta").data_ptr()
+    # mismatched chains are refused
+    other = FusedBNNChains.for_dataset(X, y, 2, **dict(kw, seed=90)).samplers
+    with pytest.raises(ValueError):
+        FusedBNNChains([group.samplers[0], other[0]])

@@ -25,3 +25,21 @@ for dt in (torch.float32,):
         for r in range(5): run(200 * (r + 1))
         torch.cuda.synchronize(); dtm = (time.perf_counter() - t0) / (5 * n_steps)
         print("%s chains=%5d : %6.1f us per step per chain-group -> %10.0f samples/s aggregate" % (str(dt).split(".")[1], nc, dtm * 1e6, nc / dtm))
+
+# the same through the sampler-level group (FusedBNNChains): chains built like BayesianNeuralNetwork's default set-up
+from pysgmcmc_amd.samplers.fused_chains import FusedBNNChains  # noqa: E402
+import time  # noqa: E402
+
+rng = np.random.RandomState(1)
+Xs = rng.rand(100, 1)
+ys = np.sinc(Xs * 10 - 5).sum(axis=1)
+for m in (1, 64, 256):
+    grp = FusedBNNChains.for_dataset(Xs, ys, m, seed=3, device="cuda:0")
+    grp.steps(100)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        grp.steps(100)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 1000
+    print("FusedBNNChains %4d chains: %6.1f us per step of all chains -> %10.0f samples/s" % (m, dt * 1e6, m / dt))
