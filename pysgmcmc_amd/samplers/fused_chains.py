@@ -70,6 +70,9 @@ class FusedBNNChains(object):
         (cost at the parameters before each step). Needs a stepsize that is constant over the chunk."""
         n_steps = int(n_steps)
         first = self.samplers[0]
+        if any(s.n_iterations != first.n_iterations for s in self.samplers):
+            raise ValueError("FusedBNNChains.steps: the chains are no longer at the same iteration "
+                             "(a member was stepped on its own)")
         eps = None
         for s in self.samplers:
             e = [next(s.stepsize_schedule) for _ in range(n_steps)]
@@ -98,6 +101,17 @@ class FusedBNNChains(object):
             s._grad_decay = float(cost.wdecay / ((a.n + 3e-16) * cost.n_examples))
             s.cost = costs[c, -1]
         return costs
+
+    def collect(self, n_samples, every=100):
+        """``n_samples`` thinned snapshots of all chains: a ``[n_chains, n_samples, n_params]`` device tensor (one
+        launch of ``every`` steps per snapshot), ready for
+        ``diagnostics.sampler_diagnostics.gelman_rubin_from_chains`` / ``effective_n``."""
+        a = self.samplers[0].arena
+        out = torch.empty(self.n_chains, int(n_samples), a.n, dtype=self.storage.dtype, device=self.storage.device)
+        for k in range(int(n_samples)):
+            self.steps(every)
+            out[:, k].copy_(self.theta())
+        return out
 
     @classmethod
     def for_dataset(cls, X, y, n_chains, hidden=(50, 50, 50), batch_size=20, seed=0, dtype=torch.float32,

@@ -162,12 +162,23 @@ def test_fused_chain_group_equals_individual_chains(gpu):
         assert torch.equal(group.theta()[c], s.arena.row("theta"))
     assert group.n_iterations == 14 and not group.samplers[0].is_burning_in
     assert not torch.equal(group.theta()[0], group.theta()[1])
+    # thinned snapshots of all chains -> R-hat across the chains (finite, and > 1 this early in the run)
+    from pysgmcmc_amd.diagnostics.sampler_diagnostics import gelman_rubin_from_chains
+    snaps = group.collect(6, every=10)
+    assert snaps.shape == (6, 6, 5252) and group.n_iterations == 14 + 60
+    assert torch.equal(snaps[:, -1], group.theta())
+    rhat = gelman_rubin_from_chains(snaps)
+    assert rhat.shape == (5252,) and torch.isfinite(rhat).all() and float(rhat.median()) > 1.0
     # members keep working as ordinary samplers on the shared memory (GEMM path), and so do their parameters
     a, b = group.samplers[2], solo[2]
+    for _ in range(6):
+        b.fused_bnn_steps(10)                             # bring the solo twin to iteration 74 as well
     a.sample_format = b.sample_format = "view"
     next(a); next(b)
     assert torch.allclose(a.arena.row("theta"), b.arena.row("theta"), rtol=1e-5, atol=1e-6)
     assert a.params[0].data_ptr() == a.arena.row("theta").data_ptr()
+    with pytest.raises(ValueError):                       # the group insists on lockstep
+        group.steps(1)
     # mismatched chains are refused
     other = FusedBNNChains.for_dataset(X, y, 2, **dict(kw, seed=90)).samplers
     with pytest.raises(ValueError):
