@@ -7,7 +7,8 @@
 //         n <= 16 (any dtype): svgd_sqdist_small_kernel -- registers only, 8/16-byte loads;
 //         17..128, f32:        svgd_gram_mfma_kernel    -- Gram matrix of column-centred tiles on the
 //                                                          matrix cores (v_mfma_f32_32x32x2_f32);
-//         17..128, f64:        svgd_sqdist_kernel       -- difference form, transposed LDS tile, 4x4 pair
+//         17..64, f64:         svgd_gram_mfma_f64_kernel -- the same with v_mfma_f64_16x16x4_f64;
+//         65..128, f64:        svgd_sqdist_kernel       -- difference form, transposed LDS tile, 4x4 pair
 //                                                          blocks per lane.
 //   S2  svgd_reduce_*_kernel   adds the partials in a fixed order (bit-reproducible, no atomics).
 //   S3  svgd_bandwidth_kernel  one workgroup: (D from the Gram matrix,) median of all n*n entries of D by
@@ -15,11 +16,12 @@
 //                              K = exp(-D / h^2 / 2), row sums (svgd.py:169-174).
 //   S4  A = K G, B = K X, then the element-wise tail of svgd.py:124-143 with one rounding per reference
 //       op. R{X,G,H} W{X,H} = 20 B / element.
-//         n <= 8 (f32), <= 16 (f64): svgd_update_small_kernel -- registers, K rows as scalar operands;
-//         9..128, f32:               svgd_update_mfma_kernel  -- matrix cores, cooperative 128-column tiles,
-//                                                                16-byte row-major global accesses;
-//         f64 up to 32:              svgd_update_reg_kernel   -- packed register pairs {g_j, x_j};
-//         f64 beyond:                svgd_update_kernel       -- pair tile in LDS, one wave per 64 columns.
+//         n <= 8:                    svgd_update_small_kernel    -- registers, K rows as scalar operands;
+//         9..128, f32:               svgd_update_mfma_kernel     -- matrix cores, cooperative 64/128-column tiles,
+//                                                                   16-byte row-major global accesses;
+//         9..64, f64:                svgd_update_mfma_f64_kernel -- the same with v_mfma_f64_16x16x4_f64;
+//         65..128, f64:              svgd_update_kernel          -- pair tile in LDS, one wave per 64 columns
+//       (svgd_update_reg_kernel / svgd_update_kernel also serve sgmcmc_svgd_kernel_*'s kernel-gradient output).
 // fp32 MFMA and packed fp32 VALU have the same peak on gfx950 (157 TFLOP/s; 155 measured for
 // v_mfma_f32_32x32x2_f32, tools/mfma_f32_probe.hip) and the f32 MFMA is exact f32, so there is no precision
 // to trade; the matrix-core forms win because K lives in LDS/registers instead of stalling on scalar loads and
@@ -889,6 +891,138 @@ __global__ __launch_bounds__(SVGD_THREADS, (IB == 2 && MT == 64 ? 3 : IB <= 2 ? 
 }
 
 // ---------------------------------------------------------------------------------------------
+// S4 on the matrix cores, f64 (9 <= n <= 64): the same three phases with v_mfma_f64_16x16x4_f64 -- 16-particle
+// blocks, 16-column strips (4 waves = one 64-column tile), k-steps of 4 particles. Operand maps: A lane l =
+// K[16 ib + (l & 15)][4 ks + (l >> 4)], B lane l = tile[4 ks + (l >> 4)][column l & 15]; output register r of
+// lane l = row (l >> 4) + 4 r, column l & 15.
+// ---------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <int IB>                              // 16-particle blocks: 1 (n <= 16), 2 (n <= 32) or 4 (n <= 64)
+__global__ __launch_bounds__(SVGD_THREADS) void svgd_update_mfma_f64_kernel(double *__restrict__ X,
+                                                                             const double *__restrict__ G,
+                                                                             double *__restrict__ H, size_t dim, size_t ld,
+                                                                             int n, const double *__restrict__ hdr,
+                                                                             const double *__restrict__ K,
+                                                                             const double *__restrict__ ksum, double eps,
+                                                                             double alpha, double one_minus_alpha,
+                                                                             double fudge, double sign) {
+    constexpr int MT = 64, KSMAX = 4 * IB, NR = 16 * IB;
+    constexpr int QPR = MT / 2, RSTEP = SVGD_THREADS / QPR, RPT = NR / RSTEP;    // row-major phases: 2 columns per lane
+    extern __shared__ __align__(16) unsigned char svgd_lds_raw[];
+    double *kfs = reinterpret_cast<double *>(svgd_lds_raw);          // [IB][KSMAX][64]
+    double *gs = kfs + IB * KSMAX * 64;                              // [NR][MT]
+    double *xs = gs + NR * MT;                                       // [NR][MT]
+    const SvgdGeom g = svgd_geom(n);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int KS = (n + 3) / 4;
+    const double h2 = hdr[2];
+    const double n_t = (double)n;
+    const bool vec = (ld % 2 == 0) && (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(G) |
+                                          reinterpret_cast<uintptr_t>(H)) & 15) == 0);
+    for (int idx = t; idx < IB * KSMAX * 64; idx += SVGD_THREADS) {
+        const int l = idx & 63, ks = (idx >> 6) % KSMAX, ib = (idx >> 6) / KSMAX;
+        const int i = 16 * ib + (l & 15), j = 4 * ks + (l >> 4);
+        kfs[idx] = (i < g.np16 && j < g.np16) ? K[(size_t)i * g.np16 + j] : 0.0;          // zero beyond n
+    }
+    const int q = t % QPR, r0 = t / QPR;
+    const size_t n_tiles = (dim + MT - 1) / MT;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t c0 = tile * MT;
+        const size_t cq = c0 + 2 * (size_t)q;
+        const bool fullq = vec && cq + 2 <= dim;
+        // ---- phase 1
+        f64x2 gv[RPT], xv[RPT], hv[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = r0 + RSTEP * k;
+            gv[k] = f64x2{0, 0};
+            xv[k] = gv[k];
+            hv[k] = gv[k];
+            if (r < n) {
+                const size_t at = (size_t)r * ld + cq;
+                if (fullq) {
+                    gv[k] = *reinterpret_cast<const f64x2 *>(G + at);
+                    xv[k] = *reinterpret_cast<const f64x2 *>(X + at);
+                    hv[k] = *reinterpret_cast<const f64x2 *>(H + at);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        if (cq + e < dim) { gv[k][e] = G[at + e]; xv[k][e] = X[at + e]; hv[k][e] = H[at + e]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = r0 + RSTEP * k;
+            *reinterpret_cast<f64x2 *>(gs + r * MT + 2 * q) = gv[k];
+            *reinterpret_cast<f64x2 *>(xs + r * MT + 2 * q) = xv[k];
+        }
+        __syncthreads();
+        // ---- phase 2: this wave's 16-column strip, all particle blocks
+        {
+            const int sc = wave * 16 + col;
+            f64x4 ag[IB], ax[IB];
+#pragma unroll
+            for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ag[ib][r] = 0.0; ax[ib][r] = 0.0; }
+            for (int ks = 0; ks < KS; ++ks) {
+                const double bg = gs[(4 * ks + kq) * MT + sc];
+                const double bx = xs[(4 * ks + kq) * MT + sc];
+#pragma unroll
+                for (int ib = 0; ib < IB; ++ib) {
+                    const double kf = kfs[(ib * KSMAX + ks) * 64 + lane];
+                    ag[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(kf, bg, ag[ib], 0, 0, 0);
+                    ax[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(kf, bx, ax[ib], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ib + kq + 4 * r;
+                    if (i < n) {
+                        const double x = xs[i * MT + sc];
+                        const double kg = (-ax[ib][r] + x * ksum[i]) / h2;         // svgd.py:176-181
+                        gs[i * MT + sc] = (ag[ib][r] + sign * kg) / n_t;           // svgd.py:124-127
+                    }
+                }
+        }
+        __syncthreads();
+        // ---- phase 3
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = r0 + RSTEP * k;
+            if (r < n && cq < dim) {
+                const f64x2 gt = *reinterpret_cast<const f64x2 *>(gs + r * MT + 2 * q);
+                const f64x2 xo = *reinterpret_cast<const f64x2 *>(xs + r * MT + 2 * q);
+                f64x2 xn, hn;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const double hnew = alpha * hv[k][e] + one_minus_alpha * (gt[e] * gt[e]);   // svgd.py:129-132
+                    const double adj = gt[e] / (fudge + sqrt_t(hnew));                          // svgd.py:134-137
+                    hn[e] = hnew;
+                    xn[e] = xo[e] - eps * adj;                                                  // svgd.py:139-143
+                }
+                const size_t at = (size_t)r * ld + cq;
+                if (fullq) {
+                    *reinterpret_cast<f64x2 *>(H + at) = hn;
+                    *reinterpret_cast<f64x2 *>(X + at) = xn;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        if (cq + e < dim) { H[at + e] = hn[e]; X[at + e] = xn[e]; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // S1 on the matrix cores (f32, 17 <= n <= 128): Gram matrix of the particles, G = X~ X~^T, accumulated over
 // 128-column tiles with v_mfma_f32_32x32x2_f32; |x_i - x_j|^2 = G_ii + G_jj - 2 G_ij afterwards (S3).
 // Every tile is first CENTRED per column (x~_ic = x_ic - mean_i x_ic; distances do not change): the Gram
@@ -999,6 +1133,108 @@ __global__ __launch_bounds__(64 * SVGD_RED_SLICES) void svgd_reduce_gram_kernel(
     if (ib != jb) gram[(size_t)j * g.np16 + i] = s;
 }
 
+// S1 on the matrix cores, f64 (17 <= n <= 64): as above with v_mfma_f64_16x16x4_f64 -- 16-particle blocks, 64-column
+// tiles, 4 columns per instruction; operand lane l = x~[16 ib + (l & 15)][4 ks + (l >> 4)], output register r of lane l =
+// G[16 ib + (l >> 4) + 4 r][16 jb + (l & 15)].
+constexpr int SVGD_GT64 = 64, SVGD_GP64 = SVGD_GT64 + 2;
+
+template <int IB>
+__global__ __launch_bounds__(SVGD_THREADS) void svgd_gram_mfma_f64_kernel(const double *__restrict__ X, size_t dim,
+                                                                           size_t ld, int n, double *__restrict__ parts) {
+    constexpr int NR = 16 * IB, QPR = SVGD_GT64 / 2, RSTEP = SVGD_THREADS / QPR, RPT = (NR + RSTEP - 1) / RSTEP;
+    constexpr int NPAIRB = IB * (IB + 1) / 2;
+    extern __shared__ __align__(16) unsigned char svgd_lds_raw[];
+    double *xs = reinterpret_cast<double *>(svgd_lds_raw);           // [NR][SVGD_GP64]; later the reduction buffer
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int q = t % QPR, r0 = t / QPR;
+    const bool vec = (ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const double inv_n = 1.0 / (double)n;
+    f64x4 acc[NPAIRB];
+#pragma unroll
+    for (int p = 0; p < NPAIRB; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[p][r] = 0.0;
+    const size_t n_tiles = (dim + SVGD_GT64 - 1) / SVGD_GT64;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t cq = tile * SVGD_GT64 + 2 * (size_t)q;
+        const bool fullq = vec && cq + 2 <= dim;
+        f64x2 xv[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = r0 + RSTEP * k;
+            xv[k] = f64x2{0, 0};
+            if (r < n) {
+                const size_t at = (size_t)r * ld + cq;
+                if (fullq) {
+                    xv[k] = *reinterpret_cast<const f64x2 *>(X + at);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        if (cq + e < dim) xv[k][e] = X[at + e];
+                }
+            }
+        }
+        __syncthreads();                                            // the previous tile's operands are consumed
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+            if (r0 + RSTEP * k < NR) *reinterpret_cast<f64x2 *>(xs + (r0 + RSTEP * k) * SVGD_GP64 + 2 * q) = xv[k];
+        __syncthreads();
+        if (t < SVGD_GT64) {                                        // centre column t of the tile
+            double s = 0.0;
+            for (int r = 0; r < n; ++r) s += xs[r * SVGD_GP64 + t];
+            const double m = s * inv_n;
+            for (int r = 0; r < n; ++r) xs[r * SVGD_GP64 + t] -= m;
+        }
+        __syncthreads();
+        for (int ks = wave; ks < SVGD_GT64 / 4; ks += SVGD_THREADS / 64) {
+            double a[IB];
+#pragma unroll
+            for (int ib = 0; ib < IB; ++ib) a[ib] = xs[(16 * ib + col) * SVGD_GP64 + 4 * ks + kq];
+            int p = 0;
+#pragma unroll
+            for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+                for (int jb = ib; jb < IB; ++jb, ++p)
+                    acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ib], a[jb], acc[p], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    for (int w = 0; w < SVGD_THREADS / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int p = 0; p < NPAIRB; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double *slot = xs + (p * 4 + r) * 64 + lane;
+                    *slot = (w == 0) ? acc[p][r] : (*slot + acc[p][r]);
+                }
+        }
+        __syncthreads();
+    }
+    double *out = parts + (size_t)blockIdx.x * (NPAIRB * 256);
+    for (int idx = t; idx < NPAIRB * 256; idx += SVGD_THREADS) out[idx] = xs[idx];
+}
+
+template <int IB>
+__global__ __launch_bounds__(64 * SVGD_RED_SLICES) void svgd_reduce_gram_f64_kernel(const double *__restrict__ parts,
+                                                                                     int n_parts, int n,
+                                                                                     double *__restrict__ gram) {
+    constexpr int NPAIRB = IB * (IB + 1) / 2;
+    const SvgdGeom g = svgd_geom(n);
+    double s;
+    int idx;
+    if (!reduce_parts(parts, n_parts, NPAIRB * 256, s, idx)) return;
+    int p = idx >> 8, ib = 0;
+    while (p >= IB - ib) { p -= IB - ib; ++ib; }
+    const int jb = ib + p;
+    const int r = (idx >> 6) & 3, l = idx & 63;
+    const int i = 16 * ib + (l >> 4) + 4 * r, j = 16 * jb + (l & 15);
+    if (i >= n || j >= n) return;
+    gram[(size_t)i * g.np16 + j] = s;
+    if (ib != jb) gram[(size_t)j * g.np16 + i] = s;
+}
+
 template <typename T>
 __global__ void svgd_copy_kernel(const T *__restrict__ K, int n, int np16, T *__restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1064,7 +1300,33 @@ inline int svgd_gram_launch(const float *X, size_t n, size_t dim, size_t ld, flo
     if (n <= 64) return svgd_gram_launch_ib<2>(X, n, dim, ld, parts, gram, st);
     return svgd_gram_launch_ib<4>(X, n, dim, ld, parts, gram, st);
 }
-[[maybe_unused]] inline int svgd_gram_launch(const double *, size_t, size_t, size_t, double *, double *, hipStream_t) { return 0; }
+template <int IB>
+int svgd_gram_launch_f64_ib(const double *X, size_t n, size_t dim, size_t ld, double *parts, double *gram, hipStream_t st) {
+    constexpr int NPAIRB = IB * (IB + 1) / 2;
+    size_t lds_bytes = (size_t)16 * IB * SVGD_GP64 * sizeof(double);
+    const size_t red_bytes = (size_t)NPAIRB * 256 * sizeof(double);
+    if (lds_bytes < red_bytes) lds_bytes = red_bytes;
+    const size_t n_tiles = (dim + SVGD_GT64 - 1) / SVGD_GT64;
+    const size_t cap = IB <= 2 ? 2048 : 1024;
+    const int n_parts = (int)(n_tiles < cap ? n_tiles : cap);
+    hipLaunchKernelGGL((svgd_gram_mfma_f64_kernel<IB>), dim3(n_parts), dim3(SVGD_THREADS), lds_bytes, st, X, dim, ld,
+                       (int)n, parts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch svgd_gram_mfma_f64_kernel");
+    hipLaunchKernelGGL((svgd_reduce_gram_f64_kernel<IB>), dim3(NPAIRB * 256 / 64), dim3(64 * SVGD_RED_SLICES), 0, st, parts,
+                       n_parts, (int)n, gram);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_reduce_gram_f64_kernel");
+}
+
+constexpr int SVGD_NOT_HANDLED = -1000;
+
+// f64: matrix-core Gram form up to 64 particles; beyond, the difference-form kernel
+inline int svgd_gram_launch(const double *X, size_t n, size_t dim, size_t ld, double *parts, double *gram, hipStream_t st) {
+    if (n <= 32) return svgd_gram_launch_f64_ib<2>(X, n, dim, ld, parts, gram, st);
+    if (n <= 64) return svgd_gram_launch_f64_ib<4>(X, n, dim, ld, parts, gram, st);
+    return SVGD_NOT_HANDLED;
+}
 
 template <typename T>
 int svgd_kernel_matrix_impl(const T *X, size_t n, size_t dim, size_t ld, T *ws, hipStream_t st) {
@@ -1073,12 +1335,10 @@ int svgd_kernel_matrix_impl(const T *X, size_t n, size_t dim, size_t ld, T *ws, 
     T *parts = ws + w.parts;
     hipError_t e;
     int from_gram = 0;
-    if constexpr (sizeof(T) == 4) {
-        if (n >= 17) {                                           // n <= 16: the register kernel S1s is faster
-            const int rc = svgd_gram_launch(X, n, dim, ld, parts, ws + w.K, st);
-            if (rc) return rc;
-            from_gram = 1;
-        }
+    if (n >= 17) {                                               // n <= 16: the register kernel S1s is faster
+        const int rc = svgd_gram_launch(X, n, dim, ld, parts, ws + w.K, st);
+        if (rc != 0 && rc != SVGD_NOT_HANDLED) return rc;
+        from_gram = rc == 0;                                     // not handled: f64 with more than 64 particles
     }
     if (from_gram) {
     } else if (n <= 16) {
@@ -1151,8 +1411,8 @@ int svgd_apply_impl(T *X, const T *G, T *H, T *kgrad_out, size_t out_ld, size_t 
     if (n <= 8)
         return svgd_apply_small<T, 8, SmallCfg<T>::CPL8, UPDATE>(X, G, H, kgrad_out, out_ld, n, dim, ld, eps, alpha, fudge,
                                                                  sign, ws, st);
-    // f32 steps with 9..64 particles run on the matrix cores (measured: 763 vs 992 us at 16 x 10 M)
-    if (n <= 16 && !(UPDATE && sizeof(T) == 4))
+    // f32 steps with 9..128 particles run on the matrix cores (measured: 763 vs 992 us at 16 x 10 M)
+    if (n <= 16 && !UPDATE)
         return svgd_apply_small<T, 16, SmallCfg<T>::CPL16, UPDATE>(X, G, H, kgrad_out, out_ld, n, dim, ld, eps, alpha,
                                                                    fudge, sign, ws, st);
     if constexpr (UPDATE && sizeof(T) == 4) {
@@ -1178,6 +1438,28 @@ int svgd_apply_impl(T *X, const T *G, T *H, T *kgrad_out, size_t out_ld, size_t 
             void *args[] = {&X, &G, &H, &dim, &ld, &n_i, &hdr, &Kp, &ksum, &eps32, &a32, &oma32, &fudge32, &sign32};
             e = hipLaunchKernel(fn, dim3(grid), dim3(SVGD_THREADS), args, lds_bytes, st);
             return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_update_mfma_kernel");
+        }
+    }
+    if constexpr (UPDATE && sizeof(T) == 8) {
+        if (n <= 64) {
+            const SvgdWs w = svgd_ws((int)n);
+            const int ib = n <= 16 ? 1 : n <= 32 ? 2 : 4;
+            const size_t n_tiles = (dim + 63) / 64;
+            const size_t lds_bytes = ((size_t)ib * 4 * ib * 64 + (size_t)2 * 16 * ib * 64) * sizeof(double);
+            const size_t cap = ib <= 2 ? 1024 : 256;
+            const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
+            const void *fn = ib == 1   ? reinterpret_cast<const void *>(&svgd_update_mfma_f64_kernel<1>)
+                             : ib == 2 ? reinterpret_cast<const void *>(&svgd_update_mfma_f64_kernel<2>)
+                                       : reinterpret_cast<const void *>(&svgd_update_mfma_f64_kernel<4>);
+            hipError_t e = hipSuccess;
+            if (lds_bytes > 64 * 1024) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(svgd_update_mfma_f64_kernel)");
+            double a64 = alpha, oma64 = 1.0 - alpha, eps64 = eps, fudge64 = fudge, sign64 = sign;
+            int n_i = (int)n;
+            const double *hdr = ws + w.hdr, *Kp = ws + w.K, *ksum = ws + w.ksum;
+            void *args[] = {&X, &G, &H, &dim, &ld, &n_i, &hdr, &Kp, &ksum, &eps64, &a64, &oma64, &fudge64, &sign64};
+            e = hipLaunchKernel(fn, dim3(grid), dim3(SVGD_THREADS), args, lds_bytes, st);
+            return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_update_mfma_f64_kernel");
         }
     }
     if (n <= 32)
