@@ -347,7 +347,9 @@ def run_svgd(args, dev, rank, world, dist):
             "roofline": {"bound": "hbm", "kernel": "sgmcmc_svgd_step_f32 (svgd_sqdist_small_kernel + svgd_update_mfma_kernel; "
                                                    "per-kernel times in profiles/r01_svgd_kernel_stats.md)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         # PMC passes of profiles/r01_svgd_pmc_traffic.md: S1 4.00 B, S4 12.00 + 8.00 B per element
+                         "traffic": int(24.0 * n * dim), "traffic_source": "profiles/r01_svgd_pmc_traffic.md",
                          "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch_mean": round(us, 2),
                          "launches_timed": len(pairs),
                          "timing": "hipEvent pair around every step (4 launches) of the timed region"},
