@@ -250,6 +250,24 @@ int sgmcmc_bnn_fused_sghmc_steps_f64(double *theta, double *V, double *grad, dou
                                      uint64_t burn_in_steps, uint64_t seed_base, const double *xi, double *cost_out,
                                      sgmcmc_stream_t stream);
 
+/* The same with the preconditioned-SGLD update (K2, pysgmcmc/samplers/sgld.py:149-211) instead of SGHMC: no
+ * momentum row; `A` as in sgmcmc_sgld_step_*. The reference's BNN accepts both samplers
+ * (pysgmcmc/sampling.py:40,64).                                                                    */
+int sgmcmc_bnn_fused_sgld_steps_f32(float *theta, float *grad, float *tau, float *g, float *v_hat, float *minv,
+                                    size_t n_params, size_t chain_stride, int n_chains, const int *layer_sizes,
+                                    int n_layers, const float *X, const float *y, size_t n_data,
+                                    const int *window_starts, int batch, double batch_size, double n_examples,
+                                    double wdecay, double prior_mean, double prior_var, float eps, float scale_grad,
+                                    float A, uint64_t first_step, uint64_t n_steps, uint64_t burn_in_steps,
+                                    uint64_t seed_base, const float *xi, float *cost_out, sgmcmc_stream_t stream);
+int sgmcmc_bnn_fused_sgld_steps_f64(double *theta, double *grad, double *tau, double *g, double *v_hat, double *minv,
+                                    size_t n_params, size_t chain_stride, int n_chains, const int *layer_sizes,
+                                    int n_layers, const double *X, const double *y, size_t n_data,
+                                    const int *window_starts, int batch, double batch_size, double n_examples,
+                                    double wdecay, double prior_mean, double prior_var, double eps, double scale_grad,
+                                    double A, uint64_t first_step, uint64_t n_steps, uint64_t burn_in_steps,
+                                    uint64_t seed_base, const double *xi, double *cost_out, sgmcmc_stream_t stream);
+
 /* ---- Stein variational gradient descent: pysgmcmc/samplers/svgd.py:118-181 -----------------------
  * The n particles are the rows of a [n_particles x ld] device matrix (row pitch ld >= dim elements; with
  * ld a multiple of 4 and 16-byte aligned bases every access is 16 bytes wide -- the sampler pads ld to 64);

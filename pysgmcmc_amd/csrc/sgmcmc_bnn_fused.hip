@@ -62,6 +62,7 @@ struct FusedArgs {
     int batch;
     double batch_size, n_examples, wp_den, lvp_den, ln_prior_mean, ln_prior_var, wdecay;
     T eps_e2, c1, c3, e4, mdecay, grad_decay;            // host-derived scalars of K1
+    T sgld_eps, sgld_A, sgld_a_eff, sgld_two_eps, sgld_den;   // host-derived scalars of K2 (SGLD chains)
     uint64_t first_step, n_steps, burn_in_steps, seed_base;
     const T *xi;                                         // nullable: [n_steps][n_params], chain 0
     T *cost_out;                                         // [n_chains][n_steps]
@@ -84,28 +85,21 @@ __device__ __forceinline__ double block_sum(double v, double *red)
     return red[16];
 }
 
-template <typename T, bool ADAPT, bool INJECT>
-__device__ __forceinline__ double update_phase(const FusedArgs<T> &a, T *theta, T *V, const T *grad, T *tau, T *g, T *vh,
-                                               T *minv, const T *xi, uint64_t seed, uint64_t step)
+template <typename Op>
+__device__ __forceinline__ double run_update(Op &op, size_t n_params)
 {
-    NoiseKey nk;
-    nk.k0 = (uint32_t)seed; nk.k1 = (uint32_t)(seed >> 32);
-    nk.s0 = (uint32_t)step; nk.s1 = (uint32_t)(step >> 32);
-    nk.step_dev = nullptr;
-    SghmcOp<T, ADAPT, INJECT> op{theta, V, grad, tau, g, vh, minv, nullptr, xi,
-                                 a.eps_e2, a.c1, a.c3, a.e4, a.mdecay, a.grad_decay, nk, nullptr};
-    const size_t nq_full = a.n_params / 4;
-    const int tail = (int)(a.n_params % 4);
+    const size_t nq_full = n_params / 4;
+    const int tail = (int)(n_params % 4);
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (size_t q = threadIdx.x; q < nq_full; q += blockDim.x) {
-        typename SghmcOp<T, ADAPT, INJECT>::Regs R;
+        typename Op::Regs R;
         op.template load_vec<false>(q, R);
         op.compute(q, R);
         op.template store_vec<false>(q, R);
         op.accumulate(R, 4, acc);
     }
     if (tail && threadIdx.x == blockDim.x - 1) {
-        typename SghmcOp<T, ADAPT, INJECT>::Regs R;
+        typename Op::Regs R;
         op.load_part_(nq_full, tail, R);
         op.compute(nq_full, R);
         op.store_part_(nq_full, tail, R);
@@ -114,7 +108,27 @@ __device__ __forceinline__ double update_phase(const FusedArgs<T> &a, T *theta, 
     return acc[0];                                        // this lane's share of sum(theta'^2)
 }
 
-template <typename T>
+// KIND 0: SGHMC (K1's operator, sghmc.py:165-251); KIND 1: preconditioned SGLD (K2's operator, sgld.py:149-211)
+template <typename T, int KIND, bool ADAPT, bool INJECT>
+__device__ __forceinline__ double update_phase(const FusedArgs<T> &a, T *theta, T *V, const T *grad, T *tau, T *g, T *vh,
+                                               T *minv, const T *xi, uint64_t seed, uint64_t step)
+{
+    NoiseKey nk;
+    nk.k0 = (uint32_t)seed; nk.k1 = (uint32_t)(seed >> 32);
+    nk.s0 = (uint32_t)step; nk.s1 = (uint32_t)(step >> 32);
+    nk.step_dev = nullptr;
+    if (KIND == 0) {
+        SghmcOp<T, ADAPT, INJECT> op{theta, V, grad, tau, g, vh, minv, nullptr, xi,
+                                     a.eps_e2, a.c1, a.c3, a.e4, a.mdecay, a.grad_decay, nk, nullptr};
+        return run_update(op, a.n_params);
+    } else {
+        SgldOp<T, ADAPT, INJECT> op{theta, grad, tau, g, vh, minv, nullptr, xi, a.sgld_eps, a.sgld_A, a.sgld_a_eff,
+                                    a.sgld_two_eps, a.sgld_den, a.grad_decay, nk, nullptr};
+        return run_update(op, a.n_params);
+    }
+}
+
+template <typename T, int KIND>
 __global__ void __launch_bounds__(FUSED_THREADS) bnn_fused_sghmc_kernel(const FusedArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -122,7 +136,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) bnn_fused_sghmc_kernel(const Fu
     T *lds = reinterpret_cast<T *>(smem_raw + 160);
     const int chain = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const size_t cs = (size_t)chain * a.chain_stride;
-    T *theta = a.theta + cs, *V = a.V + cs, *grad = a.grad + cs;
+    T *theta = a.theta + cs, *V = KIND == 0 ? a.V + cs : nullptr, *grad = a.grad + cs;
     T *tau = a.tau + cs, *g = a.g + cs, *vh = a.vh + cs, *minv = a.minv + cs;
     const int L = a.n_layers, B = a.batch;
     const uint64_t seed = a.seed_base + (uint64_t)chain;
@@ -220,31 +234,32 @@ __global__ void __launch_bounds__(FUSED_THREADS) bnn_fused_sghmc_kernel(const Fu
             }
             __syncthreads();
         }
-        // ---- fused SGHMC update (K1's operator) + sum(theta'^2)
+        // ---- fused update (K1's or K2's operator) + sum(theta'^2)
         const bool adapt = step < a.burn_in_steps || a.burn_in_steps == 0;
         const T *xi = (a.xi != nullptr && chain == 0) ? a.xi + (size_t)t * a.n_params : nullptr;
         double share;
         if (adapt) {
-            share = xi ? update_phase<T, true, true>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step)
-                       : update_phase<T, true, false>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step);
+            share = xi ? update_phase<T, KIND, true, true>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step)
+                       : update_phase<T, KIND, true, false>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step);
         } else {
-            share = xi ? update_phase<T, false, true>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step)
-                       : update_phase<T, false, false>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step);
+            share = xi ? update_phase<T, KIND, false, true>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step)
+                       : update_phase<T, KIND, false, false>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step);
         }
         __threadfence_block();
         tsq = block_sum(share, red);                      // barriers inside: the new theta is visible to the block
     }
 }
 
-template <typename T>
+template <typename T, int KIND>
 int bnn_fused_steps(T *theta, T *V, T *grad, T *tau, T *g, T *v_hat, T *minv, size_t n_params, size_t chain_stride,
                     int n_chains, const int *layer_sizes, int n_layers, const T *X, const T *y, size_t n_data,
                     const int *window_starts, int batch, double batch_size, double n_examples, double wdecay,
-                    double prior_mean, double prior_var, T eps, T scale_grad, T mdecay, uint64_t first_step,
+                    double prior_mean, double prior_var, T eps, T scale_grad, T mdecay /* SGLD: A */, uint64_t first_step,
                     uint64_t n_steps, uint64_t burn_in_steps, uint64_t seed_base, const T *xi, T *cost_out, hipStream_t st)
 {
     if (n_steps == 0 || n_chains == 0) return 0;
-    if (!theta || !V || !grad || !tau || !g || !v_hat || !minv || !layer_sizes || !X || !y || !window_starts || !cost_out)
+    if (!theta || (KIND == 0 && !V) || !grad || !tau || !g || !v_hat || !minv || !layer_sizes || !X || !y || !window_starts ||
+        !cost_out)
         return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: NULL argument");
     if (n_layers < 1 || n_layers > FUSED_MAX_LAYERS) return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: 1..8 layers");
     if (layer_sizes[n_layers] != 1) return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: the last layer must have one unit");
@@ -252,7 +267,7 @@ int bnn_fused_steps(T *theta, T *V, T *grad, T *tau, T *g, T *v_hat, T *minv, si
     if (xi && (n_params % 4) != 0) return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: injected xi needs n_params %% 4 == 0");
     if (n_chains > 1 && (chain_stride < n_params || (chain_stride % 4) != 0))
         return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: chain_stride must be >= n_params and a multiple of 4");
-    T *rows[7] = {theta, V, grad, tau, g, v_hat, minv};
+    T *rows[7] = {theta, KIND == 0 ? V : theta, grad, tau, g, v_hat, minv};
     for (T *p : rows)
         if (reinterpret_cast<uintptr_t>(p) & 15u) return fail(SGMCMC_EINVAL, "bnn_fused_sghmc_steps: rows must be 16-B aligned");
     FusedArgs<T> a;
@@ -289,15 +304,25 @@ int bnn_fused_steps(T *theta, T *V, T *grad, T *tau, T *g, T *v_hat, T *minv, si
     a.c3 = T(2) * std::pow(eps_s, T(3));
     a.e4 = std::pow(eps_s, T(4));
     a.mdecay = mdecay;
+    // K2's host-derived scalars (sgld.py:106-108,186-191), same op order as sgld_step in sgmcmc_kernels.hip
+    {
+        const T A = mdecay;                               // the SGLD entry passes A in this slot
+        const T sgn = (scale_grad > T(0)) ? T(1) : ((scale_grad < T(0)) ? T(-1) : T(0));
+        a.sgld_den = scale_grad + ((T(2) * sgn) * T(1e-16) + T(1e-16));
+        a.sgld_two_eps = T(2) * eps;
+        a.sgld_a_eff = A - T(0);
+        a.sgld_eps = eps;
+        a.sgld_A = A;
+    }
     a.grad_decay = (T)(wdecay / (a.wp_den * n_examples));   // weight-prior gradient, folded into the update
     a.first_step = first_step; a.n_steps = n_steps; a.burn_in_steps = burn_in_steps; a.seed_base = seed_base;
     a.xi = xi; a.cost_out = cost_out;
     if (lds_bytes > 64 * 1024) {
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&bnn_fused_sghmc_kernel<T>),
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&bnn_fused_sghmc_kernel<T, KIND>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e0 != hipSuccess) return hip_fail(e0, "hipFuncSetAttribute(bnn_fused_sghmc_kernel)");
     }
-    hipLaunchKernelGGL((bnn_fused_sghmc_kernel<T>), dim3((unsigned)n_chains), dim3(FUSED_THREADS), lds_bytes, st, a);
+    hipLaunchKernelGGL((bnn_fused_sghmc_kernel<T, KIND>), dim3((unsigned)n_chains), dim3(FUSED_THREADS), lds_bytes, st, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch bnn_fused_sghmc_kernel");
 }
@@ -314,7 +339,7 @@ int sgmcmc_bnn_fused_sghmc_steps_f32(float *theta, float *V, float *grad, float 
                                      float mdecay, uint64_t first_step, uint64_t n_steps, uint64_t burn_in_steps,
                                      uint64_t seed_base, const float *xi, float *cost_out, sgmcmc_stream_t stream)
 {
-    return bnn_fused_steps<float>(theta, V, grad, tau, g, v_hat, minv, n_params, chain_stride, n_chains, layer_sizes,
+    return bnn_fused_steps<float, 0>(theta, V, grad, tau, g, v_hat, minv, n_params, chain_stride, n_chains, layer_sizes,
                                   n_layers, X, y, n_data, window_starts, batch, batch_size, n_examples, wdecay,
                                   prior_mean, prior_var, eps, scale_grad, mdecay, first_step, n_steps, burn_in_steps,
                                   seed_base, xi, cost_out, static_cast<hipStream_t>(stream));
@@ -328,10 +353,37 @@ int sgmcmc_bnn_fused_sghmc_steps_f64(double *theta, double *V, double *grad, dou
                                      uint64_t burn_in_steps, uint64_t seed_base, const double *xi, double *cost_out,
                                      sgmcmc_stream_t stream)
 {
-    return bnn_fused_steps<double>(theta, V, grad, tau, g, v_hat, minv, n_params, chain_stride, n_chains, layer_sizes,
+    return bnn_fused_steps<double, 0>(theta, V, grad, tau, g, v_hat, minv, n_params, chain_stride, n_chains, layer_sizes,
                                    n_layers, X, y, n_data, window_starts, batch, batch_size, n_examples, wdecay,
                                    prior_mean, prior_var, eps, scale_grad, mdecay, first_step, n_steps, burn_in_steps,
                                    seed_base, xi, cost_out, static_cast<hipStream_t>(stream));
+}
+
+int sgmcmc_bnn_fused_sgld_steps_f32(float *theta, float *grad, float *tau, float *g, float *v_hat, float *minv,
+                                    size_t n_params, size_t chain_stride, int n_chains, const int *layer_sizes,
+                                    int n_layers, const float *X, const float *y, size_t n_data,
+                                    const int *window_starts, int batch, double batch_size, double n_examples,
+                                    double wdecay, double prior_mean, double prior_var, float eps, float scale_grad,
+                                    float A, uint64_t first_step, uint64_t n_steps, uint64_t burn_in_steps,
+                                    uint64_t seed_base, const float *xi, float *cost_out, sgmcmc_stream_t stream)
+{
+    return bnn_fused_steps<float, 1>(theta, nullptr, grad, tau, g, v_hat, minv, n_params, chain_stride, n_chains,
+                                     layer_sizes, n_layers, X, y, n_data, window_starts, batch, batch_size, n_examples,
+                                     wdecay, prior_mean, prior_var, eps, scale_grad, A, first_step, n_steps, burn_in_steps,
+                                     seed_base, xi, cost_out, static_cast<hipStream_t>(stream));
+}
+int sgmcmc_bnn_fused_sgld_steps_f64(double *theta, double *grad, double *tau, double *g, double *v_hat, double *minv,
+                                    size_t n_params, size_t chain_stride, int n_chains, const int *layer_sizes,
+                                    int n_layers, const double *X, const double *y, size_t n_data,
+                                    const int *window_starts, int batch, double batch_size, double n_examples,
+                                    double wdecay, double prior_mean, double prior_var, double eps, double scale_grad,
+                                    double A, uint64_t first_step, uint64_t n_steps, uint64_t burn_in_steps,
+                                    uint64_t seed_base, const double *xi, double *cost_out, sgmcmc_stream_t stream)
+{
+    return bnn_fused_steps<double, 1>(theta, nullptr, grad, tau, g, v_hat, minv, n_params, chain_stride, n_chains,
+                                      layer_sizes, n_layers, X, y, n_data, window_starts, batch, batch_size, n_examples,
+                                      wdecay, prior_mean, prior_var, eps, scale_grad, A, first_step, n_steps,
+                                      burn_in_steps, seed_base, xi, cost_out, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -16,7 +16,7 @@ __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
     "set_launch_config", "get_launch_config", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
-    "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
+    "bnn_fused_sgld_steps", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
 ]
 
 _SFX = {torch.float32: "f32", torch.float64: "f64"}
@@ -268,6 +268,32 @@ def bnn_fused_sghmc_steps(theta, V, grad, tau, g, v_hat, minv, layer_sizes, X, y
                int(first_step), int(n_steps), int(burn_in_steps), int(seed_base), _ptr(xi), _ptr(cost_out),
                _stream(theta))
     check(rc, "sgmcmc_bnn_fused_sghmc_steps")
+    return cost_out
+
+
+def bnn_fused_sgld_steps(theta, grad, tau, g, v_hat, minv, layer_sizes, X, y, window_starts, batch,
+                         batch_size, n_examples, wdecay, prior_mean, prior_var, eps, scale_grad, A,
+                         first_step, n_steps, burn_in_steps, seed_base, cost_out, xi=None, n_chains=1,
+                         chain_stride=None):
+    """The fused small-model kernel with the preconditioned-SGLD update (``sgmcmc_bnn_fused_sgld_steps_*``)."""
+    import ctypes
+    f = getattr(lib(), "sgmcmc_bnn_fused_sgld_steps_" + _sfx(theta))
+    sizes = [int(v) for v in layer_sizes]
+    n_layers = len(sizes) - 1
+    n_params = sum(sizes[l] * sizes[l + 1] + sizes[l + 1] for l in range(n_layers)) + 1
+    if chain_stride is None:
+        chain_stride = theta.numel() if n_chains == 1 else theta.numel() // n_chains
+    if window_starts.dtype != torch.int32 or window_starts.numel() != n_chains * n_steps:
+        raise TypeError("window_starts must be an int32 device tensor of n_chains * n_steps entries")
+    arr = (ctypes.c_int * len(sizes))(*sizes)
+    with _on(theta):
+        rc = f(_ptr(theta), _ptr(grad), _ptr(tau), _ptr(g), _ptr(v_hat), _ptr(minv), n_params,
+               int(chain_stride), int(n_chains), arr, n_layers, _ptr(X), _ptr(y), int(X.shape[0]),
+               _ptr(window_starts), int(batch), float(batch_size), float(n_examples), float(wdecay),
+               float(prior_mean), float(prior_var), float(eps), float(scale_grad), float(A),
+               int(first_step), int(n_steps), int(burn_in_steps), int(seed_base), _ptr(xi), _ptr(cost_out),
+               _stream(theta))
+    check(rc, "sgmcmc_bnn_fused_sgld_steps")
     return cost_out
 
 

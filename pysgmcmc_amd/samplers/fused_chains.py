@@ -11,18 +11,17 @@ the shared memory); chain ``c`` uses Philox seed ``seed_0 + c`` and its own wind
 import numpy as np
 import torch
 
-from pysgmcmc_amd import kernels
 from pysgmcmc_amd.samplers.sghmc import SGHMCSampler
 
 __all__ = ("FusedBNNChains",)
 
 
 class FusedBNNChains(object):
-    """Group of SGHMC chains that fit the fused small-model kernel.
+    """Group of SGHMC (or of SGLD) chains that fit the fused small-model kernel.
 
     Parameters
     ----------
-    samplers : list of SGHMCSampler
+    samplers : list of SGHMCSampler (or list of SGLDSampler)
         Chains over the SAME dataset and network shape, built with ``seed = s, s + 1, s + 2, ...``, equal
         hyper-parameters and ``fused_bnn_available()``; all at the same iteration.
     """
@@ -32,7 +31,7 @@ class FusedBNNChains(object):
         assert samplers, "FusedBNNChains needs at least one chain"
         first = samplers[0]
         for c, s in enumerate(samplers):
-            if not isinstance(s, SGHMCSampler) or not s.fused_bnn_available():
+            if type(s) is not type(first) or not hasattr(s, "_fused_bnn_launch") or not s.fused_bnn_available():
                 raise ValueError("chain %d does not fit the fused small-model kernel" % c)
             same = (s._bnn_layer_sizes() == first._bnn_layer_sizes()
                     and s._torch_dtype == first._torch_dtype and s.device == first.device
@@ -40,7 +39,9 @@ class FusedBNNChains(object):
                     and s.batch_generator.y_dev.data_ptr() == first.batch_generator.y_dev.data_ptr()
                     and s.batch_generator.batch_size == first.batch_generator.batch_size
                     and s.n_iterations == first.n_iterations and s.burn_in_steps == first.burn_in_steps
-                    and s.scale_grad == first.scale_grad and s.mdecay == first.mdecay
+                    and s.scale_grad == first.scale_grad
+                    and getattr(s, "mdecay", None) == getattr(first, "mdecay", None)
+                    and getattr(s, "A", None) == getattr(first, "A", None)
                     and all(getattr(s.cost_fun, k) == getattr(first.cost_fun, k)
                             for k in ("batch_size", "n_examples", "wdecay", "prior_mean", "prior_var")))
             if not same:
@@ -84,16 +85,13 @@ class FusedBNNChains(object):
         starts = np.stack([s.batch_generator.next_starts(n_steps) for s in self.samplers]).astype(np.int32)
         starts = torch.as_tensor(starts).to(first.device).reshape(-1)
         costs = torch.empty(self.n_chains * n_steps, dtype=first._torch_dtype, device=first.device)
-        rows = [a.row(k) for k in ("theta", "V", "grad", "tau", "g", "v_hat", "minv")]
+        rows = [a.row(k) for k in first._FUSED_ROWS]
         # chain 0's rows are the bases; the kernel adds chain * chain_stride. Hand it views that span all chains.
         span = (self.n_chains - 1) * self.chain_stride + a.n
         bases = [torch.as_strided(self.storage, (span,), (1,), r.storage_offset() - self.storage.storage_offset())
                  for r in rows]
-        kernels.bnn_fused_sghmc_steps(
-            *bases, first._bnn_layer_sizes(), gen.x_dev, gen.y_dev.reshape(-1), starts, gen.batch_size,
-            cost.batch_size, cost.n_examples, cost.wdecay, cost.prior_mean, cost.prior_var,
-            eps, first.scale_grad, first.mdecay, first.n_iterations, n_steps, max(first.burn_in_steps, 0),
-            first._philox_seed, costs, n_chains=self.n_chains, chain_stride=self.chain_stride)
+        first._fused_bnn_launch(starts, costs, eps, n_steps, n_chains=self.n_chains, chain_stride=self.chain_stride,
+                                bases=bases)
         costs = costs.view(self.n_chains, n_steps)
         for c, s in enumerate(self.samplers):
             s.n_iterations += n_steps

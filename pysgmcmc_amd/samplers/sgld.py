@@ -6,6 +6,7 @@ The per-step op chain ``sgld.py:149-211`` is kernel K2,
 import torch
 
 from pysgmcmc_amd import kernels
+from pysgmcmc_amd.samplers._fused_bnn import FusedBNNStepsMixin
 from pysgmcmc_amd.samplers.base_classes import BurnInMCMCSampler
 from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
 
@@ -18,11 +19,12 @@ __all__ = ("SGLDSampler", "STRICT_REFERENCE_QUIRKS")
 STRICT_REFERENCE_QUIRKS = False
 
 
-class SGLDSampler(BurnInMCMCSampler):
+class SGLDSampler(FusedBNNStepsMixin, BurnInMCMCSampler):
     """Stochastic Gradient Langevin Dynamics with the RMSprop-like preconditioner
     adapted during burn-in (keywords/defaults as ``sgld.py:32-35``)."""
 
     _STATE_ROWS = ("tau", "g", "v_hat", "minv")
+    _FUSED_ROWS = ("theta", "grad", "tau", "g", "v_hat", "minv")          # row order of the fused small-model kernel
 
     def __init__(self, params, cost_fun, batch_generator=None,
                  stepsize_schedule=ConstantStepsizeSchedule(0.01),
@@ -48,3 +50,13 @@ class SGLDSampler(BurnInMCMCSampler):
         if self._stats is not None:
             self._stats_valid = True          # the workspace now holds this step's per-block partials
             self._stats_out_valid = False     # K7 runs lazily (sampler.stats); the BNN head reads the partials
+
+    # ------------------------------------------------------------------ fused small-model path (see _fused_bnn.py)
+    def _fused_bnn_launch(self, starts, costs, eps, n_steps, n_chains=1, chain_stride=None, bases=None):
+        gen, cost, a = self.batch_generator, self.cost_fun, self.arena
+        rows = bases or [a.row(k) for k in self._FUSED_ROWS]
+        kernels.bnn_fused_sgld_steps(
+            *rows, self._bnn_layer_sizes(), gen.x_dev, gen.y_dev.reshape(-1), starts, gen.batch_size,
+            cost.batch_size, cost.n_examples, cost.wdecay, cost.prior_mean, cost.prior_var,
+            eps, self.scale_grad, self.A, self.n_iterations, n_steps, max(self.burn_in_steps, 0),
+            self._philox_seed, costs, n_chains=n_chains, chain_stride=chain_stride)

@@ -183,3 +183,65 @@ def test_fused_chain_group_equals_individual_chains(gpu):
     other = FusedBNNChains.for_dataset(X, y, 2, **dict(kw, seed=90)).samplers
     with pytest.raises(ValueError):
         FusedBNNChains([group.samplers[0], other[0]])
+
+
+def _sgld_chain(gpu, dt, seed=5, burn=6):
+    from pysgmcmc_amd.samplers import SGLDSampler
+    rng = np.random.RandomState(1)
+    X = rng.rand(100, 1)
+    y = np.sinc(X * 10 - 5).sum(axis=1)
+    xp, yp = Placeholder(dtype=dt, device=gpu), Placeholder(dtype=dt, device=gpu)
+    params = init_mlp_params(1, hidden=(50, 50, 50), seed=3, dtype=dt, device=gpu)
+    s = SGLDSampler(params=params, cost_fun=BNNCost(xp, yp, batch_size=20, n_examples=100),
+                    batch_generator=generate_batches(X, y, xp, yp, 20, seed=1),
+                    stepsize_schedule=ConstantStepsizeSchedule(1e-3), burn_in_steps=burn, A=1.0,
+                    scale_grad=100.0, session=gpu, dtype=dt, seed=seed)
+    s.sample_format = "view"
+    return s
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_fused_sgld_steps_track_the_gemm_path(gpu, dt):
+    """The fused kernel with K2's operator (preconditioned SGLD): same chain as next() up to the rounding of the
+    matrix products; chunking is bit-exact; the burn-in switch happens inside a launch."""
+    a, b, c = _sgld_chain(gpu, dt), _sgld_chain(gpu, dt), _sgld_chain(gpu, dt)
+    assert b.fused_bnn_available()
+    costs_a = torch.stack([cst.reshape(()).clone() for _, cst in islice(a, 14)])
+    costs_b = b.fused_bnn_steps(14)
+    costs_c = torch.cat([c.fused_bnn_steps(4), c.fused_bnn_steps(10)])
+    tol = 2e-4 if dt == torch.float32 else 1e-9
+    ta, tb = a.arena.row("theta"), b.arena.row("theta")
+    assert float((ta - tb).abs().max()) <= tol * float(ta.abs().max())
+    assert torch.allclose(costs_a, costs_b, rtol=5e-4 if dt == torch.float32 else 1e-9)
+    assert float((a.arena.row("minv") - b.arena.row("minv")).abs().max()) <= tol * float(a.arena.row("minv").abs().max())
+    assert torch.equal(tb, c.arena.row("theta")) and torch.equal(costs_b, costs_c)
+    assert b.n_iterations == 14 and not b.is_burning_in
+    next(a); next(b)
+    assert float((a.arena.row("theta") - b.arena.row("theta")).abs().max()) <= 2 * tol * float(ta.abs().max())
+
+
+def test_bnn_train_with_sgld_uses_the_fused_path_and_groups_work(gpu):
+    from pysgmcmc_amd.sampling import Sampler
+    from pysgmcmc_amd.samplers.fused_chains import FusedBNNChains
+    rng = np.random.RandomState(1)
+    X = rng.rand(100, 1)
+    y = np.sinc(X * 10 - 5).sum(axis=1)
+    Xt = np.linspace(0, 1, 100)[:, None]
+    yt = np.sinc(Xt * 10 - 5).sum(axis=1)
+    bnn = BayesianNeuralNetwork(session=gpu, sampling_method=Sampler.SGLD, dtype=torch.float32, burn_in_steps=1000,
+                                n_nets=10, seed=1)
+    bnn.train(X, y)
+    assert bnn.used_fused_steps and type(bnn.sampler).__name__ == "SGLDSampler"
+    m, v = bnn.predict(Xt)
+    assert np.isfinite(m).all() and np.mean((yt - m) ** 2) < 0.2
+    # a group of SGLD chains == the chains one by one
+    chains = [_sgld_chain(gpu, torch.float32, seed=70 + c) for c in range(3)]
+    solo = [_sgld_chain(gpu, torch.float32, seed=70 + c) for c in range(3)]
+    # the group wants ONE resident dataset: rebuild the members over chain 0's buffers
+    for s in chains[1:]:
+        s.batch_generator.x_dev, s.batch_generator.y_dev = chains[0].batch_generator.x_dev, chains[0].batch_generator.y_dev
+    group = FusedBNNChains(chains)
+    costs = group.steps(11)
+    for c, s in enumerate(solo):
+        assert torch.equal(s.fused_bnn_steps(11), costs[c])
+        assert torch.equal(s.arena.row("theta"), group.samplers[c].arena.row("theta"))
