@@ -20,7 +20,7 @@
 //         9..128, f32:               svgd_update_mfma_kernel     -- matrix cores, cooperative 64/128-column tiles,
 //                                                                   16-byte row-major global accesses;
 //         9..64, f64:                svgd_update_mfma_f64_kernel -- the same with v_mfma_f64_16x16x4_f64;
-//         65..128, f64:              svgd_update_kernel          -- pair tile in LDS, one wave per 64 columns
+//         65..128, f64:              svgd_update_mfma_f64_big_kernel -- two passes of four 16-particle blocks
 //       (svgd_update_reg_kernel / svgd_update_kernel also serve sgmcmc_svgd_kernel_*'s kernel-gradient output).
 // fp32 MFMA and packed fp32 VALU have the same peak on gfx950 (157 TFLOP/s; 155 measured for
 // v_mfma_f32_32x32x2_f32, tools/mfma_f32_probe.hip) and the f32 MFMA is exact f32, so there is no precision
@@ -1022,6 +1022,146 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_update_mfma_f64_kernel(doub
     }
 }
 
+// S4 on the matrix cores, f64, 65 <= n <= 128: eight 16-particle blocks do not fit the LDS as K fragments next to the
+// tile, so the products run in TWO passes of four blocks each (fragments of the pass staged from L2, 64 KB), on 32-column
+// tiles; two waves share a 16-column strip and take two blocks of the pass each. grad_theta of pass 0 waits in registers
+// until pass 1 has read the G rows.
+__global__ __launch_bounds__(SVGD_THREADS) void svgd_update_mfma_f64_big_kernel(double *__restrict__ X,
+                                                                                 const double *__restrict__ G,
+                                                                                 double *__restrict__ H, size_t dim,
+                                                                                 size_t ld, int n,
+                                                                                 const double *__restrict__ hdr,
+                                                                                 const double *__restrict__ K,
+                                                                                 const double *__restrict__ ksum,
+                                                                                 double eps, double alpha,
+                                                                                 double one_minus_alpha, double fudge,
+                                                                                 double sign) {
+    constexpr int MT = 32, IBP = 4, KSMAX = 32, NR = 128;            // blocks per pass, k-steps, tile rows
+    constexpr int QPR = MT / 2, RSTEP = SVGD_THREADS / QPR, RPT = NR / RSTEP;
+    extern __shared__ __align__(16) unsigned char svgd_lds_raw[];
+    double *kfs = reinterpret_cast<double *>(svgd_lds_raw);          // [IBP][KSMAX][64] of the current pass
+    double *gs = kfs + IBP * KSMAX * 64;                             // [NR][MT]
+    double *xs = gs + NR * MT;                                       // [NR][MT]
+    const SvgdGeom g = svgd_geom(n);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int KS = (n + 3) / 4;
+    const double h2 = hdr[2];
+    const double n_t = (double)n;
+    const bool vec = (ld % 2 == 0) && (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(G) |
+                                          reinterpret_cast<uintptr_t>(H)) & 15) == 0);
+    const int q = t % QPR, r0 = t / QPR;
+    const int sc = (wave & 1) * 16 + col;                            // strip of this wave
+    const int ibw = (wave >> 1) * 2;                                 // its two blocks within a pass
+    const size_t n_tiles = (dim + MT - 1) / MT;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t cq = tile * MT + 2 * (size_t)q;
+        const bool fullq = vec && cq + 2 <= dim;
+        f64x2 gv[RPT], xv[RPT], hv[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = r0 + RSTEP * k;
+            gv[k] = f64x2{0, 0};
+            xv[k] = gv[k];
+            hv[k] = gv[k];
+            if (r < n) {
+                const size_t at = (size_t)r * ld + cq;
+                if (fullq) {
+                    gv[k] = *reinterpret_cast<const f64x2 *>(G + at);
+                    xv[k] = *reinterpret_cast<const f64x2 *>(X + at);
+                    hv[k] = *reinterpret_cast<const f64x2 *>(H + at);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        if (cq + e < dim) { gv[k][e] = G[at + e]; xv[k][e] = X[at + e]; hv[k][e] = H[at + e]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = r0 + RSTEP * k;
+            *reinterpret_cast<f64x2 *>(gs + r * MT + 2 * q) = gv[k];
+            *reinterpret_cast<f64x2 *>(xs + r * MT + 2 * q) = xv[k];
+        }
+        double gt_keep[2][2][4];                                     // [pass][block of the wave][register]
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();                                         // tile written / previous pass done with kfs
+            for (int idx = t; idx < IBP * KSMAX * 64; idx += SVGD_THREADS) {
+                const int l = idx & 63, ks = (idx >> 6) % KSMAX, ib = (idx >> 6) / KSMAX;
+                const int i = 16 * (IBP * pass + ib) + (l & 15), j = 4 * ks + (l >> 4);
+                kfs[idx] = (i < g.np16 && j < g.np16) ? K[(size_t)i * g.np16 + j] : 0.0;
+            }
+            __syncthreads();
+            f64x4 ag[2], ax[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ag[b][r] = 0.0; ax[b][r] = 0.0; }
+            for (int ks = 0; ks < KS; ++ks) {
+                const double bg = gs[(4 * ks + kq) * MT + sc];
+                const double bx = xs[(4 * ks + kq) * MT + sc];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const double kf = kfs[((ibw + b) * KSMAX + ks) * 64 + lane];
+                    ag[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(kf, bg, ag[b], 0, 0, 0);
+                    ax[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(kf, bx, ax[b], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * (IBP * pass + ibw + b) + kq + 4 * r;
+                    double gt = 0.0;
+                    if (i < n) {
+                        const double x = xs[i * MT + sc];
+                        const double kg = (-ax[b][r] + x * ksum[i]) / h2;          // svgd.py:176-181
+                        gt = (ag[b][r] + sign * kg) / n_t;                         // svgd.py:124-127
+                    }
+                    gt_keep[pass][b][r] = gt;
+                }
+        }
+        __syncthreads();                                             // every product has read the G rows
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * (IBP * pass + ibw + b) + kq + 4 * r;
+                    if (i < n) gs[i * MT + sc] = gt_keep[pass][b][r];
+                }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = r0 + RSTEP * k;
+            if (r < n && cq < dim) {
+                const f64x2 gt = *reinterpret_cast<const f64x2 *>(gs + r * MT + 2 * q);
+                const f64x2 xo = *reinterpret_cast<const f64x2 *>(xs + r * MT + 2 * q);
+                f64x2 xn, hn;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const double hnew = alpha * hv[k][e] + one_minus_alpha * (gt[e] * gt[e]);   // svgd.py:129-132
+                    const double adj = gt[e] / (fudge + sqrt_t(hnew));                          // svgd.py:134-137
+                    hn[e] = hnew;
+                    xn[e] = xo[e] - eps * adj;                                                  // svgd.py:139-143
+                }
+                const size_t at = (size_t)r * ld + cq;
+                if (fullq) {
+                    *reinterpret_cast<f64x2 *>(H + at) = hn;
+                    *reinterpret_cast<f64x2 *>(X + at) = xn;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        if (cq + e < dim) { H[at + e] = hn[e]; X[at + e] = xn[e]; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // S1 on the matrix cores (f32, 17 <= n <= 128): Gram matrix of the particles, G = X~ X~^T, accumulated over
 // 128-column tiles with v_mfma_f32_32x32x2_f32; |x_i - x_j|^2 = G_ii + G_jj - 2 G_ij afterwards (S3).
@@ -1441,6 +1581,21 @@ int svgd_apply_impl(T *X, const T *G, T *H, T *kgrad_out, size_t out_ld, size_t 
         }
     }
     if constexpr (UPDATE && sizeof(T) == 8) {
+        if (n > 64) {
+            const SvgdWs w = svgd_ws((int)n);
+            const size_t n_tiles = (dim + 31) / 32;
+            const size_t lds_bytes = ((size_t)4 * 32 * 64 + (size_t)2 * 128 * 32) * sizeof(double);     // 128 KB
+            const unsigned grid = (unsigned)(n_tiles < 256 ? n_tiles : 256);
+            const void *fn = reinterpret_cast<const void *>(&svgd_update_mfma_f64_big_kernel);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(svgd_update_mfma_f64_big_kernel)");
+            double a64 = alpha, oma64 = 1.0 - alpha, eps64 = eps, fudge64 = fudge, sign64 = sign;
+            int n_i = (int)n;
+            const double *hdr = ws + w.hdr, *Kp = ws + w.K, *ksum = ws + w.ksum;
+            void *args[] = {&X, &G, &H, &dim, &ld, &n_i, &hdr, &Kp, &ksum, &eps64, &a64, &oma64, &fudge64, &sign64};
+            e = hipLaunchKernel(fn, dim3(grid), dim3(SVGD_THREADS), args, lds_bytes, st);
+            return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_update_mfma_f64_big_kernel");
+        }
         if (n <= 64) {
             const SvgdWs w = svgd_ws((int)n);
             const int ib = n <= 16 ? 1 : n <= 32 ? 2 : 4;
