@@ -203,6 +203,15 @@ def cpu_baseline(n, budget_s):
         O.c_sghmc_step(st, grad, 0.01, float(N_DATA), 0.05, False, None, seed=1, step=steps + 1)
         steps += 1
     dt = time.perf_counter() - t0
+    # the same on ONE core (B(1) next to B(all))
+    lib.oracle_set_num_threads(1)
+    t1c = time.perf_counter()
+    osteps = 0
+    while osteps < 5 and (time.perf_counter() - t1c) < budget_s / 4:
+        O.c_sghmc_step(st, grad, 0.01, float(N_DATA), 0.05, False, None, seed=1, step=100 + osteps)
+        osteps += 1
+    odt = time.perf_counter() - t1c
+    lib.oracle_set_num_threads(cores)
     # baseline A: op-by-op numpy mirror of the reference's unfused TF graph (injected noise drawn
     # by numpy, temporaries materialised, + the per-step copy-out of all parameters)
     ns = O.OpByOpState(st.theta, np.float32)
@@ -262,6 +271,7 @@ def cpu_baseline(n, budget_s):
             "full_step_samples_per_s": round(fsteps / fdt, 3) if fsteps else None,
             "full_step_sample": "%d complete steps (numpy/BLAS BNN forward+backward at batch %d + fused C update), "
                                 "%.1f s" % (fsteps, BATCH, fdt),
+            "one_core_steps_per_s": round(osteps / odt, 3) if osteps else None,
             "injected_noise_steps_per_s": round(isteps / idt, 3) if isteps else None,
             "opbyop_numpy_steps_per_s": round(asteps / adt, 3) if asteps else None}
 
