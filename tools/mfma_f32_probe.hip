@@ -1,3 +1,4 @@
+// build: /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o build/mfma_f32_probe tools/mfma_f32_probe.hip ; run: gpurun -- ./build/mfma_f32_probe
 // Throughput probe: v_mfma_f32_32x32x2_f32 with 4 independent accumulator chains per wave, 1..4 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
