@@ -294,3 +294,39 @@ def test_svgd_tight_cloud_far_from_origin(n):
     O.svgd_step(Xo, G.astype(np.float64), Ho, 1e-3, 0.9, 1e-6, -1.0)
     # the update itself is tiny next to 100: compare the displacement
     np.testing.assert_allclose(xs.cpu().numpy().reshape(n, d).astype(np.float64) - X, Xo - X, rtol=0.05, atol=2e-5)
+
+
+def test_svgd_randomised_shape_sweep():
+    """60 random (particles, parameters, row pitch, dtype, sign) combinations, one step each, against the oracle:
+    exercises every dispatch range (register / matrix-core / two-pass kernels), aligned and unaligned pitches,
+    partial tiles and base pointers that are only element-aligned."""
+    rng = np.random.default_rng(20260101)
+    for case in range(60):
+        n = int(rng.choice([2, 3, 5, 8, 9, 12, 16, 17, 24, 32, 33, 48, 64, 65, 90, 128]))
+        d = int(rng.choice([1, 2, 7, 31, 64, 65, 127, 128, 129, 300, 1000, 4099]))
+        dtype = np.float32 if rng.random() < 0.5 else np.float64
+        sign = int(rng.choice([1, -1]))
+        pad = int(rng.choice([0, 0, 1, 3, 4, 64]))
+        ld = d + pad
+        offset = int(rng.choice([0, 0, 1, 2]))                          # shifts the base pointer by elements
+        X = (0.3 + rng.normal(size=(n, d)) / np.sqrt(d)).astype(dtype)
+        G = rng.normal(size=(n, d)).astype(dtype)
+        H = rng.uniform(0.05, 1.0, size=(n, d)).astype(dtype)
+
+        def dev(a):
+            buf = torch.full((offset + n * ld,), 7.0, dtype=torch.from_numpy(a).dtype, device=DEV)
+            view = buf[offset:]
+            view.view(n, ld)[:, :d] = torch.from_numpy(a).to(DEV)
+            return view
+        x, g, h = dev(X), dev(G), dev(H)
+        ws = kernels.svgd_workspace(n, x)
+        kernels.svgd_step(x, g, h, n, d, 0.05, 0.9, 1e-6, ws, ld=ld, repulsion_sign=sign)
+        Xo, Ho = X.astype(np.float64), H.astype(np.float64)
+        O.svgd_step(Xo, G.astype(np.float64), Ho, 0.05, 0.9, 1e-6, float(sign))
+        rtol = 3e-5 if dtype == np.float32 else 1e-10
+        got = x.view(n, ld).cpu().numpy()
+        np.testing.assert_allclose(got[:, :d], Xo, rtol=rtol, atol=rtol, err_msg=str((case, n, d, ld, offset, dtype, sign)))
+        np.testing.assert_allclose(h.view(n, ld).cpu().numpy()[:, :d], Ho, rtol=10 * rtol, atol=rtol * 1e-2,
+                                   err_msg=str((case, n, d, ld, offset, dtype, sign)))
+        if pad:
+            assert np.all(got[:, d:] == 7.0), (case, n, d, ld)           # the padding is never written
