@@ -268,6 +268,13 @@ int sgmcmc_bnn_fused_sgld_steps_f64(double *theta, double *grad, double *tau, do
                                     double A, uint64_t first_step, uint64_t n_steps, uint64_t burn_in_steps,
                                     uint64_t seed_base, const double *xi, double *cost_out, sgmcmc_stream_t stream);
 
+/* Minibatch window [start, start + batch) of the device-resident dataset copied into the (static) feed buffers with
+ * ONE launch: x_out[batch][dim] = X[start ..][:], y_out[batch] = y[start ..] (pysgmcmc/data_batches.py:118-123).   */
+int sgmcmc_window_gather_f32(const float *X, const float *y, size_t n_data, size_t start, size_t batch, size_t dim,
+                             float *x_out, float *y_out, sgmcmc_stream_t stream);
+int sgmcmc_window_gather_f64(const double *X, const double *y, size_t n_data, size_t start, size_t batch, size_t dim,
+                             double *x_out, double *y_out, sgmcmc_stream_t stream);
+
 /* ---- Stein variational gradient descent: pysgmcmc/samplers/svgd.py:118-181 -----------------------
  * The n particles are the rows of a [n_particles x ld] device matrix (row pitch ld >= dim elements; with
  * ld a multiple of 4 and 16-byte aligned bases every access is 16 bytes wide -- the sampler pads ld to 64);

@@ -514,6 +514,19 @@ inline NoiseKey make_key(uint64_t seed, uint64_t step, const uint64_t *step_dev)
 
 __global__ void counter_add_kernel(uint64_t *ctr, uint64_t inc) { *ctr += inc; }
 
+// minibatch window [start, start + B) of the resident dataset into the static feed buffers
+// (pysgmcmc/data_batches.py:118-123): x rows are contiguous, so the window is ONE contiguous range of X
+template <typename T>
+__global__ void window_gather_kernel(const T *__restrict__ X, const T *__restrict__ y, size_t start, size_t B, size_t D,
+                                     T *__restrict__ xb, T *__restrict__ yb)
+{
+    const size_t nx = B * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nx + B; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < nx) xb[i] = X[start * D + i];
+        else yb[i - nx] = y[start + (i - nx)];
+    }
+}
+
 // Upper bound of the grid any launch of n elements can use (sizes the stats workspace).
 inline size_t max_grid_for(size_t n)
 {
@@ -928,6 +941,23 @@ int sgmcmc_counter_add_u64(uint64_t *counter, uint64_t inc, sgmcmc_stream_t stre
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch counter_add");
 }
+
+#define SGMCMC_WINDOW_GATHER(SFX, T)                                                                                  \
+    int sgmcmc_window_gather_##SFX(const T *X, const T *y, size_t n_data, size_t start, size_t batch, size_t dim,   \
+                                   T *x_out, T *y_out, sgmcmc_stream_t stream)                                       \
+    {                                                                                                                \
+        if (!X || !y || !x_out || !y_out) return fail(SGMCMC_EINVAL, "window_gather: NULL argument");               \
+        if (batch == 0 || start + batch > n_data) return fail(SGMCMC_EINVAL, "window_gather: window outside the data"); \
+        const size_t total = batch * dim + batch;                                                                    \
+        const size_t blocks = (total + 255) / 256;                                                                   \
+        hipLaunchKernelGGL((window_gather_kernel<T>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, \
+                           static_cast<hipStream_t>(stream), X, y, start, batch, dim, x_out, y_out);                 \
+        hipError_t e = hipGetLastError();                                                                            \
+        return e == hipSuccess ? 0 : hip_fail(e, "launch window_gather");                                            \
+    }
+SGMCMC_WINDOW_GATHER(f32, float)
+SGMCMC_WINDOW_GATHER(f64, double)
+#undef SGMCMC_WINDOW_GATHER
 
 size_t sgmcmc_summary_workspace_bytes(void) { return sizeof(Summary) * SUMMARY_BLOCKS; }
 int sgmcmc_summary_f32(const float *x, size_t n, double *out4, void *workspace, sgmcmc_stream_t stream)

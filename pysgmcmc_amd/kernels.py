@@ -16,7 +16,7 @@ __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
     "set_launch_config", "get_launch_config", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
-    "bnn_fused_sgld_steps", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
+    "bnn_fused_sgld_steps", "window_gather", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
 ]
 
 _SFX = {torch.float32: "f32", torch.float64: "f64"}
@@ -295,6 +295,18 @@ def bnn_fused_sgld_steps(theta, grad, tau, g, v_hat, minv, layer_sizes, X, y, wi
                _stream(theta))
     check(rc, "sgmcmc_bnn_fused_sgld_steps")
     return cost_out
+
+
+def window_gather(X, y, start, x_out, y_out):
+    """``x_out[:] = X[start:start + B]``, ``y_out[:] = y[start:start + B]`` in one launch (B = rows of x_out)."""
+    f = getattr(lib(), "sgmcmc_window_gather_" + _sfx(X))
+    batch = int(x_out.shape[0])
+    dim = int(X.numel() // X.shape[0])
+    if x_out.numel() != batch * dim or y_out.numel() != batch:
+        raise ValueError("pysgmcmc_amd: window_gather output shapes do not match the window")
+    with _on(X):
+        rc = f(_ptr(X), _ptr(y), int(X.shape[0]), int(start), batch, dim, _ptr(x_out), _ptr(y_out), _stream(X))
+    check(rc, "sgmcmc_window_gather")
 
 
 def svgd_max_particles():

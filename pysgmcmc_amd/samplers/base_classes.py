@@ -334,7 +334,17 @@ class MCMCSampler(object):
         constant-stepsize sampling replays one graph for burn-in and one for the frozen phase.
         Feeds are copied into static buffers first. Requirements: static feed shapes; a cost
         function without host synchronisation."""
-        feed_dict.update(self._next_batch())
+        gen = self.batch_generator
+        if (not feed_dict and hasattr(gen, "next_starts") and gen.x_dev.is_cuda
+                and gen.x_placeholder in self._static_feeds and gen.y_placeholder in self._static_feeds
+                and gen.x_dev.dtype == gen.y_dev.dtype == self._static_feeds[gen.x_placeholder].dtype):
+            # window generator with static feed buffers in place: the next window goes into them with ONE launch
+            # (same RandomState draw as next(generator)); otherwise two slice copies below
+            bx, by = self._static_feeds[gen.x_placeholder], self._static_feeds[gen.y_placeholder]
+            kernels.window_gather(gen.x_dev, gen.y_dev.reshape(-1), int(gen.next_starts(1)[0]), bx, by)
+            gen.x_placeholder.value, gen.y_placeholder.value = bx, by
+        else:
+            feed_dict.update(self._next_batch())
         eps = self._next_stepsize()
         for placeholder, value in feed_dict.items():
             if not hasattr(placeholder, "feed"):
