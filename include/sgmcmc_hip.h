@@ -268,6 +268,11 @@ int sgmcmc_bnn_fused_sgld_steps_f64(double *theta, double *grad, double *tau, do
                                     double A, uint64_t first_step, uint64_t n_steps, uint64_t burn_in_steps,
                                     uint64_t seed_base, const double *xi, double *cost_out, sgmcmc_stream_t stream);
 
+/* Forward of the last hidden layer fused with a single-output layer above it (models/bayesian_neural_network.py:
+ * 48-56): a[rows][cols] = tanh(a) in place, out[r] = sum_c a[r][c] * w[c] (no bias: sgmcmc_bnn_head_* adds it). */
+int sgmcmc_tanh_rowdot_f32(float *a, const float *w, size_t rows, size_t cols, float *out, sgmcmc_stream_t stream);
+int sgmcmc_tanh_rowdot_f64(double *a, const double *w, size_t rows, size_t cols, double *out, sgmcmc_stream_t stream);
+
 /* Minibatch window [start, start + batch) of the device-resident dataset copied into the (static) feed buffers with
  * ONE launch: x_out[batch][dim] = X[start ..][:], y_out[batch] = y[start ..] (pysgmcmc/data_batches.py:118-123).   */
 int sgmcmc_window_gather_f32(const float *X, const float *y, size_t n_data, size_t start, size_t batch, size_t dim,

@@ -84,6 +84,9 @@ def _declare(lib):
         f.argtypes = ([_vp] * 7 + [_sz, _sz, _ci, ctypes.POINTER(_ci), _ci, _vp, _vp, _sz, _vp, _ci]
                       + [ctypes.c_double] * 5 + [real, real, real, _u64, _u64, _u64, _u64, _vp, _vp, _vp])
         f.restype = _ci
+        f = getattr(lib, "sgmcmc_tanh_rowdot_" + sfx)
+        f.argtypes = [_vp, _vp, _sz, _sz, _vp, _vp]
+        f.restype = _ci
         f = getattr(lib, "sgmcmc_window_gather_" + sfx)
         f.argtypes = [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]
         f.restype = _ci

@@ -425,6 +425,31 @@ __global__ void __launch_bounds__(1024) tanh_backward_colsum_kernel(T *__restric
     }
 }
 
+// Forward of the last hidden layer fused with the single-output layer above it:
+//   h[r][c] = tanh(a[r][c]) in place,  out[r] = sum_c h[r][c] * w[c]   (the output unit's pre-bias mean)
+// one workgroup per row, fixed summation tree (deterministic). Replaces a tanh launch and a GEMV launch.
+__device__ __forceinline__ float tanh_dev(float x) { return tanhf(x); }
+__device__ __forceinline__ double tanh_dev(double x) { return tanh(x); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) tanh_rowdot_kernel(T *__restrict__ a, const T *__restrict__ w, size_t cols,
+                                                          T *__restrict__ out)
+{
+    __shared__ T lds[4];
+    T *row = a + (size_t)blockIdx.x * cols;
+    T acc = T(0);
+    for (size_t c = threadIdx.x; c < cols; c += 256) {
+        const T h = tanh_dev(row[c]);
+        row[c] = h;
+        acc += h * w[c];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+}
+
 // Backward of a single-output last layer fused with the tanh backward of the layer below:
 //   delta_prev[r][c] = dvec[r] * w[c] * (1 - h[r][c]^2)     (rank-1 back-propagation + tanh')
 //   colsum[c]        = sum_r delta_prev[r][c] (+ beta * bias_prev[c])   bias gradient of the layer below
@@ -958,6 +983,21 @@ int sgmcmc_counter_add_u64(uint64_t *counter, uint64_t inc, sgmcmc_stream_t stre
 SGMCMC_WINDOW_GATHER(f32, float)
 SGMCMC_WINDOW_GATHER(f64, double)
 #undef SGMCMC_WINDOW_GATHER
+
+#define SGMCMC_TANH_ROWDOT(SFX, T)                                                                                   \
+    int sgmcmc_tanh_rowdot_##SFX(T *a, const T *w, size_t rows, size_t cols, T *out, sgmcmc_stream_t stream)       \
+    {                                                                                                                \
+        if (rows == 0 || cols == 0) return 0;                                                                        \
+        if (!a || !w || !out) return fail(SGMCMC_EINVAL, "tanh_rowdot: NULL argument");                             \
+        if (rows > 0x7fffffffull) return fail(SGMCMC_EINVAL, "tanh_rowdot: too many rows");                          \
+        hipLaunchKernelGGL((tanh_rowdot_kernel<T>), dim3((unsigned)rows), dim3(256), 0, static_cast<hipStream_t>(stream), \
+                           a, w, cols, out);                                                                         \
+        hipError_t e = hipGetLastError();                                                                            \
+        return e == hipSuccess ? 0 : hip_fail(e, "launch tanh_rowdot");                                              \
+    }
+SGMCMC_TANH_ROWDOT(f32, float)
+SGMCMC_TANH_ROWDOT(f64, double)
+#undef SGMCMC_TANH_ROWDOT
 
 size_t sgmcmc_summary_workspace_bytes(void) { return sizeof(Summary) * SUMMARY_BLOCKS; }
 int sgmcmc_summary_f32(const float *x, size_t n, double *out4, void *workspace, sgmcmc_stream_t stream)

@@ -16,7 +16,7 @@ __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
     "set_launch_config", "get_launch_config", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
-    "bnn_fused_sgld_steps", "window_gather", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
+    "bnn_fused_sgld_steps", "window_gather", "tanh_rowdot", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
 ]
 
 _SFX = {torch.float32: "f32", torch.float64: "f64"}
@@ -295,6 +295,17 @@ def bnn_fused_sgld_steps(theta, grad, tau, g, v_hat, minv, layer_sizes, X, y, wi
                _stream(theta))
     check(rc, "sgmcmc_bnn_fused_sgld_steps")
     return cost_out
+
+
+def tanh_rowdot(a, w, out):
+    """``a = tanh(a)`` in place (``[rows, cols]``) and ``out[r] = a[r] . w`` in one launch."""
+    f = getattr(lib(), "sgmcmc_tanh_rowdot_" + _sfx(a))
+    rows, cols = int(a.shape[0]), int(a.shape[1])
+    if w.numel() != cols or out.numel() != rows:
+        raise ValueError("pysgmcmc_amd: tanh_rowdot shapes do not match")
+    with _on(a):
+        rc = f(_ptr(a), _ptr(w), rows, cols, _ptr(out), _stream(a))
+    check(rc, "sgmcmc_tanh_rowdot")
 
 
 def window_gather(X, y, start, x_out, y_out):

@@ -28,6 +28,8 @@ import math
 from collections import deque
 from time import time
 
+import os
+
 import numpy as np
 import torch
 
@@ -180,6 +182,8 @@ class BNNCost(object):
         # otherwise). False: the same algebra in device-agnostic torch ops -- an explicit opt-in used
         # to cross-check the kernels, never selected automatically.
         self.use_hip_kernels = True
+        # tanh of the last hidden layer fused with the single output unit's dot product (one launch instead of two)
+        self.fuse_tanh_rowdot = True                      # measured 228.2 vs 231.3 us per step at 10 M parameters
         # (Forking the weight-gradient GEMMs onto a second stream inside the captured graph was measured
         # on MI355X at batch 256: 291 us/step vs 275 us on one stream -- not kept.)
 
@@ -254,13 +258,18 @@ class BNNCost(object):
         single_out = params[2 * L].shape[1] == 1 and n_layers >= 2
         # forward; a single-output last layer is a plain GEMV whose bias the loss head adds
         h = X
+        fuse_top = single_out and self.fuse_tanh_rowdot
         for l in range(n_layers):
             W, b = params[2 * l], params[2 * l + 1]
             if l == L and single_out:
-                torch.mv(h, W.view(-1), out=hs[l].view(-1))
+                if not fuse_top:
+                    torch.mv(h, W.view(-1), out=hs[l].view(-1))
             else:
                 torch.addmm(b, h, W, out=hs[l])
-            if l < L:
+            if l == L - 1 and fuse_top:
+                # tanh of the last hidden layer and the output unit's dot product in one launch
+                kernels.tanh_rowdot(hs[l], params[2 * L].view(-1), hs[L].view(-1))
+            elif l < L:
                 torch.tanh_(hs[l])
             h = hs[l]
         n_params = float(sum(p.numel() for p in params))
