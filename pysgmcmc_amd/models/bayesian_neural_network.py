@@ -22,6 +22,7 @@ trainable tensor including biases and ``output_bias`` (``:386``).
     term folded into the GEMM epilogue (``beta * W``), so no gradient tensor is ever
     allocated, gathered or copied between the backward pass and the fused update.
 """
+import copy
 import itertools
 import logging
 import math
@@ -380,8 +381,9 @@ class BayesianNeuralNetwork(object):
                  n_nets=100, n_iters=50000,
                  burn_in_steps=1000, sample_steps=100,
                  normalize_input=True, normalize_output=True,
-                 seed=None, dtype=torch.float64, hidden=(50, 50, 50), **sampler_kwargs):
+                 seed=None, dtype=torch.float64, hidden=(50, 50, 50), n_chains=1, **sampler_kwargs):
         # same sanity checks as :241-262
+        assert isinstance(n_chains, int) and n_chains >= 1
         assert isinstance(n_nets, int)
         assert isinstance(n_iters, int)
         assert isinstance(burn_in_steps, int)
@@ -422,6 +424,11 @@ class BayesianNeuralNetwork(object):
         self.dtype = dtype
         self.session = session
         self.hidden = tuple(hidden)
+        # n_chains > 1 (extension): that many independent chains advance together in the fused small-model kernel
+        # and every collection point contributes one network per chain, so `n_nets` networks need 1/n_chains of
+        # the sampling iterations (the reference would run the chains one after the other)
+        self.n_chains = n_chains
+        self.chains = None
         self.is_trained = False
         # use the analytic-backward cost path (gradients straight into the arena)
         self.fused_cost = True
@@ -525,7 +532,27 @@ class BayesianNeuralNetwork(object):
                 return len(self.samples) == self.n_nets
             return False
 
+        group = None
+        if self.n_chains > 1:
+            if not fused:
+                raise ValueError("BayesianNeuralNetwork(n_chains > 1) needs the fused small-model path (a net whose "
+                                 "activations fit the LDS, SGHMC or SGLD, on an AMD GPU); got a configuration without it")
+            group = self._build_chain_group(n_datapoints, n_inputs, device)
+            self.chains = group
+
+            def handle(iteration_index, parameter_values, _single=handle):     # noqa: F811
+                burning_in = iteration_index <= self.burn_in_steps
+                if burning_in or iteration_index % logging_intervals["sampling"] != 0:
+                    return _single(iteration_index, parameter_values) if burning_in else False
+                log_full_training_error(iteration_index=iteration_index, is_sampling=True)
+                for member in group.samplers:                                   # one network per chain
+                    self.samples.append([v.clone() for v in member.arena.views("theta")])
+                    if len(self.samples) == self.n_nets:
+                        return True
+                return False
+
         if fused:
+            stepper = group.steps if group is not None else self.sampler.fused_bnn_steps
             # same loop, advanced in chunks: only iterations that log or collect need the host
             def is_event(i):
                 return (i <= self.burn_in_steps and i % logging_intervals["burn-in"] == 0) or \
@@ -535,7 +562,7 @@ class BayesianNeuralNetwork(object):
                 e = i
                 while e < self.n_iters - 1 and not is_event(e):
                     e += 1
-                self.sampler.fused_bnn_steps(e - i + 1)     # produces samples i .. e
+                stepper(e - i + 1)                          # produces samples i .. e
                 if handle(e, self.sampler.arena.views("theta")):
                     break
                 i = e + 1
@@ -545,6 +572,31 @@ class BayesianNeuralNetwork(object):
                 if handle(iteration_index, parameter_values):
                     break
         self.is_trained = True
+
+    def _build_chain_group(self, n_datapoints, n_inputs, device):
+        """Chains 1 .. n_chains-1 next to ``self.sampler`` (chain 0): own initial weights (init seed + c), own window
+        stream (RandomState(seed + c)) and Philox seed ``seed_0 + c``; one resident copy of the dataset."""
+        from pysgmcmc_amd.samplers.fused_chains import FusedBNNChains
+        first = self.sampler
+        gen0 = first.batch_generator
+        members = [first]
+        for c in range(1, self.n_chains):
+            params = init_mlp_params(n_inputs, hidden=self.hidden, seed=None if self.seed is None else self.seed + c,
+                                     dtype=self._torch_dtype, device=device)
+            kw = dict(self.sampler_kwargs)
+            kw.update({
+                "params": params,
+                "cost_fun": BNNCost(self.X_Minibatch, self.Y_Minibatch, self.batch_size, n_datapoints),
+                "batch_generator": type(gen0)(gen0.x_dev, gen0.y_dev, self.X_Minibatch, self.Y_Minibatch,
+                                              gen0.batch_size,
+                                              np.random.RandomState(None if self.seed is None else self.seed + c)),
+                "seed": int((first._philox_seed + c) & 0xFFFFFFFFFFFFFFFF),
+                "stepsize_schedule": copy.deepcopy(self.stepsize_schedule),
+            })
+            member = Sampler.get_sampler(self.sampling_method, **kw)
+            member.sample_format = "view"
+            members.append(member)
+        return FusedBNNChains(members)
 
     def compute_network_output(self, params, input_data):
         """Network output ``(N, 2)`` for one set of sampled weights (``:535-557``)."""

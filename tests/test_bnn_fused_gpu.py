@@ -245,3 +245,29 @@ def test_bnn_train_with_sgld_uses_the_fused_path_and_groups_work(gpu):
     for c, s in enumerate(solo):
         assert torch.equal(s.fused_bnn_steps(11), costs[c])
         assert torch.equal(s.arena.row("theta"), group.samplers[c].arena.row("theta"))
+
+
+def test_bnn_train_with_several_chains(gpu):
+    """BayesianNeuralNetwork(n_chains=4): the chains advance together, every collection point yields one network
+    per chain, so the same number of networks needs a quarter of the sampling iterations."""
+    rng = np.random.RandomState(1)
+    X = rng.rand(100, 1)
+    y = np.sinc(X * 10 - 5).sum(axis=1)
+    Xt = np.linspace(0, 1, 100)[:, None]
+    yt = np.sinc(Xt * 10 - 5).sum(axis=1)
+    kw = dict(session=gpu, dtype=torch.float32, burn_in_steps=1000, sample_steps=100, n_nets=20, seed=1)
+    one = BayesianNeuralNetwork(**kw)
+    one.train(X, y)
+    four = BayesianNeuralNetwork(n_chains=4, **kw)
+    four.train(X, y)
+    assert four.used_fused_steps and four.chains.n_chains == 4 and len(four.samples) == 20
+    assert one.sampler.n_iterations == 1000 + 20 * 100 + 1 and four.sampler.n_iterations == 1000 + 5 * 100 + 1
+    m, v = four.predict(Xt)
+    assert np.mean((yt - m) ** 2) < 0.1
+    # chain 0 is the single-chain run; the other chains are different draws
+    assert torch.equal(four.samples[0][0], one.samples[0][0])
+    assert not torch.equal(four.samples[0][0], four.samples[1][0])
+    with pytest.raises(ValueError):
+        b = BayesianNeuralNetwork(n_chains=2, **kw)
+        b.use_fused_steps = False
+        b.train(X, y)
