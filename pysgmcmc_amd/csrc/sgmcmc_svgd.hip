@@ -17,9 +17,9 @@
 //   S4  A = K G, B = K X, then the element-wise tail of svgd.py:124-143 with one rounding per reference
 //       op. R{X,G,H} W{X,H} = 20 B / element.
 //         n <= 8:                    svgd_update_small_kernel    -- registers, K rows as scalar operands;
-//         9..128, f32:               svgd_update_mfma_kernel     -- matrix cores, cooperative 64/128-column tiles,
-//                                                                   16-byte row-major global accesses;
-//         9..64, f64:                svgd_update_mfma_f64_kernel -- the same with v_mfma_f64_16x16x4_f64;
+//         9..64, f32 and f64:        svgd_update_mfma16_kernel   -- matrix cores (v_mfma_*_16x16x4), cooperative
+//                                                                   64-column tiles, 16-byte row-major global accesses;
+//         65..128, f32:              svgd_update_mfma_kernel     -- the same with v_mfma_f32_32x32x2_f32;
 //         65..128, f64:              svgd_update_mfma_f64_big_kernel -- two passes of four 16-particle blocks
 //       (svgd_update_reg_kernel / svgd_update_kernel also serve sgmcmc_svgd_kernel_*'s kernel-gradient output).
 // fp32 MFMA and packed fp32 VALU have the same peak on gfx950 (157 TFLOP/s; 155 measured for
@@ -894,62 +894,76 @@ __global__ __launch_bounds__(SVGD_THREADS, (IB == 2 && MT == 64 ? 3 : IB <= 2 ? 
 // S4 on the matrix cores, f64 (9 <= n <= 64): the same three phases with v_mfma_f64_16x16x4_f64 -- 16-particle
 // blocks, 16-column strips (4 waves = one 64-column tile), k-steps of 4 particles. Operand maps: A lane l =
 // K[16 ib + (l & 15)][4 ks + (l >> 4)], B lane l = tile[4 ks + (l >> 4)][column l & 15]; output register r of
-// lane l = row (l >> 4) + 4 r, column l & 15.
+// lane l = row (l >> 4) + 4 r, column l & 15 (f64) / row 4 (l >> 4) + r (f32: the standard 16x16 map).
 // ---------------------------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-template <int IB>                              // 16-particle blocks: 1 (n <= 16), 2 (n <= 32) or 4 (n <= 64)
-__global__ __launch_bounds__(SVGD_THREADS) void svgd_update_mfma_f64_kernel(double *__restrict__ X,
-                                                                             const double *__restrict__ G,
-                                                                             double *__restrict__ H, size_t dim, size_t ld,
-                                                                             int n, const double *__restrict__ hdr,
-                                                                             const double *__restrict__ K,
-                                                                             const double *__restrict__ ksum, double eps,
-                                                                             double alpha, double one_minus_alpha,
-                                                                             double fudge, double sign) {
+template <typename T> struct Mfma16;                 // 16x16x4 matrix-core step for f32 / f64
+template <> struct Mfma16<float> {
+    typedef f32x4 Acc;
+    static __device__ __forceinline__ Acc mma(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane_hi, int reg) { return 4 * lane_hi + reg; }   // standard 16x16 map
+};
+template <> struct Mfma16<double> {
+    typedef f64x4 Acc;
+    static __device__ __forceinline__ Acc mma(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane_hi, int reg) { return lane_hi + 4 * reg; }   // the f64 map
+};
+
+template <typename T, int IB>                  // 16-particle blocks: 1 (n <= 16), 2 (n <= 32) or 4 (n <= 64)
+__global__ __launch_bounds__(SVGD_THREADS) void svgd_update_mfma16_kernel(T *__restrict__ X,
+                                                                             const T *__restrict__ G,
+                                                                             T *__restrict__ H, size_t dim, size_t ld,
+                                                                             int n, const T *__restrict__ hdr,
+                                                                             const T *__restrict__ K,
+                                                                             const T *__restrict__ ksum, T eps,
+                                                                             T alpha, T one_minus_alpha,
+                                                                             T fudge, T sign) {
     constexpr int MT = 64, KSMAX = 4 * IB, NR = 16 * IB;
-    constexpr int QPR = MT / 2, RSTEP = SVGD_THREADS / QPR, RPT = NR / RSTEP;    // row-major phases: 2 columns per lane
+    constexpr int VW = 16 / (int)sizeof(T);                                     // elements per 16-byte access
+    typedef T VecT __attribute__((ext_vector_type(VW)));
+    constexpr int QPR = MT / VW, RSTEP = SVGD_THREADS / QPR, RPT = (NR + RSTEP - 1) / RSTEP;   // row-major phases
     extern __shared__ __align__(16) unsigned char svgd_lds_raw[];
-    double *kfs = reinterpret_cast<double *>(svgd_lds_raw);          // [IB][KSMAX][64]
-    double *gs = kfs + IB * KSMAX * 64;                              // [NR][MT]
-    double *xs = gs + NR * MT;                                       // [NR][MT]
+    T *kfs = reinterpret_cast<T *>(svgd_lds_raw);                    // [IB][KSMAX][64]
+    T *gs = kfs + IB * KSMAX * 64;                                   // [NR][MT]
+    T *xs = gs + NR * MT;                                            // [NR][MT]
     const SvgdGeom g = svgd_geom(n);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int KS = (n + 3) / 4;
-    const double h2 = hdr[2];
-    const double n_t = (double)n;
-    const bool vec = (ld % 2 == 0) && (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(G) |
+    const T h2 = hdr[2];
+    const T n_t = (T)n;
+    const bool vec = (ld % VW == 0) && (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(G) |
                                           reinterpret_cast<uintptr_t>(H)) & 15) == 0);
     for (int idx = t; idx < IB * KSMAX * 64; idx += SVGD_THREADS) {
         const int l = idx & 63, ks = (idx >> 6) % KSMAX, ib = (idx >> 6) / KSMAX;
         const int i = 16 * ib + (l & 15), j = 4 * ks + (l >> 4);
-        kfs[idx] = (i < g.np16 && j < g.np16) ? K[(size_t)i * g.np16 + j] : 0.0;          // zero beyond n
+        kfs[idx] = (i < g.np16 && j < g.np16) ? K[(size_t)i * g.np16 + j] : (T)0;         // zero beyond n
     }
     const int q = t % QPR, r0 = t / QPR;
     const size_t n_tiles = (dim + MT - 1) / MT;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t c0 = tile * MT;
-        const size_t cq = c0 + 2 * (size_t)q;
-        const bool fullq = vec && cq + 2 <= dim;
+        const size_t cq = c0 + VW * (size_t)q;
+        const bool fullq = vec && cq + VW <= dim;
         // ---- phase 1
-        f64x2 gv[RPT], xv[RPT], hv[RPT];
+        VecT gv[RPT], xv[RPT], hv[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int r = r0 + RSTEP * k;
-            gv[k] = f64x2{0, 0};
+            gv[k] = VecT{};
             xv[k] = gv[k];
             hv[k] = gv[k];
             if (r < n) {
                 const size_t at = (size_t)r * ld + cq;
                 if (fullq) {
-                    gv[k] = *reinterpret_cast<const f64x2 *>(G + at);
-                    xv[k] = *reinterpret_cast<const f64x2 *>(X + at);
-                    hv[k] = *reinterpret_cast<const f64x2 *>(H + at);
+                    gv[k] = *reinterpret_cast<const VecT *>(G + at);
+                    xv[k] = *reinterpret_cast<const VecT *>(X + at);
+                    hv[k] = *reinterpret_cast<const VecT *>(H + at);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 2; ++e)
+                    for (int e = 0; e < VW; ++e)
                         if (cq + e < dim) { gv[k][e] = G[at + e]; xv[k][e] = X[at + e]; hv[k][e] = H[at + e]; }
                 }
             }
@@ -957,36 +971,38 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_update_mfma_f64_kernel(doub
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int r = r0 + RSTEP * k;
-            *reinterpret_cast<f64x2 *>(gs + r * MT + 2 * q) = gv[k];
-            *reinterpret_cast<f64x2 *>(xs + r * MT + 2 * q) = xv[k];
+            if (r < NR) {
+                *reinterpret_cast<VecT *>(gs + r * MT + VW * q) = gv[k];
+                *reinterpret_cast<VecT *>(xs + r * MT + VW * q) = xv[k];
+            }
         }
         __syncthreads();
         // ---- phase 2: this wave's 16-column strip, all particle blocks
         {
             const int sc = wave * 16 + col;
-            f64x4 ag[IB], ax[IB];
+            typename Mfma16<T>::Acc ag[IB], ax[IB];
 #pragma unroll
             for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { ag[ib][r] = 0.0; ax[ib][r] = 0.0; }
+                for (int r = 0; r < 4; ++r) { ag[ib][r] = (T)0; ax[ib][r] = (T)0; }
             for (int ks = 0; ks < KS; ++ks) {
-                const double bg = gs[(4 * ks + kq) * MT + sc];
-                const double bx = xs[(4 * ks + kq) * MT + sc];
+                const T bg = gs[(4 * ks + kq) * MT + sc];
+                const T bx = xs[(4 * ks + kq) * MT + sc];
 #pragma unroll
                 for (int ib = 0; ib < IB; ++ib) {
-                    const double kf = kfs[(ib * KSMAX + ks) * 64 + lane];
-                    ag[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(kf, bg, ag[ib], 0, 0, 0);
-                    ax[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(kf, bx, ax[ib], 0, 0, 0);
+                    const T kf = kfs[(ib * KSMAX + ks) * 64 + lane];
+                    ag[ib] = Mfma16<T>::mma(kf, bg, ag[ib]);
+                    ax[ib] = Mfma16<T>::mma(kf, bx, ax[ib]);
                 }
             }
 #pragma unroll
             for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * ib + kq + 4 * r;
+                    const int i = 16 * ib + Mfma16<T>::row(kq, r);
                     if (i < n) {
-                        const double x = xs[i * MT + sc];
-                        const double kg = (-ax[ib][r] + x * ksum[i]) / h2;         // svgd.py:176-181
+                        const T x = xs[i * MT + sc];
+                        const T kg = (-ax[ib][r] + x * ksum[i]) / h2;              // svgd.py:176-181
                         gs[i * MT + sc] = (ag[ib][r] + sign * kg) / n_t;           // svgd.py:124-127
                     }
                 }
@@ -997,23 +1013,23 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_update_mfma_f64_kernel(doub
         for (int k = 0; k < RPT; ++k) {
             const int r = r0 + RSTEP * k;
             if (r < n && cq < dim) {
-                const f64x2 gt = *reinterpret_cast<const f64x2 *>(gs + r * MT + 2 * q);
-                const f64x2 xo = *reinterpret_cast<const f64x2 *>(xs + r * MT + 2 * q);
-                f64x2 xn, hn;
+                const VecT gt = *reinterpret_cast<const VecT *>(gs + r * MT + VW * q);
+                const VecT xo = *reinterpret_cast<const VecT *>(xs + r * MT + VW * q);
+                VecT xn, hn;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const double hnew = alpha * hv[k][e] + one_minus_alpha * (gt[e] * gt[e]);   // svgd.py:129-132
-                    const double adj = gt[e] / (fudge + sqrt_t(hnew));                          // svgd.py:134-137
+                for (int e = 0; e < VW; ++e) {
+                    const T hnew = alpha * hv[k][e] + one_minus_alpha * (gt[e] * gt[e]);        // svgd.py:129-132
+                    const T adj = gt[e] / (fudge + sqrt_t(hnew));                               // svgd.py:134-137
                     hn[e] = hnew;
                     xn[e] = xo[e] - eps * adj;                                                  // svgd.py:139-143
                 }
                 const size_t at = (size_t)r * ld + cq;
                 if (fullq) {
-                    *reinterpret_cast<f64x2 *>(H + at) = hn;
-                    *reinterpret_cast<f64x2 *>(X + at) = xn;
+                    *reinterpret_cast<VecT *>(H + at) = hn;
+                    *reinterpret_cast<VecT *>(X + at) = xn;
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 2; ++e)
+                    for (int e = 0; e < VW; ++e)
                         if (cq + e < dim) { H[at + e] = hn[e]; X[at + e] = xn[e]; }
                 }
             }
@@ -1556,29 +1572,35 @@ int svgd_apply_impl(T *X, const T *G, T *H, T *kgrad_out, size_t out_ld, size_t 
         return svgd_apply_small<T, 16, SmallCfg<T>::CPL16, UPDATE>(X, G, H, kgrad_out, out_ld, n, dim, ld, eps, alpha,
                                                                    fudge, sign, ws, st);
     if constexpr (UPDATE && sizeof(T) == 4) {
+        const SvgdWs w = svgd_ws((int)n);
+        float a32 = (float)alpha, oma32 = (float)(1.0 - alpha), eps32 = eps, fudge32 = fudge, sign32 = sign;
+        int n_i = (int)n;
+        const float *hdr = ws + w.hdr, *Kp = ws + w.K, *ksum = ws + w.ksum;
+        void *args[] = {&X, &G, &H, &dim, &ld, &n_i, &hdr, &Kp, &ksum, &eps32, &a32, &oma32, &fudge32, &sign32};
+        if (n <= 64) {
+            // 16x16x4 instruction, 64-column tiles: 20 KB (n <= 32) / 48 KB of LDS per workgroup. Measured against the
+            // 32x32x2 form with 128/64-column tiles: 889 vs 969 us at 16 x 10 M, 1.62 vs 1.71 ms at 32, 3.98 vs 4.14 at 64.
+            // Many more workgroups than fit the chip balance better than a persistent grid (64 x 10 M: 4.14 ms at 8 k
+            // workgroups vs 4.40 ms at 768, 5.2 ms uncapped).
+            const int ib = n <= 16 ? 1 : n <= 32 ? 2 : 4;
+            const size_t n_tiles = (dim + 63) / 64;
+            const size_t lds_bytes = ((size_t)ib * 4 * ib * 64 + (size_t)2 * 16 * ib * 64) * sizeof(float);
+            const unsigned grid = (unsigned)(n_tiles < 8192 ? n_tiles : 8192);
+            const void *fn = ib == 1   ? reinterpret_cast<const void *>(&svgd_update_mfma16_kernel<float, 1>)
+                             : ib == 2 ? reinterpret_cast<const void *>(&svgd_update_mfma16_kernel<float, 2>)
+                                       : reinterpret_cast<const void *>(&svgd_update_mfma16_kernel<float, 4>);
+            hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(SVGD_THREADS), args, lds_bytes, st);
+            return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_update_mfma16_kernel");
+        }
         {
-            const SvgdWs w = svgd_ws((int)n);
-            const int ib = n <= 32 ? 1 : n <= 64 ? 2 : 4;
-            // n > 32: 64-column tiles, two waves per 32-column strip with half of the particle blocks each -- 48 KB of
-            // LDS and 94 registers per lane at n <= 64 (3 workgroups per CU; 3.57 vs 4.20 ms at 64 x 10 M with 128 columns)
-            const int mt = ib == 1 ? SVGD_MT : 64;
-            const size_t n_tiles = (dim + mt - 1) / mt;
-            const size_t lds_bytes = ((size_t)ib * 16 * ib * 64 + (size_t)2 * 32 * ib * mt) * sizeof(float);
-            // grid cap: many more workgroups than fit the chip balance better than a persistent grid (64 x 10 M: 4.14 ms
-            // at 8-16 k workgroups vs 4.40 ms at 768, 5.2 ms uncapped); at 128 particles staging the 64 KB of K fragments
-            // per workgroup dominates, so that grid stays resident-sized
-            const size_t cap = ib <= 2 ? 8192 : 256;
-            const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
-            const void *fn = ib == 1   ? reinterpret_cast<const void *>(&svgd_update_mfma_kernel<1, SVGD_MT>)
-                             : ib == 2 ? reinterpret_cast<const void *>(&svgd_update_mfma_kernel<2, 64>)
-                                       : reinterpret_cast<const void *>(&svgd_update_mfma_kernel<4, 64>);
-            hipError_t e = hipSuccess;
-            if (lds_bytes > 64 * 1024) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            // 65..128 particles: 32x32x2 instruction, 64-column tiles, two waves per 32-column strip with two of the four
+            // particle blocks each; staging the 64 KB of K fragments per workgroup dominates, so the grid is resident-sized
+            const size_t n_tiles = (dim + 63) / 64;
+            const size_t lds_bytes = ((size_t)4 * 16 * 4 * 64 + (size_t)2 * 32 * 4 * 64) * sizeof(float);
+            const unsigned grid = (unsigned)(n_tiles < 256 ? n_tiles : 256);
+            const void *fn = reinterpret_cast<const void *>(&svgd_update_mfma_kernel<4, 64>);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(svgd_update_mfma_kernel)");
-            float a32 = (float)alpha, oma32 = (float)(1.0 - alpha), eps32 = eps, fudge32 = fudge, sign32 = sign;
-            int n_i = (int)n;
-            const float *hdr = ws + w.hdr, *Kp = ws + w.K, *ksum = ws + w.ksum;
-            void *args[] = {&X, &G, &H, &dim, &ld, &n_i, &hdr, &Kp, &ksum, &eps32, &a32, &oma32, &fudge32, &sign32};
             e = hipLaunchKernel(fn, dim3(grid), dim3(SVGD_THREADS), args, lds_bytes, st);
             return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_update_mfma_kernel");
         }
@@ -1606,9 +1628,9 @@ int svgd_apply_impl(T *X, const T *G, T *H, T *kgrad_out, size_t out_ld, size_t 
             const size_t lds_bytes = ((size_t)ib * 4 * ib * 64 + (size_t)2 * 16 * ib * 64) * sizeof(double);
             const size_t cap = ib <= 2 ? 8192 : 256;                // as for f32: large grids balance better up to 32 particles
             const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
-            const void *fn = ib == 1   ? reinterpret_cast<const void *>(&svgd_update_mfma_f64_kernel<1>)
-                             : ib == 2 ? reinterpret_cast<const void *>(&svgd_update_mfma_f64_kernel<2>)
-                                       : reinterpret_cast<const void *>(&svgd_update_mfma_f64_kernel<4>);
+            const void *fn = ib == 1   ? reinterpret_cast<const void *>(&svgd_update_mfma16_kernel<double, 1>)
+                             : ib == 2 ? reinterpret_cast<const void *>(&svgd_update_mfma16_kernel<double, 2>)
+                                       : reinterpret_cast<const void *>(&svgd_update_mfma16_kernel<double, 4>);
             hipError_t e = hipSuccess;
             if (lds_bytes > 64 * 1024) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(svgd_update_mfma_f64_kernel)");
