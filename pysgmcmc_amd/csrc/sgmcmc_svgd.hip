@@ -747,7 +747,8 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_update_reg_kernel(T *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// S4 on the matrix cores (f32, 9 <= n <= 128): A = K G and B = K X with v_mfma_f32_32x32x2_f32 (exact f32,
+// S4 on the matrix cores, 32x32x2 form (used for f32 with 65 <= n <= 128; the 16x16x4 kernel below serves n <= 64):
+// A = K G and B = K X with v_mfma_f32_32x32x2_f32 (exact f32,
 // an fmaf chain per output). A workgroup owns a tile of 128 columns:
 //   phase 1  all 256 lanes fetch the tile's G, X (into LDS, row-major) and H (registers) with 16-byte
 //            accesses -- 512 contiguous bytes per particle row per wave instruction. With up to 192 row
@@ -891,7 +892,8 @@ __global__ __launch_bounds__(SVGD_THREADS, (IB == 2 && MT == 64 ? 3 : IB <= 2 ? 
 }
 
 // ---------------------------------------------------------------------------------------------
-// S4 on the matrix cores, f64 (9 <= n <= 64): the same three phases with v_mfma_f64_16x16x4_f64 -- 16-particle
+// S4 on the matrix cores, 16x16x4 form (f32 and f64, 9 <= n <= 64): the same three phases with
+// v_mfma_{f32,f64}_16x16x4 -- 16-particle
 // blocks, 16-column strips (4 waves = one 64-column tile), k-steps of 4 particles. Operand maps: A lane l =
 // K[16 ib + (l & 15)][4 ks + (l >> 4)], B lane l = tile[4 ks + (l >> 4)][column l & 15]; output register r of
 // lane l = row (l >> 4) + 4 r, column l & 15 (f64) / row 4 (l >> 4) + r (f32: the standard 16x16 map).
