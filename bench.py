@@ -354,7 +354,7 @@ def run_svgd(args, dev, rank, world, dist):
                                    "update) on %d particles x %d parameters, row pitch %d, fixed synthetic gradients; "
                                    "1 particle set per GPU" % (args.workload, n, dim, ld),
                        "particles": n, "params": dim, "chains": world},
-            "roofline": {"bound": "hbm", "kernel": "sgmcmc_svgd_step_f32 (svgd_sqdist_small_kernel + svgd_update_mfma_kernel; "
+            "roofline": {"bound": "hbm", "kernel": "sgmcmc_svgd_step_f32 (svgd_gram_mfma16_kernel + svgd_update_mfma16_kernel; "
                                                    "per-kernel times in profiles/r01_svgd_kernel_stats.md)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),

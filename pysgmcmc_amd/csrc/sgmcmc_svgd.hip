@@ -4,10 +4,10 @@
 // sampler's arena, row pitch padded to 64 elements); G holds d cost / d X, H the running mean of squared
 // updates ("historical_grad"). One step is four launches:
 //   S1  pairwise squared distances, partial sums per column range. Reads X once (4 B / element).
-//         n <= 16 (any dtype): svgd_sqdist_small_kernel -- registers only, 8/16-byte loads;
-//         17..128, f32:        svgd_gram_mfma_kernel    -- Gram matrix of column-centred tiles on the
-//                                                          matrix cores (v_mfma_f32_32x32x2_f32);
-//         17..64, f64:         svgd_gram_mfma_f64_kernel -- the same with v_mfma_f64_16x16x4_f64;
+//         n <= 12 (any dtype): svgd_sqdist_small_kernel -- registers only, 8/16-byte loads;
+//         13..32 f32, 13..64 f64: svgd_gram_mfma16_kernel -- Gram matrix of column-centred 64-column tiles on the
+//                                                          matrix cores (v_mfma_{f32,f64}_16x16x4);
+//         33..128, f32:        svgd_gram_mfma_kernel    -- the same with v_mfma_f32_32x32x2_f32, 128-column tiles;
 //         65..128, f64:        svgd_sqdist_kernel       -- difference form, transposed LDS tile, 4x4 pair
 //                                                          blocks per lane.
 //   S2  svgd_reduce_*_kernel   adds the partials in a fixed order (bit-reproducible, no atomics).
@@ -96,7 +96,7 @@ inline SvgdWs svgd_ws(int n) {
     w.ksum = off; off += g.np16;
     const size_t per_part = (size_t)g.npb * 16 > 120 ? (size_t)g.npb * 16 : 120;   // S1 or S1s layout
     size_t parts_elems = (size_t)SVGD_MAX_PARTS * per_part;
-    const size_t gram_elems = n < 17 ? 0 : n <= 32 ? (size_t)2048 * 1024 : n <= 64 ? (size_t)1024 * 3072 : (size_t)512 * 10240;
+    const size_t gram_elems = n < 13 ? 0 : n <= 32 ? (size_t)2048 * 1024 : n <= 64 ? (size_t)1024 * 3072 : (size_t)512 * 10240;
     if (parts_elems < gram_elems) parts_elems = gram_elems;           // partial Gram blocks of the matrix-core S1
     w.parts = off; off += parts_elems;
     w.total = off;
@@ -913,6 +913,7 @@ template <> struct Mfma16<double> {
     static __device__ __forceinline__ int row(int lane_hi, int reg) { return lane_hi + 4 * reg; }   // the f64 map
 };
 
+
 template <typename T, int IB>                  // 16-particle blocks: 1 (n <= 16), 2 (n <= 32) or 4 (n <= 64)
 __global__ __launch_bounds__(SVGD_THREADS) void svgd_update_mfma16_kernel(T *__restrict__ X,
                                                                              const T *__restrict__ G,
@@ -1294,41 +1295,43 @@ __global__ __launch_bounds__(64 * SVGD_RED_SLICES) void svgd_reduce_gram_kernel(
 // S1 on the matrix cores, f64 (17 <= n <= 64): as above with v_mfma_f64_16x16x4_f64 -- 16-particle blocks, 64-column
 // tiles, 4 columns per instruction; operand lane l = x~[16 ib + (l & 15)][4 ks + (l >> 4)], output register r of lane l =
 // G[16 ib + (l >> 4) + 4 r][16 jb + (l & 15)].
-constexpr int SVGD_GT64 = 64, SVGD_GP64 = SVGD_GT64 + 2;
+constexpr int SVGD_GT64 = 64;                  // tile columns; LDS pitch = 64 + one 16-byte vector
 
-template <int IB>
-__global__ __launch_bounds__(SVGD_THREADS) void svgd_gram_mfma_f64_kernel(const double *__restrict__ X, size_t dim,
-                                                                           size_t ld, int n, double *__restrict__ parts) {
-    constexpr int NR = 16 * IB, QPR = SVGD_GT64 / 2, RSTEP = SVGD_THREADS / QPR, RPT = (NR + RSTEP - 1) / RSTEP;
+template <typename T, int IB>
+__global__ __launch_bounds__(SVGD_THREADS) void svgd_gram_mfma16_kernel(const T *__restrict__ X, size_t dim, size_t ld,
+                                                                         int n, T *__restrict__ parts) {
+    constexpr int VW = 16 / (int)sizeof(T), SVGD_GP64 = SVGD_GT64 + VW;
+    typedef T VecT __attribute__((ext_vector_type(VW)));
+    constexpr int NR = 16 * IB, QPR = SVGD_GT64 / VW, RSTEP = SVGD_THREADS / QPR, RPT = (NR + RSTEP - 1) / RSTEP;
     constexpr int NPAIRB = IB * (IB + 1) / 2;
     extern __shared__ __align__(16) unsigned char svgd_lds_raw[];
-    double *xs = reinterpret_cast<double *>(svgd_lds_raw);           // [NR][SVGD_GP64]; later the reduction buffer
+    T *xs = reinterpret_cast<T *>(svgd_lds_raw);                     // [NR][SVGD_GP64]; later the reduction buffer
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int q = t % QPR, r0 = t / QPR;
-    const bool vec = (ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    const double inv_n = 1.0 / (double)n;
-    f64x4 acc[NPAIRB];
+    const bool vec = (ld % VW == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const T inv_n = (T)1 / (T)n;
+    typename Mfma16<T>::Acc acc[NPAIRB];
 #pragma unroll
     for (int p = 0; p < NPAIRB; ++p)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[p][r] = 0.0;
+        for (int r = 0; r < 4; ++r) acc[p][r] = (T)0;
     const size_t n_tiles = (dim + SVGD_GT64 - 1) / SVGD_GT64;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const size_t cq = tile * SVGD_GT64 + 2 * (size_t)q;
-        const bool fullq = vec && cq + 2 <= dim;
-        f64x2 xv[RPT];
+        const size_t cq = tile * SVGD_GT64 + VW * (size_t)q;
+        const bool fullq = vec && cq + VW <= dim;
+        VecT xv[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int r = r0 + RSTEP * k;
-            xv[k] = f64x2{0, 0};
+            xv[k] = VecT{};
             if (r < n) {
                 const size_t at = (size_t)r * ld + cq;
                 if (fullq) {
-                    xv[k] = *reinterpret_cast<const f64x2 *>(X + at);
+                    xv[k] = *reinterpret_cast<const VecT *>(X + at);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 2; ++e)
+                    for (int e = 0; e < VW; ++e)
                         if (cq + e < dim) xv[k][e] = X[at + e];
                 }
             }
@@ -1336,17 +1339,17 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_gram_mfma_f64_kernel(const 
         __syncthreads();                                            // the previous tile's operands are consumed
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
-            if (r0 + RSTEP * k < NR) *reinterpret_cast<f64x2 *>(xs + (r0 + RSTEP * k) * SVGD_GP64 + 2 * q) = xv[k];
+            if (r0 + RSTEP * k < NR) *reinterpret_cast<VecT *>(xs + (r0 + RSTEP * k) * SVGD_GP64 + VW * q) = xv[k];
         __syncthreads();
         if (t < SVGD_GT64) {                                        // centre column t of the tile
-            double s = 0.0;
+            T s = (T)0;
             for (int r = 0; r < n; ++r) s += xs[r * SVGD_GP64 + t];
-            const double m = s * inv_n;
+            const T m = s * inv_n;
             for (int r = 0; r < n; ++r) xs[r * SVGD_GP64 + t] -= m;
         }
         __syncthreads();
         for (int ks = wave; ks < SVGD_GT64 / 4; ks += SVGD_THREADS / 64) {
-            double a[IB];
+            T a[IB];
 #pragma unroll
             for (int ib = 0; ib < IB; ++ib) a[ib] = xs[(16 * ib + col) * SVGD_GP64 + 4 * ks + kq];
             int p = 0;
@@ -1354,7 +1357,7 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_gram_mfma_f64_kernel(const 
             for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
                 for (int jb = ib; jb < IB; ++jb, ++p)
-                    acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ib], a[jb], acc[p], 0, 0, 0);
+                    acc[p] = Mfma16<T>::mma(a[ib], a[jb], acc[p]);
         }
     }
     __syncthreads();
@@ -1364,30 +1367,30 @@ __global__ __launch_bounds__(SVGD_THREADS) void svgd_gram_mfma_f64_kernel(const 
             for (int p = 0; p < NPAIRB; ++p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    double *slot = xs + (p * 4 + r) * 64 + lane;
+                    T *slot = xs + (p * 4 + r) * 64 + lane;
                     *slot = (w == 0) ? acc[p][r] : (*slot + acc[p][r]);
                 }
         }
         __syncthreads();
     }
-    double *out = parts + (size_t)blockIdx.x * (NPAIRB * 256);
+    T *out = parts + (size_t)blockIdx.x * (NPAIRB * 256);
     for (int idx = t; idx < NPAIRB * 256; idx += SVGD_THREADS) out[idx] = xs[idx];
 }
 
-template <int IB>
-__global__ __launch_bounds__(64 * SVGD_RED_SLICES) void svgd_reduce_gram_f64_kernel(const double *__restrict__ parts,
-                                                                                     int n_parts, int n,
-                                                                                     double *__restrict__ gram) {
+template <typename T, int IB>
+__global__ __launch_bounds__(64 * SVGD_RED_SLICES) void svgd_reduce_gram16_kernel(const T *__restrict__ parts,
+                                                                                   int n_parts, int n,
+                                                                                   T *__restrict__ gram) {
     constexpr int NPAIRB = IB * (IB + 1) / 2;
     const SvgdGeom g = svgd_geom(n);
-    double s;
+    T s;
     int idx;
     if (!reduce_parts(parts, n_parts, NPAIRB * 256, s, idx)) return;
     int p = idx >> 8, ib = 0;
     while (p >= IB - ib) { p -= IB - ib; ++ib; }
     const int jb = ib + p;
     const int r = (idx >> 6) & 3, l = idx & 63;
-    const int i = 16 * ib + (l >> 4) + 4 * r, j = 16 * jb + (l & 15);
+    const int i = 16 * ib + Mfma16<T>::row(l >> 4, r), j = 16 * jb + (l & 15);
     if (i >= n || j >= n) return;
     gram[(size_t)i * g.np16 + j] = s;
     if (ib != jb) gram[(size_t)j * g.np16 + i] = s;
@@ -1453,36 +1456,41 @@ int svgd_gram_launch_ib(const float *X, size_t n, size_t dim, size_t ld, float *
     return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_reduce_gram_kernel");
 }
 
-inline int svgd_gram_launch(const float *X, size_t n, size_t dim, size_t ld, float *parts, float *gram, hipStream_t st) {
-    if (n <= 32) return svgd_gram_launch_ib<1>(X, n, dim, ld, parts, gram, st);
-    if (n <= 64) return svgd_gram_launch_ib<2>(X, n, dim, ld, parts, gram, st);
-    return svgd_gram_launch_ib<4>(X, n, dim, ld, parts, gram, st);
-}
-template <int IB>
-int svgd_gram_launch_f64_ib(const double *X, size_t n, size_t dim, size_t ld, double *parts, double *gram, hipStream_t st) {
+template <typename T, int IB>
+int svgd_gram16_launch_ib(const T *X, size_t n, size_t dim, size_t ld, T *parts, T *gram, hipStream_t st) {
     constexpr int NPAIRB = IB * (IB + 1) / 2;
-    size_t lds_bytes = (size_t)16 * IB * SVGD_GP64 * sizeof(double);
-    const size_t red_bytes = (size_t)NPAIRB * 256 * sizeof(double);
+    constexpr int GP = SVGD_GT64 + 16 / (int)sizeof(T);
+    size_t lds_bytes = (size_t)16 * IB * GP * sizeof(T);
+    const size_t red_bytes = (size_t)NPAIRB * 256 * sizeof(T);
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     const size_t n_tiles = (dim + SVGD_GT64 - 1) / SVGD_GT64;
     const size_t cap = IB <= 2 ? 2048 : 1024;
     const int n_parts = (int)(n_tiles < cap ? n_tiles : cap);
-    hipLaunchKernelGGL((svgd_gram_mfma_f64_kernel<IB>), dim3(n_parts), dim3(SVGD_THREADS), lds_bytes, st, X, dim, ld,
+    hipLaunchKernelGGL((svgd_gram_mfma16_kernel<T, IB>), dim3(n_parts), dim3(SVGD_THREADS), lds_bytes, st, X, dim, ld,
                        (int)n, parts);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "launch svgd_gram_mfma_f64_kernel");
-    hipLaunchKernelGGL((svgd_reduce_gram_f64_kernel<IB>), dim3(NPAIRB * 256 / 64), dim3(64 * SVGD_RED_SLICES), 0, st, parts,
+    if (e != hipSuccess) return hip_fail(e, "launch svgd_gram_mfma16_kernel");
+    hipLaunchKernelGGL((svgd_reduce_gram16_kernel<T, IB>), dim3(NPAIRB * 256 / 64), dim3(64 * SVGD_RED_SLICES), 0, st, parts,
                        n_parts, (int)n, gram);
     e = hipGetLastError();
-    return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_reduce_gram_f64_kernel");
+    return e == hipSuccess ? 0 : hip_fail(e, "launch svgd_reduce_gram16_kernel");
 }
 
+inline int svgd_gram_launch(const float *X, size_t n, size_t dim, size_t ld, float *parts, float *gram, hipStream_t st) {
+    // up to 32 particles the 16x16x4 form on 64-column tiles wins (16 x 10 M: 172 vs 247 us for the register kernel,
+    // 32: 296 vs ~330 us for the 32x32x2 form); at 64 the 32x32x2 form does (755 vs 820 us)
+    if (n <= 16) return svgd_gram16_launch_ib<float, 1>(X, n, dim, ld, parts, gram, st);
+    if (n <= 32) return svgd_gram16_launch_ib<float, 2>(X, n, dim, ld, parts, gram, st);
+    if (n <= 64) return svgd_gram_launch_ib<2>(X, n, dim, ld, parts, gram, st);
+    return svgd_gram_launch_ib<4>(X, n, dim, ld, parts, gram, st);
+}
 constexpr int SVGD_NOT_HANDLED = -1000;
 
 // f64: matrix-core Gram form up to 64 particles; beyond, the difference-form kernel
 inline int svgd_gram_launch(const double *X, size_t n, size_t dim, size_t ld, double *parts, double *gram, hipStream_t st) {
-    if (n <= 32) return svgd_gram_launch_f64_ib<2>(X, n, dim, ld, parts, gram, st);
-    if (n <= 64) return svgd_gram_launch_f64_ib<4>(X, n, dim, ld, parts, gram, st);
+    if (n <= 16) return svgd_gram16_launch_ib<double, 1>(X, n, dim, ld, parts, gram, st);
+    if (n <= 32) return svgd_gram16_launch_ib<double, 2>(X, n, dim, ld, parts, gram, st);
+    if (n <= 64) return svgd_gram16_launch_ib<double, 4>(X, n, dim, ld, parts, gram, st);
     return SVGD_NOT_HANDLED;
 }
 
@@ -1493,7 +1501,7 @@ int svgd_kernel_matrix_impl(const T *X, size_t n, size_t dim, size_t ld, T *ws, 
     T *parts = ws + w.parts;
     hipError_t e;
     int from_gram = 0;
-    if (n >= 17) {                                               // n <= 16: the register kernel S1s is faster
+    if (n >= 13) {                                               // n <= 12: the register kernel S1s is as fast or faster
         const int rc = svgd_gram_launch(X, n, dim, ld, parts, ws + w.K, st);
         if (rc != 0 && rc != SVGD_NOT_HANDLED) return rc;
         from_gram = rc == 0;                                     // not handled: f64 with more than 64 particles
