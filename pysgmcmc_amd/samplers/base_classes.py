@@ -140,6 +140,7 @@ class MCMCSampler(object):
         self._ctr_value = -1
         self._capturing = False
         self._grad_decay = 0.0
+        self._view_cache = None
 
     def _rebind_arena(self, storage):
         """Re-home this chain's state in ``storage`` (see ``FlatArena.rebind``) and refresh the cached views."""
@@ -149,6 +150,7 @@ class MCMCSampler(object):
         self._graphs.clear()
         self._static_feeds.clear()
         self._stats_valid = False
+        self._view_cache = None
 
     # ------------------------------------------------------------------ feeds
     def _next_batch(self):
@@ -285,7 +287,10 @@ class MCMCSampler(object):
         elif fmt == "device":
             out = [v.detach().clone() for v in self.arena.views("theta")]
         elif fmt == "view":
-            out = [v.detach() for v in self.arena.views("theta")]
+            # the views alias the arena and never change: build them once (50 particles = 50 tensor objects per step)
+            if self._view_cache is None:
+                self._view_cache = [v.detach() for v in self.arena.views("theta")]
+            out = list(self._view_cache)
         else:
             raise ValueError("sample_format must be 'numpy', 'device' or 'view'")
         if len(out) == 1:
