@@ -339,3 +339,22 @@ def test_svgd_checkpoint_resume(shim):
     for _ in range(5):
         got, _ = next(resumed)
     np.testing.assert_array_equal(np.stack(got), np.stack(ref))
+
+
+def test_arena_rebind_and_param_alignment():
+    """FlatArena.rebind moves a chain's state into caller-provided memory (several chains back to back in one
+    allocation) and keeps the parameters aliased; param_align pads every parameter's start."""
+    from pysgmcmc_amd.arena import FlatArena
+    a, b = torch.arange(5.0), torch.arange(6.0).reshape(2, 3) + 10
+    arena = FlatArena([a, b], ("V",), torch.float32, "cpu")
+    arena.row("V").fill_(3.0)
+    pool = torch.full((2 * arena.storage.numel(),), -1.0)
+    arena.rebind(pool[arena.storage.numel():])
+    assert arena.storage.data_ptr() == pool[arena.storage.numel():].data_ptr()
+    assert a.data_ptr() == arena.row("theta").data_ptr() and torch.equal(b, torch.arange(6.0).reshape(2, 3) + 10)
+    assert torch.all(arena.row("V") == 3.0) and torch.all(pool[:arena.storage.numel()] == -1.0)
+    a.data.add_(1.0)                                     # writes through to the arena row
+    assert torch.equal(arena.row("theta")[:5], torch.arange(5.0) + 1)
+    assert arena.grad_views[1].data_ptr() == arena.row("grad")[5:].data_ptr()
+    padded = FlatArena([torch.zeros(5), torch.zeros(70), torch.zeros(3)], (), torch.float32, "cpu", param_align=64)
+    assert padded.offsets == [0, 64, 192] and padded.n == 256
