@@ -16,10 +16,19 @@ N > 1: independent chains, one per GPU (weak scaling, no collective on the data 
 every --rhat-every steps the chains exchange Welford moments with one RCCL all-reduce
 to compute R-hat (the only communication the path has).
 
-Output: ONE JSON line on rank 0. ``value`` = whole-job samples/s. ``roofline`` = the
-fused update kernel measured live with HIP events inside the timed region.
-``cpu_baseline`` (N = 1 only) = the fused C oracle timed on the host cores on the same
-10 M-parameter update.
+Phases: (1) PRIME, always and untimed, independent of --warmup: the chain's burn-in (8 adapting
+steps), then frozen steps with a Welford moments update, a trace append and (N > 1) one complete
+R-hat exchange -- every code path the timed loop can take has run once (first use of a kernel
+loads its code object: tens of ms); (2) --warmup untimed steps; (3) EXACTLY --steps timed steps
+between barrier + synchronize fences, all in the frozen-preconditioner phase.
+
+Output: ONE JSON line on rank 0. ``value`` = whole-job samples/s over the whole timed region
+(``step_ms_median`` / ``step_ms_max`` from per-step HIP events expose one-offs). ``roofline`` = the
+fused update kernel measured live with HIP events inside the timed region (10 M parameters: 240 MB
+per launch, Infinity-Cache-assisted); ``roofline_hbm_resident`` = the same kernels on 49 826 818
+parameters (1.2 GB per launch, cannot live in the 256 MiB Infinity Cache), measured after the
+timed region. ``cpu_baseline`` (N = 1 only) = the same full step on the host cores (numpy/BLAS
+BNN gradient + the fused C oracle update), unit samples/s like ``value``.
 """
 import argparse
 import json
@@ -37,9 +46,24 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:35
 # algorithmic bytes per parameter per launch, fp32
 BYTES_PER_PARAM = {"sghmc_frozen": 24, "sghmc_adapt": 48, "sgld_frozen": 16, "sgld_adapt": 40, "rsghmc": 20}
-# measured by rocprofv3 PMC counters (profiles/r01_pmc_traffic.md): read (2 x FETCH_SIZE) + written (WRITE_SIZE)
-PMC_BYTES_PER_PARAM = {"sghmc_frozen": 16.00 + 8.00, "sghmc_adapt": 24.00 + 24.00, "sgld_frozen": 12.00 + 4.00,
-                       "sgld_adapt": 20.00 + 20.00, "rsghmc": 12.00 + 8.00}
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PRIME_BURN_IN = 8              # adapting steps of the chain, run in the prime phase (never timed)
+PRIME_FROZEN = 4               # frozen steps of the prime phase (moments + trace appended every step)
+N_HBM_RESIDENT = 49_826_818    # configs[4]'s parameter count: 1.2 GB per frozen SGHMC launch
+
+
+def pmc_traffic(mode, n):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of the CURRENT kernels
+    (tools/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950
+    correction of MI355X_MICROARCH.md, calibrated on launches with known byte counts). Returns
+    (bytes per launch or None, source string)."""
+    try:
+        with open(PMC_TRAFFIC_FILE) as fh:
+            doc = json.load(fh)
+        entry = doc["sizes"][str(n)][mode]
+        return int(round(entry["bytes_per_param"] * n)), "profiles/r02_pmc_traffic.json (%s)" % doc.get("collected", "?")
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC pass for n=%d in profiles/r02_pmc_traffic.json" % n
 BATCH = 256
 N_DATA = 100_000
 # workloads: the default is BASELINE.json configs[2]; the 50 M ones are configs[4]'s two samplers
@@ -173,6 +197,61 @@ def update_only(sampler, iters=200):
     return out
 
 
+def hbm_resident_roofline(dev, n=N_HBM_RESIDENT, iters=40):
+    """The update kernels on a working set that cannot live in the 256 MiB Infinity Cache (configs[4]'s
+    49 826 818 parameters: 0.8-2.4 GB per launch). Every launch is bracketed by its own HIP event pair on the
+    stream it runs on (raw, conservative: includes the ~5 us event-pair overhead); state is synthetic
+    (theta ~ N(0, 0.02^2), grad ~ N(0, 0.1^2), minv ~ U(0.5, 2)), in-register Philox noise."""
+    from pysgmcmc_amd import kernels
+    g = torch.Generator(device=dev).manual_seed(0)
+    mk = lambda sc: torch.randn(n, device=dev, generator=g) * sc
+    theta, V, grad = mk(0.02), torch.zeros(n, device=dev), mk(0.1)
+    minv = torch.rand(n, device=dev, generator=g) * 1.5 + 0.5
+    tau, gg, vh = (torch.ones(n, device=dev) for _ in range(3))
+    calls = {
+        "sghmc_frozen": lambda i: kernels.sghmc_step(theta, V, grad, None, None, None, minv, None, 0.01, float(N_DATA),
+                                                     0.05, False, seed=1, step=i),
+        "sghmc_adapt": lambda i: kernels.sghmc_step(theta, V, grad, tau, gg, vh, minv, None, 0.01, float(N_DATA),
+                                                    0.05, True, seed=1, step=i),
+        "sgld_frozen": lambda i: kernels.sgld_step(theta, grad, None, None, None, minv, None, 1e-3, 1.0, float(N_DATA),
+                                                   False, seed=1, step=i),
+        "sgld_adapt": lambda i: kernels.sgld_step(theta, grad, tau, gg, vh, minv, None, 1e-3, 1.0, float(N_DATA),
+                                                  True, seed=1, step=i),
+        "rsghmc": lambda i: kernels.rsghmc_step(theta, V, grad, 1e-3, 1.0, 1.0, 1.0, 0.0, seed=1, step=i),
+    }
+    out = {}
+    for name, call in calls.items():
+        for i in range(5):
+            call(i)
+        torch.cuda.synchronize()
+        pairs = []
+        for i in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            call(5 + i)
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        us = np.array([a.elapsed_time(b) for a, b in pairs]) * 1e3
+        alg = BYTES_PER_PARAM[name] * n
+        traffic, src = pmc_traffic(name, n)
+        out[name] = {"us_per_launch_mean": round(float(us.mean()), 2), "us_per_launch_median": round(float(np.median(us)), 2),
+                     "algorithmic_bytes_per_launch": alg, "achieved": round(alg / (us.mean() * 1e-6) / 1e9, 1),
+                     "frac": round(alg / (us.mean() * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "launches_timed": iters}
+        theta.normal_(0.0, 0.02, generator=g)              # keep the chain finite across 225 synthetic steps
+        V.zero_()
+    assert torch.isfinite(theta).all()
+    head = out["sghmc_frozen"]
+    return {"bound": "hbm", "kernel": "stream_quads_vec<SghmcOp<float,false,false>,1,true,false,false> (128-lane blocks, nt)",
+            "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
+            "traffic": head["traffic"], "traffic_source": pmc_traffic("sghmc_frozen", n)[1],
+            "params": n, "working_set_note": "%.2f GB per frozen SGHMC launch: HBM-resident, cannot be served by the 256 MiB "
+                                             "Infinity Cache" % (head["algorithmic_bytes_per_launch"] / 1e9),
+            "timing": "hipEvent pair around every launch, back to back, after the timed region (not part of `value`)",
+            "kernels": out}
+
+
 def usable_cores():
     """Cores this process may actually use: min(affinity mask, cgroup CPU quota). (The GPU box shows
     256 logical CPUs but a 16-CPU cgroup quota; 256 OpenMP threads there run 8x SLOWER than 16.)"""
@@ -264,16 +343,21 @@ def cpu_baseline(n, budget_s):
     fdt = time.perf_counter() - t3
     if blas_limit is not None:
         blas_limit.restore_original_limits()
-    return {"value": round(steps / dt, 3), "unit": "update-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d frozen SGHMC update steps (update kernel only, no BNN gradient) of %d fp32 params, "
-                      "fused C oracle + OpenMP on %d threads, Philox noise generated in the loop like the GPU "
-                      "kernel, %.1f s" % (steps, n, cores, dt),
-            "full_step_samples_per_s": round(fsteps / fdt, 3) if fsteps else None,
-            "full_step_sample": "%d complete steps (numpy/BLAS BNN forward+backward at batch %d + fused C update), "
-                                "%.1f s" % (fsteps, BATCH, fdt),
-            "one_core_steps_per_s": round(osteps / odt, 3) if osteps else None,
-            "injected_noise_steps_per_s": round(isteps / idt, 3) if isteps else None,
-            "opbyop_numpy_steps_per_s": round(asteps / adt, 3) if asteps else None}
+    # `value` is the like-for-like figure: the COMPLETE step (gradient + update), samples/s. The update-only
+    # figures are sub-fields; the C port spends ~94 % of its update time in double-precision libm Box-Muller
+    # (compare update_only_steps_per_s with update_only_injected_noise_steps_per_s) -- a stated baseline, not a target.
+    return {"value": round(fsteps / fdt, 3) if fsteps else None, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d complete steps of the same workload (numpy/BLAS BNN forward + analytic backward at batch %d on "
+                      "%d threads, then the fused C oracle update of %d fp32 params with OpenMP on %d threads, Philox "
+                      "noise generated in the loop like the GPU kernel), %.1f s; TensorFlow is not installable here, so "
+                      "this port stands in for the reference's TF-CPU sampler" % (fsteps, BATCH, cores, n, cores, fdt),
+            "update_only_steps_per_s": round(steps / dt, 3),
+            "update_only_sample": "%d frozen SGHMC update steps (no BNN gradient), %.1f s" % (steps, dt),
+            "update_only_one_core_steps_per_s": round(osteps / odt, 3) if osteps else None,
+            "update_only_injected_noise_steps_per_s": round(isteps / idt, 3) if isteps else None,
+            "opbyop_numpy_update_steps_per_s": round(asteps / adt, 3) if asteps else None,
+            "opbyop_note": "op-by-op numpy mirror of the reference's unfused TF graph (temporaries materialised, "
+                           "+ the per-step copy-out of all parameters): the closest proxy of TF-CPU's update"}
 
 
 def svgd_cpu_baseline(n_particles, dim, budget_s):
@@ -404,9 +488,9 @@ def main():
         except Exception as exc:                               # tuning is an optimisation, never a requirement
             print("bench: GEMM tuning unavailable (%s); using the BLAS heuristics" % exc, file=sys.stderr)
             args.no_gemm_tuning = True
-    # burn-in (preconditioner adaptation) happens inside the warm-up so that every TIMED step is in one
-    # phase: frozen if warmup >= 1, else (warmup = 0 -> burn_in_steps = 0) perpetual adaptation
-    sampler = build_chain(dev, rank, args.workload, burn_in=min(8, max(args.warmup, 0)))
+    # burn-in (preconditioner adaptation) happens in the PRIME phase, so every warm-up and every timed step is
+    # in the frozen phase whatever --warmup is
+    sampler = build_chain(dev, rank, args.workload, burn_in=PRIME_BURN_IN)
     kind = WORKLOADS[args.workload]["sampler"]
     sampler.sample_format = "view"                             # no D2H copy of 40 MB per sample
     sampler.use_hip_graph = not args.eager
@@ -415,28 +499,45 @@ def main():
     from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange
     moments = ChainMoments(n, dev)
     exchange = RhatExchange(n, dev) if world > 1 else None
-    rhat_summary = [None]
     half = max(args.rhat_every // 2, 1)
     # thinned low-dimensional trace for ESS: [cost, theta[c0], theta[c1], theta[c2]] every moments_every steps,
     # appended on the device (no sync); gathered across chains AFTER the timed region
     coords = torch.tensor([0, n // 2, n - 1], device=dev)
-    trace = torch.zeros(max((args.steps + args.warmup) // max(args.moments_every, 1) + 1, 1), 4, device=dev)
+    total_steps = PRIME_BURN_IN + PRIME_FROZEN + args.steps + args.warmup
+    trace = torch.zeros(total_steps // max(args.moments_every, 1) + PRIME_FROZEN + 2, 4, device=dev)
     kept = [0]
+    ex_events = []                                                     # (start, packed, finish-begin, finish-end) HIP events
 
-    def one_step(i):
+    def one_step(i, every=None):
+        every = args.moments_every if every is None else every
         _, cost = next(sampler)
-        if (i + 1) % args.moments_every == 0:
+        if (i + 1) % every == 0:
             moments.update(sampler.arena.row("theta"))                 # K4 Welford, every chain
             trace[kept[0], 0:1].copy_(cost.reshape(1))
             torch.index_select(sampler.arena.row("theta"), 0, coords, out=trace[kept[0], 1:4])
             kept[0] += 1
         if exchange is not None:
             # the only exchange on the path: ONE all-reduce of 3P floats over RCCL/xGMI, issued
-            # asynchronously and collected half a period later, so it overlaps with sampling
+            # asynchronously and collected half a period later, so it overlaps with sampling.
+            # finish() leaves the R-hat summary on the device: no host synchronisation in the loop.
             if (i + 1) % args.rhat_every == 0 and moments.count >= 2 and not exchange.pending:
-                exchange.start(moments)
+                rhat_start()
             elif exchange.pending and (i + 1) % args.rhat_every == half:
-                _, rhat_summary[0] = exchange.finish()
+                rhat_finish()
+
+    def rhat_start():
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        exchange.start(moments)                                        # pack kernel + async all-reduce (RCCL stream)
+        ev[1].record()
+        ex_events.append(ev)
+
+    def rhat_finish():
+        ev = ex_events[-1]
+        ev[2].record()
+        exchange.finish()                                              # stream wait + finish kernel + K6 summary
+        ev[3].record()
+        ev.append("done")
 
     def fence():
         torch.cuda.synchronize()
@@ -444,20 +545,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- phase 1: PRIME (untimed, independent of --warmup): burn-in, then every other code path once
+    for i in range(PRIME_BURN_IN):
+        one_step(i, every=1 << 30)
+    assert not getattr(sampler, "_adapting", False), "prime phase must leave the chain in the frozen phase"
+    for i in range(PRIME_FROZEN):
+        one_step(i, every=1)                                           # frozen step + K4 + trace append
+    if exchange is not None:
+        rhat_start()
+        rhat_finish()
+        exchange.summary.as_dict()
+    prime_rhat_events = len(ex_events)
+    fence()
+    # ---- phase 2: --warmup untimed steps
+    moments.reset()
+    kept[0] = 0
     for i in range(args.warmup):
         one_step(i)
     frozen_phase = not getattr(sampler, "_adapting", False)
     moments.reset()
     kept[0] = 0
+    # ---- phase 3: the timed region
     timer.enabled = True
     fence()
     t0 = time.perf_counter()
+    host_stamps = [t0]
     for i in range(args.steps):
         one_step(i)
+        host_stamps.append(time.perf_counter())                        # host-side enqueue time of each step (no sync)
     if exchange is not None and exchange.pending:                      # inside the timed region
-        _, rhat_summary[0] = exchange.finish()
+        rhat_finish()
     fence()
     elapsed = time.perf_counter() - t0
+    host_ms = np.diff(np.array(host_stamps)) * 1e3
+    final_fence_ms = (t0 + elapsed - host_stamps[-1]) * 1e3
     timer.enabled = False
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -476,12 +597,23 @@ def main():
         ev_us = timer.event_pair_overhead_us()
         alg_bytes = BYTES_PER_PARAM[mode] * n
         achieved = alg_bytes / (k_us * 1e-6) / 1e9  # conservative: computed from the RAW bracket
+        big = alg_bytes > (640 << 20)
+        traffic, traffic_src = pmc_traffic(mode, n)
+        # per-step device time: from the end of one step's update kernel to the end of the next one's
+        ends = [b for _, b in timer.pairs]
+        step_ms = np.array([ends[j].elapsed_time(ends[j + 1]) for j in range(len(ends) - 1)]) if len(ends) > 1 else None
         line = {
             "metric": "MCMC samples/sec + fused-update HBM GB/s (% roofline), BNN 10M params",
             "value": round(world * args.steps / elapsed, 2),
             "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "step_ms_median": round(float(np.median(step_ms)), 4) if step_ms is not None else None,
+            "step_ms_max": round(float(step_ms.max()), 4) if step_ms is not None else None,
+            # host side of the timed region: enqueue time per step (the device runs asynchronously behind it) and
+            # the time the closing fence waited for the device to drain
+            "host_enqueue_ms": {"first_step": round(float(host_ms[0]), 4), "median": round(float(np.median(host_ms)), 4),
+                                "max": round(float(host_ms.max()), 4), "final_fence": round(final_fence_ms, 4)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s (%s) full next(sampler) step: BNN fwd+bwd + fused update; "
@@ -492,36 +624,66 @@ def main():
                        "rhat_every": args.rhat_every if world > 1 else None,
                        "moments_every": args.moments_every, "hip_graph": bool(sampler.use_hip_graph),
                        "gemm_tuning": not args.no_gemm_tuning,
+                       "prime_steps": {"burn_in": PRIME_BURN_IN, "frozen": PRIME_FROZEN},
                        "launch": kernels.get_launch_config()},
             # template args: <Op<float, ADAPT, INJECT>, quads per lane, NT, STATS, LOOP>
             "roofline": {"bound": "hbm", "kernel": "stream_quads_vec<%s<float,%s,false>,1,%s,true,false>" % (
-                             op_name, "false" if frozen_phase else "true",
-                             "true" if alg_bytes > (640 << 20) else "false"),
+                             op_name, "false" if frozen_phase else "true", "true" if big else "false"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         # HBM bytes per launch from the PMC passes of profiles/r01_pmc_traffic.md (separate
-                         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950
-                         # correction): measured bytes/param == algorithmic bytes/param for every kernel
-                         "traffic": int(round(PMC_BYTES_PER_PARAM[mode] * n)),
-                         "traffic_source": "profiles/r01_pmc_traffic.md",
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "us_per_launch_mean": round(k_us, 2), "us_per_launch_median": round(timer.median_us(), 2),
                          "launches_timed": len(timer.pairs),
                          "us_event_pair_overhead": round(ev_us, 2),
                          "achieved_minus_event_overhead": round(alg_bytes / ((k_us - ev_us) * 1e-6) / 1e9, 1),
+                         "cache_note": ("%.0f MB per launch: HBM-resident (larger than the 256 MiB Infinity Cache)" if big else
+                                        "%.0f MB per launch fits the 256 MiB Infinity Cache: part of this rate is cache-"
+                                        "assisted (it exceeds the 6.29 TB/s HBM copy ceiling of MI355X_MICROARCH.md); the "
+                                        "HBM-resident figure is `roofline_hbm_resident`") % (alg_bytes / 1e6),
                          "timing": "hipEvent pair around every launch of the timed region, in-pipeline (after the "
                                    "GEMMs evicted part of the state from the Infinity Cache); rocprofv3 kernel-only "
                                    "durations are in profiles/"},
         }
-        if rhat_summary[0] is not None:
-            line["rhat"] = {k: round(v, 4) for k, v in rhat_summary[0].items()}
+        if exchange is not None:
+            timed = ex_events[prime_rhat_events:]
+            done = [ev for ev in timed if len(ev) == 5]
+            line["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                            "exchanges_timed": len(done),
+                            "payload_bytes": int(exchange.pack.numel() * exchange.pack.element_size())}
+            if done:
+                # start -> finish wall on the compute stream (includes the steps sampled in between), the pack launch,
+                # and the tail the compute stream actually spends on the exchange when it collects it
+                line["rccl"]["rhat_exchange_ms"] = {
+                    "start_to_finish": round(float(np.mean([ev[0].elapsed_time(ev[3]) for ev in done])), 3),
+                    "pack_and_issue": round(float(np.mean([ev[0].elapsed_time(ev[1]) for ev in done])), 3),
+                    "wait_finish_summary": round(float(np.mean([ev[2].elapsed_time(ev[3]) for ev in done])), 3)}
+            line["rccl"]["collective_alone_ms"] = None
+            line["rhat"] = {k: round(v, 4) for k, v in exchange.summary.as_dict().items()} if exchange.exchanges else None
         if ess is not None:
             line["ess"] = {"kept_per_chain": kept[0], "cost": ess[0], "theta_coords": ess[1:]}
-        if world == 1:
-            if not args.no_update_only and kind == "sghmc":
-                line["update_only"] = update_only(sampler)
-            if not args.no_cpu_baseline and kind == "sghmc":
-                line["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
+    if exchange is not None:
+        # the collective alone: blocking all-reduce of the same 3P-float payload, after the timed region (all ranks)
+        torch.cuda.synchronize()
+        dist.barrier()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(exchange.pack)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        if rank == 0:
+            line["rccl"]["collective_alone_ms"] = round(float(np.median(ts[1:])), 3)
+    if rank == 0:
+        if not args.no_update_only and kind == "sghmc":
+            # identical code path at every N (SCALE N = 1 equals BENCH): runs on rank 0 after the timed region
+            line["update_only"] = update_only(sampler)
+            del moments, trace
+            line["roofline_hbm_resident"] = hbm_resident_roofline(dev)
+        if world == 1 and not args.no_cpu_baseline and kind == "sghmc":
+            line["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(line))
         sys.stdout.flush()
     if dist is not None:

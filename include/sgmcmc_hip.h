@@ -19,8 +19,9 @@
  *     results.
  *   - Calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL =
  *     the null stream) and are legal inside hipStreamBeginCapture.
- *   - No global mutable state except the launch-geometry knobs of
- *     sgmcmc_set_launch_config(), which never change results.
+ *   - No global mutable state at all: launch geometry is an optional per-call argument
+ *     (`const sgmcmc_launch_t *launch`, NULL = the measured defaults), error text is thread-local.
+ *     One host thread per chain / per GPU is safe, and so are several chains per thread.
  *   - Arithmetic: one IEEE rounding per reference op, in the reference's op order
  *     (built with -ffp-contract=off; '/' and sqrt correctly rounded), so with
  *     injected noise (`xi` != NULL) results are bit-identical to the CPU oracle
@@ -42,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SGMCMC_ABI_VERSION 1
+#define SGMCMC_ABI_VERSION 2
 
 #define SGMCMC_EINVAL   (-1)   /* null/invalid argument */
 #define SGMCMC_ENODEV   (-2)   /* no HIP device / not gfx950 code object */
@@ -55,16 +56,20 @@ const char *sgmcmc_last_error(void);
 /* Number of HIP devices visible, or a negative code. Does not create a context. */
 int sgmcmc_device_count(void);
 
-/* Launch geometry knobs (performance only; results never depend on them).
+/* Launch geometry of ONE call (performance only; results never depend on it). Pass NULL for the
+ * defaults; a field set to 0 (nontemporal: -1) keeps its default.
  *   block_threads: 64, 128, 192, 256, or -1 = auto (default): 128 when one launch streams more
  *                than 640 MiB (HBM-resident working set), else 256
  *   quads_per_thread: 1, 2 or 4 float4 groups in flight per lane (default 1)
  *   max_blocks: grid cap, the kernel grid-strides beyond it (default 2^20 = uncapped)
  *   nontemporal: 0 plain, 1 nt loads+stores, 2 auto = nt iff one launch touches more
- *                than 640 MiB, i.e. cannot live in the 256 MiB Infinity Cache (default 2)
- * Pass 0 (or -1 for nontemporal) to keep the current value. */
-int sgmcmc_set_launch_config(int block_threads, int quads_per_thread, int max_blocks, int nontemporal);
-int sgmcmc_get_launch_config(int *block_threads, int *quads_per_thread, int *max_blocks, int *nontemporal);
+ *                than 640 MiB, i.e. cannot live in the 256 MiB Infinity Cache (default 2)      */
+typedef struct sgmcmc_launch {
+    int block_threads;
+    int quads_per_thread;
+    int max_blocks;
+    int nontemporal;
+} sgmcmc_launch_t;
 
 /* K1 -- fused SGHMC step. Replaces the op chain pysgmcmc/samplers/sghmc.py:165-251
  * (+ constants :111-117) and the burn-in switch pysgmcmc/samplers/base_classes.py:432-456.
@@ -93,12 +98,12 @@ int sgmcmc_sghmc_step_f32(float *theta, float *V, const float *grad,
                           float *tau, float *g, float *v_hat, float *minv, float *r,
                           size_t n, float eps, float scale_grad, float mdecay, float grad_decay, int adapt,
                           const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, sgmcmc_stream_t stream);
+                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
 int sgmcmc_sghmc_step_f64(double *theta, double *V, const double *grad,
                           double *tau, double *g, double *v_hat, double *minv, double *r,
                           size_t n, double eps, double scale_grad, double mdecay, double grad_decay, int adapt,
                           const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, sgmcmc_stream_t stream);
+                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
 
 size_t sgmcmc_step_stats_workspace_bytes(size_t n);
 /* K7 -- stats_out[0..3] (device doubles) = fixed-order sum of the per-block partials a step kernel left
@@ -112,12 +117,12 @@ int sgmcmc_sgld_step_f32(float *theta, const float *grad,
                          float *tau, float *g, float *v_hat, float *minv, float *r,
                          size_t n, float eps, float A, float scale_grad, float grad_decay, int adapt,
                          const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, sgmcmc_stream_t stream);
+                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
 int sgmcmc_sgld_step_f64(double *theta, const double *grad,
                          double *tau, double *g, double *v_hat, double *minv, double *r,
                          size_t n, double eps, double A, double scale_grad, double grad_decay, int adapt,
                          const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, sgmcmc_stream_t stream);
+                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
 
 /* K3 -- fused relativistic SGHMC step, per element. Replaces
  * pysgmcmc/samplers/relativistic_sghmc.py:120-140. grad_cost = d cost / d theta
@@ -126,19 +131,19 @@ int sgmcmc_sgld_step_f64(double *theta, const double *grad,
 int sgmcmc_rsghmc_step_f32(float *theta, float *p, const float *grad_cost, size_t n,
                            float eps, float mass, float c, float D, float b_hat, float grad_decay,
                            const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, sgmcmc_stream_t stream);
+                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
 int sgmcmc_rsghmc_step_f64(double *theta, double *p, const double *grad_cost, size_t n,
                            double eps, double mass, double c, double D, double b_hat, double grad_decay,
                            const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, sgmcmc_stream_t stream);
+                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
 
 /* K5 -- write the N(0,1) stream itself: out[i] = xi(seed, step, i). Replaces
  * tf.random_normal in pysgmcmc/samplers/base_classes.py:218-220 for callers that
  * want the draws materialised (tests, relativistic momentum initialisation).      */
 int sgmcmc_philox_normal_f32(float *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                             sgmcmc_stream_t stream);
+                             const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
 int sgmcmc_philox_normal_f64(double *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                             sgmcmc_stream_t stream);
+                             const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
 /* raw Philox words: out[i] = x[i & 3] of quad i >> 2 (bit-exact integer check)     */
 int sgmcmc_philox_bits_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev,
                              sgmcmc_stream_t stream);
@@ -151,18 +156,26 @@ int sgmcmc_counter_add_u64(uint64_t *counter, uint64_t inc, sgmcmc_stream_t stre
  * delegates to pymc3. count = samples folded in INCLUDING this one (>= 1).
  * R{theta,mean,m2} W{mean,m2}                                        20 B/param f32 */
 int sgmcmc_moments_update_f32(const float *theta, float *mean, float *m2, size_t n,
-                              uint64_t count, sgmcmc_stream_t stream);
+                              uint64_t count, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
 int sgmcmc_moments_update_f64(const double *theta, double *mean, double *m2, size_t n,
-                              uint64_t count, sgmcmc_stream_t stream);
+                              uint64_t count, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
 
-/* R-hat exchange step. pack: out3[0:n] = mean, out3[n:2n] = mean^2,
- * out3[2n:3n] = m2/(count-1). The caller all-reduces (SUM) out3 across the m chains
- * over RCCL, then finish: rhat[i] = sqrt(((W (cnt-1)/cnt) + B/cnt) / W) with
- * W = S_var/m, B = cnt * (S_sq - S_mean^2/m)/(m-1).                                */
+/* R-hat exchange step (replaces what pysgmcmc/diagnostics/sampler_diagnostics.py:118-194
+ * delegates to pymc3.diagnostics.gelman_rubin). pack: out3[0:n] = mean, out3[n:2n] = mean^2,
+ * out3[2n:3n] = m2/(count-1). The caller all-reduces (SUM) out3 across the m chains over RCCL
+ * (torch.distributed), then finish: rhat[i] = sqrt(((W (cnt-1)/cnt) + B/cnt) / W) with
+ * W = S_var/m, B = cnt * (S_sq - S_mean^2/m)/(m-1); one IEEE rounding per operation in the dtype.
+ * summary_out4 / summary_ws (both NULL or both given; ws = sgmcmc_summary_workspace_bytes()):
+ * the K6 summary {sum, sum of squares, min, max} of rhat is left in DEVICE memory on the same
+ * stream -- the in-loop exchange never synchronises with the host.                              */
 int sgmcmc_rhat_pack_f32(const float *mean, const float *m2, size_t n, uint64_t count,
                          float *out3, sgmcmc_stream_t stream);
+int sgmcmc_rhat_pack_f64(const double *mean, const double *m2, size_t n, uint64_t count,
+                         double *out3, sgmcmc_stream_t stream);
 int sgmcmc_rhat_finish_f32(const float *sum3, size_t n, int m_chains, uint64_t count,
-                           float *rhat, sgmcmc_stream_t stream);
+                           float *rhat, double *summary_out4, void *summary_ws, sgmcmc_stream_t stream);
+int sgmcmc_rhat_finish_f64(const double *sum3, size_t n, int m_chains, uint64_t count,
+                           double *rhat, double *summary_out4, void *summary_ws, sgmcmc_stream_t stream);
 
 /* K6 -- deterministic summary of an array: out4 (device, 4 doubles) = {sum, sum of
  * squares, min, max}. Wave-shuffle partial sums -> LDS -> per-block partials in
@@ -312,6 +325,26 @@ int sgmcmc_svgd_kernel_f32(const float *particles, size_t n_particles, size_t di
 int sgmcmc_svgd_kernel_f64(const double *particles, size_t n_particles, size_t dim, size_t ld, void *workspace,
                            double *kernel_out, double *kernel_grad_out, size_t kernel_grad_ld, double *bandwidth_out,
                            sgmcmc_stream_t stream);
+
+/* ---- Deviations from the signatures proposed in SURVEY.md section 8(b), and why -------------------
+ *  1. eps_scaled is not an argument: K1 takes (eps, scale_grad) and derives eps/sqrt(scale_grad) and
+ *     the noise-scale constants itself, in the dtype and in the reference's op order
+ *     (sghmc.py:115,211-217) -- a caller computing them in double would break bit-parity.
+ *  2. philox_offset became (step, step_dev): the Philox counter is (step, quad), so the caller passes
+ *     n_iterations instead of step * ceil(n/4); step_dev (device counter) exists for hipGraph replay.
+ *  3. grad_decay (all three steps): weight-prior gradient term formed in registers; 0 = reference.
+ *  4. stats_ws: the fused "LDS-staged reduction" of north_star rides on the step call itself.
+ *  5. launch: per-call geometry instead of a process-wide setter (section 8(b): no global state).
+ *  6. sgmcmc_moments_update_*: as proposed (+ launch).
+ *  7. sgmcmc_rhat_allreduce(ncclComm_t) is NOT exported: the library would have to own an RCCL
+ *     communicator and link librccl; instead the exchange is split into sgmcmc_rhat_pack_* /
+ *     sgmcmc_rhat_finish_* around ONE all-reduce the host issues through torch.distributed
+ *     (backend "nccl" = RCCL), which already owns the communicator. No torch/RCCL types in the ABI.
+ *  8. sgmcmc_cpu_* is NOT exported by the product library: the CPU restatement is test
+ *     infrastructure (oracle/libsgmcmc_oracle.so: oracle_sghmc_step_f32, ...), never shipped as a
+ *     fallback -- the product path fails loudly without a GPU.
+ *  9. f64 variants of everything (the reference's default dtype is float64, base_classes.py:25).
+ */
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,12 @@ def load_c():
         f = getattr(lib, "oracle_moments_update_" + sfx)
         f.argtypes = [vp, vp, vp, sz, u64]
         f.restype = ci
+        f = getattr(lib, "oracle_rhat_pack_" + sfx)
+        f.argtypes = [vp, vp, sz, u64, vp]
+        f.restype = ci
+        f = getattr(lib, "oracle_rhat_finish_" + sfx)
+        f.argtypes = [vp, sz, ci, u64, vp]
+        f.restype = ci
         f = getattr(lib, "oracle_philox_normal_" + sfx)
         f.argtypes = [u64, u64, sz, vp]
         f.restype = None
@@ -171,6 +177,25 @@ def c_moments_update(theta, mean, m2, count):
     f = getattr(lib, "oracle_moments_update_" + _sfx(theta.dtype))
     rc = f(_p(theta), _p(mean), _p(m2), theta.size, count)
     assert rc == 0
+
+
+def c_rhat_pack(mean, m2, count):
+    """[mean | mean^2 | m2/(count-1)] of one chain, in the arrays' dtype (the R-hat all-reduce payload)."""
+    lib = load_c()
+    out3 = np.empty(3 * mean.size, mean.dtype)
+    rc = getattr(lib, "oracle_rhat_pack_" + _sfx(mean.dtype))(_p(mean), _p(m2), mean.size, int(count), _p(out3))
+    assert rc == 0
+    return out3
+
+
+def c_rhat_finish(sum3, m_chains, count):
+    """R-hat per parameter from the chain-summed pack, in the pack's dtype."""
+    lib = load_c()
+    n = sum3.size // 3
+    rhat = np.empty(n, sum3.dtype)
+    rc = getattr(lib, "oracle_rhat_finish_" + _sfx(sum3.dtype))(_p(sum3), n, int(m_chains), int(count), _p(rhat))
+    assert rc == 0
+    return rhat
 
 
 def c_philox_normal(seed, step, n, dtype=np.float32):

@@ -37,6 +37,7 @@ def build(force=False):
 
 
 _lib = None
+ABI_VERSION = 2               # SGMCMC_ABI_VERSION of include/sgmcmc_hip.h
 
 _u64 = ctypes.c_uint64
 _sz = ctypes.c_size_t
@@ -44,29 +45,39 @@ _ci = ctypes.c_int
 _vp = ctypes.c_void_p
 
 
+class LaunchStruct(ctypes.Structure):
+    """``sgmcmc_launch_t``: per-call launch geometry (0 / -1 = default)."""
+    _fields_ = [("block_threads", _ci), ("quads_per_thread", _ci), ("max_blocks", _ci), ("nontemporal", _ci)]
+
+
+_lp = ctypes.POINTER(LaunchStruct)
+
+
 def _declare(lib):
     lib.sgmcmc_abi_version.restype = _ci
     lib.sgmcmc_last_error.restype = ctypes.c_char_p
     lib.sgmcmc_device_count.restype = _ci
-    lib.sgmcmc_set_launch_config.argtypes = [_ci, _ci, _ci, _ci]
-    lib.sgmcmc_set_launch_config.restype = _ci
-    lib.sgmcmc_get_launch_config.argtypes = [ctypes.POINTER(_ci)] * 4
-    lib.sgmcmc_get_launch_config.restype = _ci
     for sfx, real in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
         f = getattr(lib, "sgmcmc_sghmc_step_" + sfx)
-        f.argtypes = [_vp] * 8 + [_sz, real, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp, _vp]
+        f.argtypes = [_vp] * 8 + [_sz, real, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp, _lp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_sgld_step_" + sfx)
-        f.argtypes = [_vp] * 7 + [_sz, real, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp, _vp]
+        f.argtypes = [_vp] * 7 + [_sz, real, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp, _lp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_rsghmc_step_" + sfx)
-        f.argtypes = [_vp] * 3 + [_sz, real, real, real, real, real, real, _vp, _u64, _u64, _vp, _vp, _vp]
+        f.argtypes = [_vp] * 3 + [_sz, real, real, real, real, real, real, _vp, _u64, _u64, _vp, _vp, _lp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_philox_normal_" + sfx)
-        f.argtypes = [_vp, _sz, _u64, _u64, _vp, _vp]
+        f.argtypes = [_vp, _sz, _u64, _u64, _vp, _lp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_moments_update_" + sfx)
-        f.argtypes = [_vp, _vp, _vp, _sz, _u64, _vp]
+        f.argtypes = [_vp, _vp, _vp, _sz, _u64, _lp, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_rhat_pack_" + sfx)
+        f.argtypes = [_vp, _vp, _sz, _u64, _vp, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_rhat_finish_" + sfx)
+        f.argtypes = [_vp, _sz, _ci, _u64, _vp, _vp, _vp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_bnn_head_" + sfx)
         f.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz] + [ctypes.c_double] * 6 + [_ci, _vp, _vp, _vp, _vp, _vp, _vp]
@@ -107,10 +118,6 @@ def _declare(lib):
     lib.sgmcmc_counter_add_u64.argtypes = [_vp, _u64, _vp]
     lib.sgmcmc_counter_add_u64.restype = _ci
     lib.sgmcmc_philox_bits_u32.restype = _ci
-    lib.sgmcmc_rhat_pack_f32.argtypes = [_vp, _vp, _sz, _u64, _vp, _vp]
-    lib.sgmcmc_rhat_pack_f32.restype = _ci
-    lib.sgmcmc_rhat_finish_f32.argtypes = [_vp, _sz, _ci, _u64, _vp, _vp]
-    lib.sgmcmc_rhat_finish_f32.restype = _ci
     lib.sgmcmc_summary_workspace_bytes.restype = _sz
     lib.sgmcmc_svgd_workspace_bytes.argtypes = [_sz, _sz]
     lib.sgmcmc_svgd_workspace_bytes.restype = _sz
@@ -135,7 +142,7 @@ def lib():
     except OSError as exc:
         raise SgmcmcLibraryError("pysgmcmc_amd: cannot load %s: %s" % (_LIB_PATH, exc))
     _declare(handle)
-    if handle.sgmcmc_abi_version() != 1:
+    if handle.sgmcmc_abi_version() != ABI_VERSION:
         raise SgmcmcLibraryError("pysgmcmc_amd: ABI version mismatch in %s" % _LIB_PATH)
     _lib = handle
     return handle

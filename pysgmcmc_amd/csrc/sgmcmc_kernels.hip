@@ -28,7 +28,6 @@
 //     LDS -> per-block partials -> fixed-order final pass.
 #include <hip/hip_runtime.h>
 
-#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -250,27 +249,30 @@ __global__ void __launch_bounds__(SUMMARY_THREADS) summary_final(const Summary *
 // R-hat pack / finish and raw Philox words (small elementwise kernels)
 // --------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(256) rhat_pack_kernel(const float *__restrict__ mean, const float *__restrict__ m2,
-                                                        size_t n, float inv_cm1, float *__restrict__ out3)
+// One IEEE rounding per operation in T (fp contract off): the C oracle's rhat_pack / rhat_finish give the same bits.
+template <typename T>
+__global__ void __launch_bounds__(256) rhat_pack_kernel(const T *__restrict__ mean, const T *__restrict__ m2,
+                                                        size_t n, T inv_cm1, T *__restrict__ out3)
 {
     const size_t G = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += G) {
-        float mu = mean[i];
+        T mu = mean[i];
         out3[i] = mu;
         out3[n + i] = mu * mu;
         out3[2 * n + i] = m2[i] * inv_cm1;
     }
 }
-__global__ void __launch_bounds__(256) rhat_finish_kernel(const float *__restrict__ sum3, size_t n, float m, float cnt,
-                                                          float *__restrict__ rhat)
+template <typename T>
+__global__ void __launch_bounds__(256) rhat_finish_kernel(const T *__restrict__ sum3, size_t n, T m, T cnt,
+                                                          T *__restrict__ rhat)
 {
     const size_t G = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += G) {
-        float s_mean = sum3[i], s_sq = sum3[n + i], s_var = sum3[2 * n + i];
-        float W = s_var / m;
-        float B = cnt * ((s_sq - (s_mean * s_mean) / m) / (m - 1.0f));
-        float Vhat = W * ((cnt - 1.0f) / cnt) + B / cnt;
-        rhat[i] = sqrtf(Vhat / W);
+        T s_mean = sum3[i], s_sq = sum3[n + i], s_var = sum3[2 * n + i];
+        T W = s_var / m;
+        T B = cnt * ((s_sq - (s_mean * s_mean) / m) / (m - T(1)));
+        T Vhat = W * ((cnt - T(1)) / cnt) + B / cnt;
+        rhat[i] = sqrt(Vhat / W);
     }
 }
 __global__ void __launch_bounds__(256) philox_bits_kernel(uint32_t *__restrict__ out, size_t n, NoiseKey nk)
@@ -516,10 +518,40 @@ using namespace sgmcmc_host;
 
 namespace {
 
-std::atomic<int> g_block_threads{-1};   // -1 = auto: 128 lanes when a launch streams > NT_AUTO_BYTES, else 256
-std::atomic<int> g_qpt{1};
-std::atomic<int> g_max_blocks{1 << 20};
-std::atomic<int> g_nt{2};                 // 0 = plain, 1 = nt, 2 = auto by working-set size
+// Launch geometry of ONE call (sgmcmc_launch_t in the header; NULL = these defaults). The library keeps
+// no mutable state: two host threads may step two chains with different geometries concurrently.
+struct LaunchCfg {
+    int block_threads = -1;       // -1 = auto: 128 lanes when a launch streams > NT_AUTO_BYTES, else 256
+    int qpt = 1;
+    int max_blocks = 1 << 20;
+    int nt = 2;                   // 0 = plain, 1 = nt, 2 = auto by working-set size
+    int bt = 256;                 // resolved block size of this launch (set by launch_inner)
+};
+// validates *in (0 / -1 fields keep the default); returns 0 or SGMCMC_EINVAL
+inline int resolve_launch(const sgmcmc_launch_t *in, LaunchCfg &c)
+{
+    if (!in) return 0;
+    if (in->block_threads != 0) {
+        if (in->block_threads != -1 && (in->block_threads < 64 || in->block_threads > 256 || (in->block_threads % 64) != 0))
+            return fail(SGMCMC_EINVAL, "launch.block_threads must be 64, 128, 192, 256, 0 (default) or -1 (auto)");
+        c.block_threads = in->block_threads;
+    }
+    if (in->quads_per_thread != 0) {
+        if (in->quads_per_thread != 1 && in->quads_per_thread != 2 && in->quads_per_thread != 4)
+            return fail(SGMCMC_EINVAL, "launch.quads_per_thread must be 0 (default), 1, 2 or 4");
+        c.qpt = in->quads_per_thread;
+    }
+    if (in->max_blocks != 0) {
+        if (in->max_blocks < 1) return fail(SGMCMC_EINVAL, "launch.max_blocks must be 0 (default) or >= 1");
+        c.max_blocks = in->max_blocks;
+    }
+    if (in->nontemporal != -1) {
+        if (in->nontemporal < 0 || in->nontemporal > 2)
+            return fail(SGMCMC_EINVAL, "launch.nontemporal must be -1 (default), 0 (off), 1 (on) or 2 (auto)");
+        c.nt = in->nontemporal;
+    }
+    return 0;
+}
 // Above this many bytes touched per launch the arrays cannot stay in the 256 MiB
 // Infinity Cache between steps and nt accesses win (+6..7 % at 1.2 GB); below it
 // plain accesses win (the cache holds part of the working set across steps:
@@ -561,19 +593,16 @@ inline size_t max_grid_for(size_t n)
     return want < cap ? (want ? want : 1) : cap;
 }
 
-// block size of the launch being issued on this thread (set by launch_inner)
-thread_local int g_bt_launch = 256;
-
 template <typename Op, int QPT, bool NT>
-int launch_vec(const Op &op, size_t n, hipStream_t st)
+int launch_vec(const Op &op, size_t n, const LaunchCfg &cfg, hipStream_t st)
 {
-    const int bt = g_bt_launch;
+    const int bt = cfg.bt;
     const size_t nq_full = n / 4;
     const int tail = (int)(n % 4);
     size_t per_block = (size_t)bt * QPT;
     size_t want = (nq_full + per_block - 1) / per_block;
     if (want == 0) want = 1;
-    size_t cap = (size_t)g_max_blocks.load();
+    size_t cap = (size_t)cfg.max_blocks;
     unsigned grid = (unsigned)(want < cap ? want : cap);
     const bool with_stats = op.stats_part != nullptr;
     if constexpr (QPT == 1) {
@@ -594,13 +623,13 @@ int launch_vec(const Op &op, size_t n, hipStream_t st)
     return e == hipSuccess ? 0 : hip_fail(e, "launch stream_quads_vec");
 }
 template <typename Op>
-int launch_scalar(const Op &op, size_t n, hipStream_t st)
+int launch_scalar(const Op &op, size_t n, const LaunchCfg &cfg, hipStream_t st)
 {
-    const int bt = g_bt_launch;
+    const int bt = cfg.bt;
     size_t nq = (n + 3) / 4;
     size_t want = (nq + bt - 1) / bt;
     if (want == 0) want = 1;
-    size_t cap = (size_t)g_max_blocks.load();
+    size_t cap = (size_t)cfg.max_blocks;
     unsigned grid = (unsigned)(want < cap ? want : cap);
     if (op.stats_part != nullptr)
         hipLaunchKernelGGL((stream_quads_scalar<Op, true>), dim3(grid), dim3(bt), 0, st, op, n);
@@ -613,43 +642,34 @@ int launch_scalar(const Op &op, size_t n, hipStream_t st)
 // f32 ops honour the (quads_per_thread, nontemporal) knobs; f64 ops (a quad is
 // already 32 B per lane per array) use one quad per lane.
 template <typename Op>
-int launch_inner(const Op &op, size_t n, bool vec_ok, size_t bytes_per_elem, hipStream_t st);
-
-template <typename Op>
-int launch(const Op &op, size_t n, bool vec_ok, size_t bytes_per_elem, hipStream_t st)
-{
-    return launch_inner(op, n, vec_ok, bytes_per_elem, st);
-}
-
-template <typename Op>
-int launch_inner(const Op &op, size_t n, bool vec_ok, size_t bytes_per_elem, hipStream_t st)
+int launch(const Op &op, size_t n, bool vec_ok, size_t bytes_per_elem, const sgmcmc_launch_t *launch_in, hipStream_t st)
 {
     if (n == 0) return 0;
+    LaunchCfg cfg;
+    if (int rc = resolve_launch(launch_in, cfg)) return rc;
     const bool big = n * bytes_per_elem > NT_AUTO_BYTES;     // cannot stay in the Infinity Cache between steps
-    const int bt_cfg = g_block_threads.load();
     // measured (profiles/r01_block_sweep.txt): 128-lane blocks +7 % at 50 M params (HBM-resident), 256 +2 % at 10 M
-    g_bt_launch = bt_cfg > 0 ? bt_cfg : (big ? 128 : 256);
-    if (!vec_ok) return launch_scalar<Op>(op, n, st);
-    const int nt_cfg = g_nt.load();
-    const bool nt = nt_cfg == 2 ? big : (nt_cfg != 0);
+    cfg.bt = cfg.block_threads > 0 ? cfg.block_threads : (big ? 128 : 256);
+    if (!vec_ok) return launch_scalar<Op>(op, n, cfg, st);
+    const bool nt = cfg.nt == 2 ? big : (cfg.nt != 0);
     if (sizeof(typename Op::real) == 8) {
-        return nt ? launch_vec<Op, 1, true>(op, n, st) : launch_vec<Op, 1, false>(op, n, st);
+        return nt ? launch_vec<Op, 1, true>(op, n, cfg, st) : launch_vec<Op, 1, false>(op, n, cfg, st);
     }
-    const int qpt = g_qpt.load();
+    const int qpt = cfg.qpt;
     if (nt) {
-        if (qpt >= 4) return launch_vec<Op, 4, true>(op, n, st);
-        if (qpt == 2) return launch_vec<Op, 2, true>(op, n, st);
-        return launch_vec<Op, 1, true>(op, n, st);
+        if (qpt >= 4) return launch_vec<Op, 4, true>(op, n, cfg, st);
+        if (qpt == 2) return launch_vec<Op, 2, true>(op, n, cfg, st);
+        return launch_vec<Op, 1, true>(op, n, cfg, st);
     }
-    if (qpt >= 4) return launch_vec<Op, 4, false>(op, n, st);
-    if (qpt == 2) return launch_vec<Op, 2, false>(op, n, st);
-    return launch_vec<Op, 1, false>(op, n, st);
+    if (qpt >= 4) return launch_vec<Op, 4, false>(op, n, cfg, st);
+    if (qpt == 2) return launch_vec<Op, 2, false>(op, n, cfg, st);
+    return launch_vec<Op, 1, false>(op, n, cfg, st);
 }
 
 template <typename T>
 int sghmc_step(T *theta, T *V, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, size_t n,
                T eps, T scale_grad, T mdecay, T grad_decay, int adapt, const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-               void *stats_ws, hipStream_t st)
+               void *stats_ws, const sgmcmc_launch_t *lc, hipStream_t st)
 {
     if (n == 0) return 0;
     if (!theta || !V || !grad || !minv) return fail(SGMCMC_EINVAL, "sghmc_step: theta, V, grad and minv must be non-NULL");
@@ -667,7 +687,7 @@ int sghmc_step(T *theta, T *V, const T *grad, T *tau, T *g, T *v_hat, T *minv, T
 #define SGHMC_GO(AD, INJ)                                                                              \
     {                                                                                                  \
         SghmcOp<T, AD, INJ> op{theta, V, grad, tau, g, v_hat, minv, r, xi, e2, c1, c3, e4, mdecay, grad_decay, nk, sp}; \
-        return launch(op, n, vec_ok, sizeof(T) * ((AD ? 12 : 6) + (INJ ? 1 : 0)), st);                 \
+        return launch(op, n, vec_ok, sizeof(T) * ((AD ? 12 : 6) + (INJ ? 1 : 0)), lc, st);                 \
     }
     if (adapt) { if (xi) SGHMC_GO(true, true) else SGHMC_GO(true, false) }
     else { if (xi) SGHMC_GO(false, true) else SGHMC_GO(false, false) }
@@ -677,7 +697,7 @@ int sghmc_step(T *theta, T *V, const T *grad, T *tau, T *g, T *v_hat, T *minv, T
 template <typename T>
 int sgld_step(T *theta, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, size_t n,
               T eps, T A, T scale_grad, T grad_decay, int adapt, const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-               void *stats_ws, hipStream_t st)
+               void *stats_ws, const sgmcmc_launch_t *lc, hipStream_t st)
 {
     if (n == 0) return 0;
     if (!theta || !grad || !minv) return fail(SGMCMC_EINVAL, "sgld_step: theta, grad and minv must be non-NULL");
@@ -693,7 +713,7 @@ int sgld_step(T *theta, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, si
 #define SGLD_GO(AD, INJ)                                                                            \
     {                                                                                               \
         SgldOp<T, AD, INJ> op{theta, grad, tau, g, v_hat, minv, r, xi, eps, A, a_eff, two_eps, sg_den, grad_decay, nk, sp}; \
-        return launch(op, n, vec_ok, sizeof(T) * ((AD ? 10 : 4) + (INJ ? 1 : 0)), st);              \
+        return launch(op, n, vec_ok, sizeof(T) * ((AD ? 10 : 4) + (INJ ? 1 : 0)), lc, st);              \
     }
     if (adapt) { if (xi) SGLD_GO(true, true) else SGLD_GO(true, false) }
     else { if (xi) SGLD_GO(false, true) else SGLD_GO(false, false) }
@@ -703,7 +723,7 @@ int sgld_step(T *theta, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, si
 template <typename T>
 int rsghmc_step(T *theta, T *p, const T *grad, size_t n, T eps, T mass, T c, T D, T b_hat, T grad_decay,
                 const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                void *stats_ws, hipStream_t st)
+                void *stats_ws, const sgmcmc_launch_t *lc, hipStream_t st)
 {
     if (n == 0) return 0;
     if (!theta || !p || !grad) return fail(SGMCMC_EINVAL, "rsghmc_step: theta, p and grad_cost must be non-NULL");
@@ -714,10 +734,10 @@ int rsghmc_step(T *theta, T *p, const T *grad, size_t n, T eps, T mass, T c, T D
     bool vec_ok = aligned16(theta) && aligned16(p) && aligned16(grad) && aligned16(xi);
     if (xi) {
         RsghmcOp<T, false, true> op{theta, p, grad, xi, eps, mass, D, m2c2, nscale, grad_decay, nk, sp};
-        return launch(op, n, vec_ok, sizeof(T) * 6, st);
+        return launch(op, n, vec_ok, sizeof(T) * 6, lc, st);
     }
     RsghmcOp<T, false, false> op{theta, p, grad, xi, eps, mass, D, m2c2, nscale, grad_decay, nk, sp};
-    return launch(op, n, vec_ok, sizeof(T) * 5, st);
+    return launch(op, n, vec_ok, sizeof(T) * 5, lc, st);
 }
 
 template <typename T>
@@ -736,7 +756,7 @@ int summary(const T *x, size_t n, double *out4, void *ws, hipStream_t st)
 inline unsigned small_grid(size_t n)
 {
     size_t want = (n + 255) / 256;
-    size_t cap = (size_t)g_max_blocks.load();
+    size_t cap = (size_t)1 << 20;
     return (unsigned)(want < cap ? (want ? want : 1) : cap);
 }
 
@@ -810,86 +830,55 @@ int sgmcmc_device_count(void)
     return n;
 }
 
-int sgmcmc_set_launch_config(int block_threads, int quads_per_thread, int max_blocks, int nontemporal)
-{
-    if (block_threads != 0) {
-        if (block_threads != -1 && (block_threads < 64 || block_threads > 256 || (block_threads % 64) != 0))
-            return fail(SGMCMC_EINVAL, "block_threads must be 64, 128, 192, 256 or -1 (auto)");
-        g_block_threads.store(block_threads);
-    }
-    if (quads_per_thread != 0) {
-        if (quads_per_thread != 1 && quads_per_thread != 2 && quads_per_thread != 4)
-            return fail(SGMCMC_EINVAL, "quads_per_thread must be 1, 2 or 4");
-        g_qpt.store(quads_per_thread);
-    }
-    if (max_blocks != 0) {
-        if (max_blocks < 1) return fail(SGMCMC_EINVAL, "max_blocks must be >= 1");
-        g_max_blocks.store(max_blocks);
-    }
-    if (nontemporal >= 0) {
-        if (nontemporal > 2) return fail(SGMCMC_EINVAL, "nontemporal must be 0 (off), 1 (on) or 2 (auto)");
-        g_nt.store(nontemporal);
-    }
-    return 0;
-}
-int sgmcmc_get_launch_config(int *block_threads, int *quads_per_thread, int *max_blocks, int *nontemporal)
-{
-    if (block_threads) *block_threads = g_block_threads.load();
-    if (quads_per_thread) *quads_per_thread = g_qpt.load();
-    if (max_blocks) *max_blocks = g_max_blocks.load();
-    if (nontemporal) *nontemporal = g_nt.load();
-    return 0;
-}
-
 int sgmcmc_sghmc_step_f32(float *theta, float *V, const float *grad, float *tau, float *g, float *v_hat,
                           float *minv, float *r, size_t n, float eps, float scale_grad, float mdecay, float grad_decay, int adapt,
                           const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, sgmcmc_stream_t stream)
+                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream)
 {
     return sghmc_step<float>(theta, V, grad, tau, g, v_hat, minv, r, n, eps, scale_grad, mdecay, grad_decay, adapt, xi, seed, step,
-                             step_dev, stats_ws, static_cast<hipStream_t>(stream));
+                             step_dev, stats_ws, launch, static_cast<hipStream_t>(stream));
 }
 int sgmcmc_sghmc_step_f64(double *theta, double *V, const double *grad, double *tau, double *g, double *v_hat,
                           double *minv, double *r, size_t n, double eps, double scale_grad, double mdecay, double grad_decay,
                           int adapt,
                           const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, sgmcmc_stream_t stream)
+                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream)
 {
     return sghmc_step<double>(theta, V, grad, tau, g, v_hat, minv, r, n, eps, scale_grad, mdecay, grad_decay, adapt, xi, seed, step,
-                              step_dev, stats_ws, static_cast<hipStream_t>(stream));
+                              step_dev, stats_ws, launch, static_cast<hipStream_t>(stream));
 }
 int sgmcmc_sgld_step_f32(float *theta, const float *grad, float *tau, float *g, float *v_hat, float *minv, float *r,
                          size_t n, float eps, float A, float scale_grad, float grad_decay, int adapt, const float *xi,
                          uint64_t seed,
-                         uint64_t step, const uint64_t *step_dev, void *stats_ws,
+                         uint64_t step, const uint64_t *step_dev, void *stats_ws, const sgmcmc_launch_t *launch,
                          sgmcmc_stream_t stream)
 {
     return sgld_step<float>(theta, grad, tau, g, v_hat, minv, r, n, eps, A, scale_grad, grad_decay, adapt, xi, seed, step, step_dev,
-                            stats_ws, static_cast<hipStream_t>(stream));
+                            stats_ws, launch, static_cast<hipStream_t>(stream));
 }
 int sgmcmc_sgld_step_f64(double *theta, const double *grad, double *tau, double *g, double *v_hat, double *minv,
                          double *r, size_t n, double eps, double A, double scale_grad, double grad_decay, int adapt,
                          const double *xi,
-                         uint64_t seed, uint64_t step, const uint64_t *step_dev, void *stats_ws,
+                         uint64_t seed, uint64_t step, const uint64_t *step_dev, void *stats_ws, const sgmcmc_launch_t *launch,
                          sgmcmc_stream_t stream)
 {
     return sgld_step<double>(theta, grad, tau, g, v_hat, minv, r, n, eps, A, scale_grad, grad_decay, adapt, xi, seed, step, step_dev,
-                             stats_ws, static_cast<hipStream_t>(stream));
+                             stats_ws, launch, static_cast<hipStream_t>(stream));
 }
 int sgmcmc_rsghmc_step_f32(float *theta, float *p, const float *grad_cost, size_t n, float eps, float mass, float c,
                            float D, float b_hat, float grad_decay, const float *xi, uint64_t seed, uint64_t step,
-                           const uint64_t *step_dev, void *stats_ws, sgmcmc_stream_t stream)
+                           const uint64_t *step_dev, void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream)
 {
     return rsghmc_step<float>(theta, p, grad_cost, n, eps, mass, c, D, b_hat, grad_decay, xi, seed, step, step_dev,
-                              stats_ws, static_cast<hipStream_t>(stream));
+                              stats_ws, launch, static_cast<hipStream_t>(stream));
 }
 int sgmcmc_rsghmc_step_f64(double *theta, double *p, const double *grad_cost, size_t n, double eps, double mass,
                            double c, double D, double b_hat, double grad_decay, const double *xi, uint64_t seed,
                            uint64_t step,
-                           const uint64_t *step_dev, void *stats_ws, sgmcmc_stream_t stream)
+                           const uint64_t *step_dev, void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream)
 {
     return rsghmc_step<double>(theta, p, grad_cost, n, eps, mass, c, D, b_hat, grad_decay, xi, seed, step, step_dev,
-                               stats_ws, static_cast<hipStream_t>(stream));
+                               stats_ws, launch, static_cast<hipStream_t>(stream));
 }
 size_t sgmcmc_step_stats_workspace_bytes(size_t n) { return (max_grid_for(n) + 1) * 4 * sizeof(double); }
 int sgmcmc_step_stats_finish(const void *stats_ws, double *stats_out, sgmcmc_stream_t stream)
@@ -901,19 +890,21 @@ int sgmcmc_step_stats_finish(const void *stats_ws, double *stats_out, sgmcmc_str
     return e == hipSuccess ? 0 : hip_fail(e, "launch stats_final");
 }
 
-int sgmcmc_philox_normal_f32(float *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
+int sgmcmc_philox_normal_f32(float *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+                             const sgmcmc_launch_t *launch_cfg, sgmcmc_stream_t stream)
 {
     if (n == 0) return 0;
     if (!out) return fail(SGMCMC_EINVAL, "philox_normal: out is NULL");
     NormalFillOp<float> op{out, make_key(seed, step, step_dev)};
-    return launch(op, n, aligned16(out), sizeof(*out), static_cast<hipStream_t>(stream));
+    return launch(op, n, aligned16(out), sizeof(*out), launch_cfg, static_cast<hipStream_t>(stream));
 }
-int sgmcmc_philox_normal_f64(double *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
+int sgmcmc_philox_normal_f64(double *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev,
+                             const sgmcmc_launch_t *launch_cfg, sgmcmc_stream_t stream)
 {
     if (n == 0) return 0;
     if (!out) return fail(SGMCMC_EINVAL, "philox_normal: out is NULL");
     NormalFillOp<double> op{out, make_key(seed, step, step_dev)};
-    return launch(op, n, aligned16(out), sizeof(*out), static_cast<hipStream_t>(stream));
+    return launch(op, n, aligned16(out), sizeof(*out), launch_cfg, static_cast<hipStream_t>(stream));
 }
 int sgmcmc_philox_bits_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t step, const uint64_t *step_dev, sgmcmc_stream_t stream)
 {
@@ -925,39 +916,51 @@ int sgmcmc_philox_bits_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t step
     return e == hipSuccess ? 0 : hip_fail(e, "launch philox_bits");
 }
 
-int sgmcmc_moments_update_f32(const float *theta, float *mean, float *m2, size_t n, uint64_t count, sgmcmc_stream_t stream)
+int sgmcmc_moments_update_f32(const float *theta, float *mean, float *m2, size_t n, uint64_t count,
+                              const sgmcmc_launch_t *launch_cfg, sgmcmc_stream_t stream)
 {
     if (n == 0) return 0;
     if (!theta || !mean || !m2 || count == 0) return fail(SGMCMC_EINVAL, "moments_update: NULL argument or count == 0");
     MomentsOp<float> op{theta, mean, m2, 1.0f / (float)count};
-    return launch(op, n, aligned16(theta) && aligned16(mean) && aligned16(m2), 5 * sizeof(*theta), static_cast<hipStream_t>(stream));
+    return launch(op, n, aligned16(theta) && aligned16(mean) && aligned16(m2), 5 * sizeof(*theta), launch_cfg, static_cast<hipStream_t>(stream));
 }
-int sgmcmc_moments_update_f64(const double *theta, double *mean, double *m2, size_t n, uint64_t count, sgmcmc_stream_t stream)
+int sgmcmc_moments_update_f64(const double *theta, double *mean, double *m2, size_t n, uint64_t count,
+                              const sgmcmc_launch_t *launch_cfg, sgmcmc_stream_t stream)
 {
     if (n == 0) return 0;
     if (!theta || !mean || !m2 || count == 0) return fail(SGMCMC_EINVAL, "moments_update: NULL argument or count == 0");
     MomentsOp<double> op{theta, mean, m2, 1.0 / (double)count};
-    return launch(op, n, aligned16(theta) && aligned16(mean) && aligned16(m2), 5 * sizeof(*theta), static_cast<hipStream_t>(stream));
+    return launch(op, n, aligned16(theta) && aligned16(mean) && aligned16(m2), 5 * sizeof(*theta), launch_cfg, static_cast<hipStream_t>(stream));
 }
 
-int sgmcmc_rhat_pack_f32(const float *mean, const float *m2, size_t n, uint64_t count, float *out3, sgmcmc_stream_t stream)
-{
-    if (n == 0) return 0;
-    if (!mean || !m2 || !out3 || count < 2) return fail(SGMCMC_EINVAL, "rhat_pack: NULL argument or count < 2");
-    hipLaunchKernelGGL(rhat_pack_kernel, dim3(small_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), mean, m2, n,
-                       1.0f / (float)(count - 1), out3);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : hip_fail(e, "launch rhat_pack");
-}
-int sgmcmc_rhat_finish_f32(const float *sum3, size_t n, int m_chains, uint64_t count, float *rhat, sgmcmc_stream_t stream)
-{
-    if (n == 0) return 0;
-    if (!sum3 || !rhat || m_chains < 2 || count < 2) return fail(SGMCMC_EINVAL, "rhat_finish: NULL argument, m_chains < 2 or count < 2");
-    hipLaunchKernelGGL(rhat_finish_kernel, dim3(small_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), sum3, n,
-                       (float)m_chains, (float)count, rhat);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : hip_fail(e, "launch rhat_finish");
-}
+#define SGMCMC_RHAT(SFX, T)                                                                                           \
+    int sgmcmc_rhat_pack_##SFX(const T *mean, const T *m2, size_t n, uint64_t count, T *out3, sgmcmc_stream_t stream) \
+    {                                                                                                                 \
+        if (n == 0) return 0;                                                                                         \
+        if (!mean || !m2 || !out3 || count < 2) return fail(SGMCMC_EINVAL, "rhat_pack: NULL argument or count < 2"); \
+        hipLaunchKernelGGL((rhat_pack_kernel<T>), dim3(small_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), \
+                           mean, m2, n, T(1) / (T)(count - 1), out3);                                                 \
+        hipError_t e = hipGetLastError();                                                                             \
+        return e == hipSuccess ? 0 : hip_fail(e, "launch rhat_pack");                                                 \
+    }                                                                                                                 \
+    int sgmcmc_rhat_finish_##SFX(const T *sum3, size_t n, int m_chains, uint64_t count, T *rhat, double *summary_out4, \
+                                 void *summary_ws, sgmcmc_stream_t stream)                                            \
+    {                                                                                                                 \
+        if (n == 0) return 0;                                                                                         \
+        if (!sum3 || !rhat || m_chains < 2 || count < 2)                                                              \
+            return fail(SGMCMC_EINVAL, "rhat_finish: NULL argument, m_chains < 2 or count < 2");                      \
+        if ((summary_out4 == nullptr) != (summary_ws == nullptr))                                                     \
+            return fail(SGMCMC_EINVAL, "rhat_finish: summary_out4 and summary_ws go together");                       \
+        hipLaunchKernelGGL((rhat_finish_kernel<T>), dim3(small_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), \
+                           sum3, n, (T)m_chains, (T)count, rhat);                                                     \
+        hipError_t e = hipGetLastError();                                                                             \
+        if (e != hipSuccess) return hip_fail(e, "launch rhat_finish");                                                \
+        /* device-side summary {sum, sum of squares, min, max} of R-hat: no host synchronisation on the path */      \
+        return summary_out4 ? summary<T>(rhat, n, summary_out4, summary_ws, static_cast<hipStream_t>(stream)) : 0;   \
+    }
+SGMCMC_RHAT(f32, float)
+SGMCMC_RHAT(f64, double)
+#undef SGMCMC_RHAT
 
 int sgmcmc_counter_add_u64(uint64_t *counter, uint64_t inc, sgmcmc_stream_t stream)
 {

@@ -25,7 +25,7 @@ import torch
 
 from pysgmcmc_amd import kernels
 
-__all__ = ["ChainMoments", "cross_chain_rhat", "RhatExchange", "gelman_rubin_from_chains", "ess_across_ranks", "effective_n",
+__all__ = ["ChainMoments", "cross_chain_rhat", "RhatExchange", "RhatSummary", "gelman_rubin_from_chains", "ess_across_ranks", "effective_n",
            "effective_sample_sizes", "gelman_rubin"]
 
 
@@ -56,10 +56,32 @@ class ChainMoments(object):
         return self.m2 / max(self.count - 1, 1)
 
 
+class RhatSummary(object):
+    """Device-resident K6 summary {sum, sum^2, min, max} of an R-hat vector. Reading it (``mean``, ``max``,
+    ``as_dict``) is the only host synchronisation; the exchange itself never waits for the host."""
+
+    def __init__(self, n, device):
+        self.n = int(n)
+        self.out4 = torch.zeros(4, dtype=torch.float64, device=device)
+        self.workspace = kernels.summary_workspace(device)
+
+    def as_dict(self):
+        s = self.out4.cpu().numpy()
+        return {"mean": float(s[0] / self.n), "max": float(s[3])}
+
+    @property
+    def mean(self):
+        return self.as_dict()["mean"]
+
+    @property
+    def max(self):
+        return self.as_dict()["max"]
+
+
 def cross_chain_rhat(moments, group=None, pack=None, rhat=None, with_summary=True):
     """R-hat of every parameter across the chains of the process group.
 
-    One all-reduce of ``3 * n`` floats. All ranks must call with the same
+    One all-reduce of ``3 * n`` elements in the moments' dtype. All ranks must call with the same
     ``moments.count``. Returns ``(rhat, summary)`` with ``summary = {"mean", "max"}``
     (python floats; forces a sync) or ``None`` when ``with_summary`` is False.
     """
@@ -70,30 +92,38 @@ def cross_chain_rhat(moments, group=None, pack=None, rhat=None, with_summary=Tru
     if world < 2:
         raise RuntimeError("R-hat needs at least 2 chains")
     n = moments.n
+    dt, dev = moments.mean.dtype, moments.mean.device
     if pack is None:
-        pack = torch.empty(3 * n, dtype=torch.float32, device=moments.mean.device)
+        pack = torch.empty(3 * n, dtype=dt, device=dev)
     if rhat is None:
-        rhat = torch.empty(n, dtype=torch.float32, device=moments.mean.device)
+        rhat = torch.empty(n, dtype=dt, device=dev)
     kernels.rhat_pack(moments.mean, moments.m2, moments.count, pack)
     dist.all_reduce(pack, group=group)
-    kernels.rhat_finish(pack, n, world, moments.count, rhat)
     if not with_summary:
+        kernels.rhat_finish(pack, n, world, moments.count, rhat)
         return rhat, None
-    s = kernels.summary(rhat).cpu().numpy()
-    return rhat, {"mean": float(s[0] / n), "max": float(s[3])}
+    summ = RhatSummary(n, dev)
+    kernels.rhat_finish(pack, n, world, moments.count, rhat, summ.out4, summ.workspace)
+    return rhat, summ.as_dict()
 
 
 class RhatExchange(object):
     """Non-blocking form of :func:`cross_chain_rhat`: ``start`` packs a snapshot of the moments and
     issues the all-reduce asynchronously on RCCL's own stream, sampling continues, ``finish`` waits
-    for the collective and computes R-hat. The snapshot buffer is private, so the chain may keep
-    updating its moments in between (overlaps the only collective of the path with compute)."""
+    (stream-level) for the collective and computes R-hat. The snapshot buffer is private, so the chain may
+    keep updating its moments in between (overlaps the only collective of the path with compute).
 
-    def __init__(self, n, device, group=None):
+    ``finish()`` never synchronises with the host: the R-hat summary stays in device memory
+    (``exchange.summary``, a :class:`RhatSummary`) and is read when the caller asks for it.
+    ``finish(with_summary=True)`` reads it immediately (a ``.cpu()`` sync; end-of-run reporting)."""
+
+    def __init__(self, n, device, group=None, dtype=torch.float32):
         self.n = int(n)
         self.group = group
-        self.pack = torch.empty(3 * self.n, dtype=torch.float32, device=device)
-        self.rhat = torch.empty(self.n, dtype=torch.float32, device=device)
+        self.pack = torch.empty(3 * self.n, dtype=dtype, device=device)
+        self.rhat = torch.empty(self.n, dtype=dtype, device=device)
+        self.summary = RhatSummary(self.n, device)
+        self.exchanges = 0
         self._work = None
         self._count = 0
 
@@ -110,15 +140,14 @@ class RhatExchange(object):
         self._count = moments.count
         self._work = dist.all_reduce(self.pack, group=self.group, async_op=True)
 
-    def finish(self, with_summary=True):
+    def finish(self, with_summary=False):
         dist = _dist()
         self._work.wait()                     # stream-level wait: the current stream now depends on the collective
         self._work = None
-        kernels.rhat_finish(self.pack, self.n, dist.get_world_size(self.group), self._count, self.rhat)
-        if not with_summary:
-            return self.rhat, None
-        s = kernels.summary(self.rhat).cpu().numpy()
-        return self.rhat, {"mean": float(s[0] / self.n), "max": float(s[3])}
+        kernels.rhat_finish(self.pack, self.n, dist.get_world_size(self.group), self._count, self.rhat,
+                            self.summary.out4, self.summary.workspace)
+        self.exchanges += 1
+        return self.rhat, (self.summary.as_dict() if with_summary else None)
 
 
 def gelman_rubin_from_chains(chains):

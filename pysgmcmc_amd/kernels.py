@@ -15,7 +15,7 @@ from pysgmcmc_amd._lib import SgmcmcLibraryError, check, lib
 __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
-    "set_launch_config", "get_launch_config", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
+    "LaunchConfig", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
     "bnn_fused_sgld_steps", "window_gather", "tanh_rowdot", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
 ]
 
@@ -97,57 +97,91 @@ def _on(t):
     return torch.cuda.device(t.device)
 
 
+class LaunchConfig(object):
+    """Launch geometry of the streaming kernels (``sgmcmc_launch_t``; performance only, results never depend
+    on it). Pass one as ``launch=`` to a kernel call, or hang it on a sampler (``sampler.launch``). ``None``
+    everywhere = the library's measured defaults. There is no process-wide setting in the C ABI; the
+    module-level default below exists for the sweep tools and is plain Python state of the caller."""
+
+    __slots__ = ("_c",)
+
+    def __init__(self, block_threads=0, quads_per_thread=0, max_blocks=0, nontemporal=-1):
+        from pysgmcmc_amd._lib import LaunchStruct
+        self._c = LaunchStruct(int(block_threads), int(quads_per_thread), int(max_blocks), int(nontemporal))
+
+    def as_dict(self):
+        c = self._c
+        return {"block_threads": c.block_threads, "quads_per_thread": c.quads_per_thread,
+                "max_blocks": c.max_blocks, "nontemporal": c.nontemporal}
+
+
+_default_launch = None
+
+
 def set_launch_config(block_threads=0, quads_per_thread=0, max_blocks=0, nontemporal=-1):
-    check(lib().sgmcmc_set_launch_config(block_threads, quads_per_thread, max_blocks, nontemporal),
-          "sgmcmc_set_launch_config")
+    """Python-side default ``LaunchConfig`` for calls that pass no ``launch=`` (sweep tools). Validated by the
+    library at the next launch. ``set_launch_config()`` with no arguments restores the library defaults."""
+    global _default_launch
+    cfg = LaunchConfig(block_threads, quads_per_thread, max_blocks, nontemporal)
+    _default_launch = None if cfg.as_dict() == LaunchConfig().as_dict() else cfg
 
 
 def get_launch_config():
+    """The effective defaults: the library's (block_threads -1 = auto, 1 quad per lane, uncapped grid,
+    nontemporal 2 = auto) overlaid with the Python-side default."""
+    out = {"block_threads": -1, "quads_per_thread": 1, "max_blocks": 1 << 20, "nontemporal": 2}
+    if _default_launch is not None:
+        d = _default_launch.as_dict()
+        out.update({k: v for k, v in d.items() if v != (-1 if k == "nontemporal" else 0)})
+    return out
+
+
+def _launch(launch):
     import ctypes
-    a, b, c, d = (ctypes.c_int() for _ in range(4))
-    check(lib().sgmcmc_get_launch_config(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)),
-          "sgmcmc_get_launch_config")
-    return {"block_threads": a.value, "quads_per_thread": b.value, "max_blocks": c.value, "nontemporal": d.value}
+    cfg = launch if launch is not None else _default_launch
+    return None if cfg is None else ctypes.byref(cfg._c)
 
 
 def sghmc_step(theta, V, grad, tau, g, v_hat, minv, r, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step=0, step_dev=None,
-               stats=None, grad_decay=0.0):
+               stats=None, grad_decay=0.0, launch=None):
     """K1, one fused SGHMC step in place (pysgmcmc/samplers/sghmc.py:165-251)."""
     f = getattr(lib(), "sgmcmc_sghmc_step_" + _sfx(theta))
     with _on(theta):
         rc = f(_ptr(theta), _ptr(V, theta), _ptr(grad, theta), _ptr(tau, theta), _ptr(g, theta),
                _ptr(v_hat, theta), _ptr(minv, theta), _ptr(r, theta), theta.numel(),
                float(eps), float(scale_grad), float(mdecay), float(grad_decay), int(bool(adapt)), _ptr(xi, theta),
-               int(seed), int(step), _ctr(step_dev), *_stats(stats), _stream(theta))
+               int(seed), int(step), _ctr(step_dev), *_stats(stats), _launch(launch), _stream(theta))
     check(rc, "sgmcmc_sghmc_step")
 
 
 def sgld_step(theta, grad, tau, g, v_hat, minv, r, eps, A, scale_grad, adapt, xi=None, seed=0, step=0, step_dev=None,
-               stats=None, grad_decay=0.0):
+              stats=None, grad_decay=0.0, launch=None):
     """K2, one fused SGLD step in place (pysgmcmc/samplers/sgld.py:149-211)."""
     f = getattr(lib(), "sgmcmc_sgld_step_" + _sfx(theta))
     with _on(theta):
         rc = f(_ptr(theta), _ptr(grad, theta), _ptr(tau, theta), _ptr(g, theta), _ptr(v_hat, theta),
                _ptr(minv, theta), _ptr(r, theta), theta.numel(), float(eps), float(A), float(scale_grad),
-               float(grad_decay), int(bool(adapt)), _ptr(xi, theta), int(seed), int(step), _ctr(step_dev), *_stats(stats), _stream(theta))
+               float(grad_decay), int(bool(adapt)), _ptr(xi, theta), int(seed), int(step), _ctr(step_dev), *_stats(stats), _launch(launch),
+               _stream(theta))
     check(rc, "sgmcmc_sgld_step")
 
 
 def rsghmc_step(theta, p, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, step=0, step_dev=None,
-                stats=None, grad_decay=0.0):
+                stats=None, grad_decay=0.0, launch=None):
     """K3, one fused relativistic SGHMC step (pysgmcmc/samplers/relativistic_sghmc.py:120-140)."""
     f = getattr(lib(), "sgmcmc_rsghmc_step_" + _sfx(theta))
     with _on(theta):
         rc = f(_ptr(theta), _ptr(p, theta), _ptr(grad_cost, theta), theta.numel(), float(eps), float(mass),
-               float(c), float(D), float(b_hat), float(grad_decay), _ptr(xi, theta), int(seed), int(step), _ctr(step_dev), *_stats(stats), _stream(theta))
+               float(c), float(D), float(b_hat), float(grad_decay), _ptr(xi, theta), int(seed), int(step), _ctr(step_dev), *_stats(stats),
+               _launch(launch), _stream(theta))
     check(rc, "sgmcmc_rsghmc_step")
 
 
-def philox_normal(out, seed, step, step_dev=None):
+def philox_normal(out, seed, step, step_dev=None, launch=None):
     """K5, out[i] = xi(seed, step, i)."""
     f = getattr(lib(), "sgmcmc_philox_normal_" + _sfx(out))
     with _on(out):
-        rc = f(_ptr(out), out.numel(), int(seed), int(step), _ctr(step_dev), _stream(out))
+        rc = f(_ptr(out), out.numel(), int(seed), int(step), _ctr(step_dev), _launch(launch), _stream(out))
     check(rc, "sgmcmc_philox_normal")
     return out
 
@@ -161,29 +195,40 @@ def philox_bits(out, seed, step, step_dev=None):
     return out
 
 
-def moments_update(theta, mean, m2, count):
+def moments_update(theta, mean, m2, count, launch=None):
     """K4, Welford update of (mean, m2) with the sample theta; count includes it."""
     f = getattr(lib(), "sgmcmc_moments_update_" + _sfx(theta))
     with _on(theta):
-        rc = f(_ptr(theta), _ptr(mean, theta), _ptr(m2, theta), theta.numel(), int(count), _stream(theta))
+        rc = f(_ptr(theta), _ptr(mean, theta), _ptr(m2, theta), theta.numel(), int(count), _launch(launch), _stream(theta))
     check(rc, "sgmcmc_moments_update")
 
 
 def rhat_pack(mean, m2, count, out3):
-    if mean.dtype != torch.float32:
-        raise TypeError("rhat_pack is float32-only")
+    """``out3 = [mean | mean^2 | m2 / (count - 1)]``: this chain's contribution to the R-hat all-reduce."""
     if out3.numel() != 3 * mean.numel():
         raise ValueError("out3 must hold 3*n elements")
+    f = getattr(lib(), "sgmcmc_rhat_pack_" + _sfx(mean))
     with _on(mean):
-        rc = lib().sgmcmc_rhat_pack_f32(_ptr(mean), _ptr(m2, mean), mean.numel(), int(count), _ptr(out3),
-                                        _stream(mean))
-    check(rc, "sgmcmc_rhat_pack_f32")
+        rc = f(_ptr(mean), _ptr(m2, mean), mean.numel(), int(count), _ptr(out3), _stream(mean))
+    check(rc, "sgmcmc_rhat_pack")
 
 
-def rhat_finish(sum3, n, m_chains, count, rhat):
+def rhat_finish(sum3, n, m_chains, count, rhat, summary_out4=None, summary_workspace=None):
+    """R-hat of every parameter from the all-reduced pack. With ``summary_out4`` (float64[4] device tensor) and
+    ``summary_workspace`` the K6 summary {sum, sum^2, min, max} of R-hat is left on the device (no host sync)."""
+    f = getattr(lib(), "sgmcmc_rhat_finish_" + _sfx(sum3))
+    if rhat.dtype != sum3.dtype:
+        raise TypeError("rhat and sum3 must share a dtype")
+    if summary_out4 is not None and summary_out4.dtype != torch.float64:
+        raise TypeError("summary_out4 must be float64")
     with _on(sum3):
-        rc = lib().sgmcmc_rhat_finish_f32(_ptr(sum3), int(n), int(m_chains), int(count), _ptr(rhat), _stream(sum3))
-    check(rc, "sgmcmc_rhat_finish_f32")
+        rc = f(_ptr(sum3), int(n), int(m_chains), int(count), _ptr(rhat), _ptr(summary_out4), _ptr(summary_workspace),
+               _stream(sum3))
+    check(rc, "sgmcmc_rhat_finish")
+
+
+def summary_workspace(device):
+    return torch.empty(lib().sgmcmc_summary_workspace_bytes(), dtype=torch.uint8, device=device)
 
 
 def summary(x, out4=None, workspace=None):

@@ -105,6 +105,8 @@ class MCMCSampler(object):
         self.batch_generator = batch_generator
         self.session = session
         self.sample_format = "numpy"
+        # launch geometry of this chain's update kernel (kernels.LaunchConfig; None = library defaults)
+        self.launch = None
 
         params = list(params)
         for p in params:
@@ -134,6 +136,7 @@ class MCMCSampler(object):
         self._stats_out_valid = False
         # hipGraph mode
         self.use_hip_graph = False
+        self.max_full_graphs = 4              # "full" mode: graphs kept per (stepsize, phase) before falling back
         self._graphs = {}
         self._static_feeds = {}
         self._step_ctr = None
@@ -336,7 +339,9 @@ class MCMCSampler(object):
         then launched directly (stepsize / phase / Philox step by value, HIP events can bracket it).
         ``use_hip_graph = "full"``: the graph also holds the fused update (Philox step read from a
         device counter) and ``counter += 1``; a new (eps, phase) pair captures a new graph, so
-        constant-stepsize sampling replays one graph for burn-in and one for the frozen phase.
+        constant-stepsize sampling replays one graph for burn-in and one for the frozen phase. With a
+        scheduled stepsize the cache is bounded by ``max_full_graphs``; beyond it the sampler drops to
+        ``use_hip_graph = True`` for good (eps is then a by-value argument of a direct launch).
         Feeds are copied into static buffers first. Requirements: static feed shapes; a cost
         function without host synchronisation."""
         gen = self.batch_generator
@@ -373,6 +378,19 @@ class MCMCSampler(object):
             self._ctr_value = self.n_iterations
         key = self._graph_key(eps) if full else ("cost",)
         entry = self._graphs.get(key)
+        if entry is None and full and len(self._graphs) >= self.max_full_graphs:
+            # "full" bakes the stepsize into the captured update launch, one graph per (eps, phase). A stepsize
+            # SCHEDULE (e.g. BurnInRampStepsizeSchedule) would capture and keep a new graph every step: stop
+            # capturing, drop the cache and continue in cost-graph mode (update launched directly, eps by value).
+            import logging
+            logging.getLogger(__name__).warning(
+                "use_hip_graph='full': more than %d distinct (stepsize, phase) pairs -- the stepsize is scheduled; "
+                "switching this sampler to use_hip_graph=True (cost graph + direct update launch)", self.max_full_graphs)
+            self._graphs.clear()
+            self.use_hip_graph = True
+            full = False
+            key = ("cost",)
+            entry = None
         if entry is None:
             entry = self._capture(eps, full)
             self._graphs[key] = entry

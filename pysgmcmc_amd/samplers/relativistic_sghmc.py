@@ -10,9 +10,20 @@ for larger tensors it is the natural element-wise generalisation.
 Initial momenta. The reference draws them by adaptive rejection sampling from
 p(p) ~ exp(-m c^2 sqrt(p^2/(m^2 c^2) + 1)) with the un-vendored ``arspy``
 package (``:208-223``; parity unpinned -- neither arspy nor its outputs are in the
-reference). Here they are drawn from the same law by inverse-CDF on a tabulated
+reference). ARS is an exact sampler, so any correct sampler of that law is
+distribution-identical. Here the draws are made by inverse-CDF on a tabulated
 CDF (65 537 knots, tail mass < 1e-13), driven by the chain's Philox stream
-(reserved step index 2^63), so a seed fixes them.
+(reserved step index 2^63), so a seed fixes them; tests/test_relativistic_momentum.py
+KS-tests them against a restatement of Gilks & Wild's sampler (oracle/ars_oracle.py)
+and against the law's quadrature CDF.
+
+``strict_reference_quirks`` (per-instance attribute, default ``False``; quirk Q5): the
+reference draws ONE momentum per parameter *tensor* on the host
+(``n_params=len(self.params)``, ``:108-113``) and reshapes every update to that scalar's
+shape, so it is only defined for 1-element parameters. ``sampler.strict_reference_quirks =
+True`` (before the first step) redraws the momenta that way -- ``len(params)`` draws from the
+host ``RandomState(seed)``, one per tensor -- and refuses parameters with more than one
+element like the reference's arithmetic does.
 """
 import numpy as np
 import torch
@@ -85,11 +96,37 @@ class RelativisticSGHMCSampler(MCMCSampler):
         self.speed_of_light = float(speed_of_light)
         self.D = float(D)
         self.Bhat = float(Bhat)
+        self._strict = False
+        self._draw_initial_momenta()
+
+    def _draw_initial_momenta(self):
+        if self._strict:
+            # the reference: one scalar per parameter tensor, drawn on the host (relativistic_sghmc.py:108-113)
+            sizes = self.arena.sizes
+            assert all(int(sz) == 1 for sz in sizes), (
+                "strict_reference_quirks: the reference keeps one scalar momentum per parameter tensor and reshapes the "
+                "update to its shape (relativistic_sghmc.py:108-113,126-129); only 1-element parameters are defined")
+            per_tensor = _sample_relativistic_momentum(m=self.mass, c=self.speed_of_light, n_params=len(self.params),
+                                                      seed=self.seed, device="cpu", dtype=self._torch_dtype)
+            row = self.arena.row("p")
+            for off, sz, val in zip(self.arena.offsets, sizes, per_tensor):
+                row[int(off):int(off) + int(sz)] = val.to(row.device)
+            return
         p0 = _sample_relativistic_momentum(
             m=self.mass, c=self.speed_of_light, n_params=self.arena.n,
             seed=self._philox_seed if self.device.type == "cuda" else self.seed,
             device=self.device, dtype=self._torch_dtype)
         self.arena.row("p").copy_(p0)
+
+    @property
+    def strict_reference_quirks(self):
+        return self._strict
+
+    @strict_reference_quirks.setter
+    def strict_reference_quirks(self, strict):
+        assert self.n_iterations == 0, "strict_reference_quirks selects how the INITIAL momenta are drawn: set it before stepping"
+        self._strict = bool(strict)
+        self._draw_initial_momenta()
 
     @property
     def momentum(self):
@@ -100,7 +137,7 @@ class RelativisticSGHMCSampler(MCMCSampler):
         kernels.rsghmc_step(
             a.row("theta"), a.row("p"), a.row("grad"),
             eps, self.mass, self.speed_of_light, self.D, self.Bhat,
-            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, **self._noise_args())
+            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, launch=self.launch, **self._noise_args())
         if self._stats is not None:
             self._stats_valid = True          # the workspace now holds this step's per-block partials
             self._stats_out_valid = False     # K7 runs lazily (sampler.stats); the BNN head reads the partials

@@ -10,18 +10,19 @@ from pysgmcmc_amd.samplers._fused_bnn import FusedBNNStepsMixin
 from pysgmcmc_amd.samplers.base_classes import BurnInMCMCSampler
 from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
 
-__all__ = ("SGLDSampler", "STRICT_REFERENCE_QUIRKS")
-
-# The reference never forwards `stepsize_schedule` to its base class
-# (sgld.py:96-100), so its SGLD always runs at the base default epsilon = 0.01
-# whatever the caller passes. That is a bug; it is fixed here by default. Set this
-# flag to True to reproduce the reference's behaviour exactly.
-STRICT_REFERENCE_QUIRKS = False
+__all__ = ("SGLDSampler",)
 
 
 class SGLDSampler(FusedBNNStepsMixin, BurnInMCMCSampler):
     """Stochastic Gradient Langevin Dynamics with the RMSprop-like preconditioner
-    adapted during burn-in (keywords/defaults as ``sgld.py:32-35``)."""
+    adapted during burn-in (keywords/defaults as ``sgld.py:32-35``).
+
+    ``strict_reference_quirks`` (per-instance attribute, default ``False``; not a constructor keyword so that
+    ``get_sampler``'s keyword reflection stays the reference's): the reference never forwards
+    ``stepsize_schedule`` to its base class (``sgld.py:96-100``, quirk Q1), so its SGLD always runs at the base
+    default ``ConstantStepsizeSchedule(0.01)`` whatever the caller passes. That is a bug and is fixed by default;
+    ``sampler.strict_reference_quirks = True`` reproduces it (the caller's schedule is then ignored, not even
+    ``update``d), ``= False`` switches back. Two samplers in one process can differ."""
 
     _STATE_ROWS = ("tau", "g", "v_hat", "minv")
     _FUSED_ROWS = ("theta", "grad", "tau", "g", "v_hat", "minv")          # row order of the fused small-model kernel
@@ -30,8 +31,9 @@ class SGLDSampler(FusedBNNStepsMixin, BurnInMCMCSampler):
                  stepsize_schedule=ConstantStepsizeSchedule(0.01),
                  burn_in_steps=3000, A=1.0, scale_grad=1.0,
                  session=None, dtype=torch.float64, seed=None):
-        if STRICT_REFERENCE_QUIRKS:
-            stepsize_schedule = ConstantStepsizeSchedule(0.01)
+        self._caller_schedule = stepsize_schedule
+        self._reference_schedule = ConstantStepsizeSchedule(0.01)      # base default, base_classes.py:323
+        self._strict = False
         super().__init__(
             params=params, cost_fun=cost_fun, batch_generator=batch_generator,
             burn_in_steps=burn_in_steps, seed=seed,
@@ -40,13 +42,23 @@ class SGLDSampler(FusedBNNStepsMixin, BurnInMCMCSampler):
         self.A = float(A)
         self.scale_grad = float(scale_grad)
 
+    @property
+    def strict_reference_quirks(self):
+        return self._strict
+
+    @strict_reference_quirks.setter
+    def strict_reference_quirks(self, strict):
+        self._strict = bool(strict)
+        self.stepsize_schedule = self._reference_schedule if self._strict else self._caller_schedule
+        self.epsilon = self.stepsize_schedule.initial_value
+
     def _kernel_step(self, eps, xi):
         a = self.arena
         kernels.sgld_step(
             a.row("theta"), a.row("grad"),
             a.row("tau"), a.row("g"), a.row("v_hat"), a.row("minv"), self._r_row(),
             eps, self.A, self.scale_grad, self._adapting,
-            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, **self._noise_args())
+            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, launch=self.launch, **self._noise_args())
         if self._stats is not None:
             self._stats_valid = True          # the workspace now holds this step's per-block partials
             self._stats_out_valid = False     # K7 runs lazily (sampler.stats); the BNN head reads the partials

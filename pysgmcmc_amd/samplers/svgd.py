@@ -14,8 +14,9 @@ Sign of the kernel-gradient term (quirk Q10). The reference adds
 (``svgd.py:124-127,139-143``). The driving term is right (``-K grad(cost) = K grad log p``)
 but the kernel-gradient term enters with the wrong sign: it pulls particles together
 instead of pushing them apart, and the particle cloud collapses onto the mode. That
-is a bug; it is fixed here by default (Liu & Wang's update). Set
-``STRICT_REFERENCE_QUIRKS = True`` to reproduce the reference's arithmetic exactly.
+is a bug; it is fixed here by default (Liu & Wang's update). Set the per-instance attribute
+``sampler.strict_reference_quirks = True`` to reproduce the reference's arithmetic exactly
+(``repulsion_sign = +1``); two samplers in one process can differ.
 """
 import torch
 
@@ -23,9 +24,7 @@ from pysgmcmc_amd import kernels
 from pysgmcmc_amd.samplers.base_classes import MCMCSampler
 from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
 
-__all__ = ("SVGDSampler", "STRICT_REFERENCE_QUIRKS")
-
-STRICT_REFERENCE_QUIRKS = False
+__all__ = ("SVGDSampler",)
 
 
 class SVGDSampler(MCMCSampler):
@@ -85,7 +84,7 @@ class SVGDSampler(MCMCSampler):
         self.fudge_factor = float(fudge_factor)
         self.n_particles = len(particles)
         self.particle_dim = sizes.pop()
-        self.repulsion_sign = 1 if STRICT_REFERENCE_QUIRKS else -1
+        self.repulsion_sign = -1              # Liu & Wang; +1 = the reference as written (strict_reference_quirks)
         # the particles as one [n, d] matrix: the theta row of the arena (svgd.py:84 tf.stack)
         self.particle_pitch = ((self.particle_dim + 63) // 64) * 64
         self.particles = self._matrix("theta")
@@ -95,6 +94,16 @@ class SVGDSampler(MCMCSampler):
         self._vmapped = None
         self._workspace = None
         self.collect_stats = False
+
+    @property
+    def strict_reference_quirks(self):
+        """True = the reference's update as written (attracting kernel-gradient term, quirk Q10)."""
+        return self.repulsion_sign == 1
+
+    @strict_reference_quirks.setter
+    def strict_reference_quirks(self, strict):
+        self.repulsion_sign = 1 if strict else -1
+        self._graphs.clear()                  # a fully captured step has the sign baked in
 
     # the base class differentiates `cost_fun(self.params)` particle by particle (n backward passes); a batched
     # cost differentiates the [n, d] matrix in one pass, and a plain per-particle cost is batched with

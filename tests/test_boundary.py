@@ -23,6 +23,7 @@ def test_header_declares_the_expected_entry_points():
     for name in ("sgmcmc_sghmc_step_f32", "sgmcmc_sghmc_step_f64", "sgmcmc_sgld_step_f32", "sgmcmc_sgld_step_f64",
                  "sgmcmc_rsghmc_step_f32", "sgmcmc_rsghmc_step_f64", "sgmcmc_philox_normal_f32",
                  "sgmcmc_moments_update_f32", "sgmcmc_rhat_pack_f32", "sgmcmc_rhat_finish_f32",
+                 "sgmcmc_rhat_pack_f64", "sgmcmc_rhat_finish_f64",
                  "sgmcmc_summary_f32", "sgmcmc_last_error", "sgmcmc_abi_version"):
         assert name in syms
 
@@ -34,12 +35,33 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in _declared_symbols():
         assert hasattr(handle, name), "libsgmcmc_hip.so does not export %s" % name
     lib = _lib.lib()
-    assert lib.sgmcmc_abi_version() == 1
+    assert lib.sgmcmc_abi_version() == _lib.ABI_VERSION == 2
     assert lib.sgmcmc_summary_workspace_bytes() >= 1024 * 32
-    # launch-config knobs are host-only: usable without a GPU
-    assert lib.sgmcmc_set_launch_config(-1, 1, 1 << 20, 2) == 0
-    assert lib.sgmcmc_set_launch_config(100, 0, 0, -1) != 0
-    assert b"block_threads" in lib.sgmcmc_last_error()
+    # the per-call launch geometry is validated on the host before anything is launched: checkable without a
+    # GPU (the output pointer is a dummy that is never dereferenced because the call fails first)
+    bad = _lib.LaunchStruct(100, 0, 0, -1)
+    rc = lib.sgmcmc_philox_normal_f32(ctypes.c_void_p(4096), 8, 1, 0, None, ctypes.byref(bad), None)
+    assert rc == -1 and b"block_threads" in lib.sgmcmc_last_error()
+    bad = _lib.LaunchStruct(0, 3, 0, -1)
+    rc = lib.sgmcmc_moments_update_f32(ctypes.c_void_p(4096), ctypes.c_void_p(4096), ctypes.c_void_p(4096), 8, 1,
+                                       ctypes.byref(bad), None)
+    assert rc == -1 and b"quads_per_thread" in lib.sgmcmc_last_error()
+
+
+def test_abi_holds_no_process_wide_state():
+    """no global mutable state. The launch-geometry setter of ABI v1 is gone; the header must not
+    declare, and the library must not export, any set/get configuration entry point."""
+    from pysgmcmc_amd import _lib
+    handle = ctypes.CDLL(_lib.build())
+    for name in ("sgmcmc_set_launch_config", "sgmcmc_get_launch_config"):
+        assert name not in _declared_symbols()
+        assert not hasattr(handle, name)
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.lib_path()], capture_output=True, text=True).stdout
+    # exported data symbols (B/D = bss/data) would be process-wide state; the one allowed is the THREAD-LOCAL
+    # error text behind sgmcmc_last_error() (sgmcmc_host::g_err, a TLS symbol)
+    data = [l for l in nm.splitlines() if l.split()[1:2] and l.split()[1] in ("B", "D") and "sgmcmc" in l.lower()
+            and "g_err" not in l]
+    assert not data, data
 
 
 def test_library_contains_gfx950_code_object():

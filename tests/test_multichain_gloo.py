@@ -56,7 +56,9 @@ def _worker(rank, world, port, out_dir):
     ex = RhatExchange(n, "cpu")
     ex.start(mom)
     next(s)
-    rhat2, summ2 = ex.finish()
+    rhat2, none = ex.finish()              # in-loop default: no host read of the summary
+    assert none is None and ex.exchanges == 1
+    summ2 = ex.summary.as_dict()           # read when asked for
     assert torch.equal(rhat, rhat2) and summ == summ2 and not ex.pending
     ess = ess_across_ranks(torch.tensor(trace, dtype=torch.float32))
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), kept=np.array(kept), rhat=rhat.numpy(),

@@ -123,17 +123,26 @@ def test_stepsize_schedule_is_fed_and_updated(shim):
 
 
 def test_sgld_forwards_schedule_unless_strict(shim):
-    from pysgmcmc_amd.samplers import sgld
     mk = lambda: SGLDSampler(params=[torch.tensor(0.0)], cost_fun=lambda p: p[0] ** 2,
                              stepsize_schedule=ConstantStepsizeSchedule(0.5), session="cpu", seed=0)
-    next(mk())
+    fixed, strict = mk(), mk()
+    strict.strict_reference_quirks = True          # reference bug sgld.py:96-100: schedule dropped (per instance)
+    next(fixed)
+    assert shim[-1][2] == 0.5 and not fixed.strict_reference_quirks
+    next(strict)
+    assert shim[-1][2] == 0.01 and strict.strict_reference_quirks
+    next(fixed)                                    # side by side in one process
     assert shim[-1][2] == 0.5
-    sgld.STRICT_REFERENCE_QUIRKS = True            # reference bug sgld.py:96-100: schedule dropped
-    try:
-        next(mk())
-        assert shim[-1][2] == 0.01
-    finally:
-        sgld.STRICT_REFERENCE_QUIRKS = False
+    strict.strict_reference_quirks = False
+    next(strict)
+    assert shim[-1][2] == 0.5
+    # the factory's samplers take the attribute the same way (it is not a constructor keyword)
+    from pysgmcmc_amd.sampling import Sampler
+    s = Sampler.get_sampler(Sampler.SGLD, params=[torch.tensor(0.0)], cost_fun=lambda p: p[0] ** 2,
+                            stepsize_schedule=ConstantStepsizeSchedule(0.5), session="cpu", seed=0)
+    s.strict_reference_quirks = True
+    next(s)
+    assert shim[-1][2] == 0.01
 
 
 def test_batches_are_fed_through_placeholders(shim):
@@ -277,12 +286,10 @@ def test_svgd_host_logic_matches_oracle_and_fixes_the_sign(shim):
     x0 = rng.normal(size=(10, 2))
 
     def run(strict, steps=200):
-        svgd_mod.STRICT_REFERENCE_QUIRKS = strict
-        try:
-            s = SVGDSampler(particles=[torch.tensor(r) for r in x0], cost_fun=lambda p: 0.5 * (p ** 2).sum(),
-                            session="cpu", dtype=torch.float64)
-        finally:
-            svgd_mod.STRICT_REFERENCE_QUIRKS = False
+        s = SVGDSampler(particles=[torch.tensor(r) for r in x0], cost_fun=lambda p: 0.5 * (p ** 2).sum(),
+                        session="cpu", dtype=torch.float64)
+        s.strict_reference_quirks = strict
+        assert s.repulsion_sign == (1 if strict else -1)
         assert iter(s) is s and s.n_particles == 10 and s.particle_dim == 2
         X, H = x0.copy(), np.zeros_like(x0)
         for t in range(steps):

@@ -201,12 +201,9 @@ def test_svgd_sampler_on_gpu_fits_a_gaussian_and_reference_sign_collapses():
     K_ref, kg_ref, _, _ = O.svgd_kernel(P.astype(np.float64))
     np.testing.assert_allclose(K.cpu().numpy(), K_ref, rtol=1e-4, atol=1e-5)
 
-    svgd_mod.STRICT_REFERENCE_QUIRKS = True
-    try:
-        s = Sampler.get_sampler(Sampler.SVGD, particles=[torch.tensor(r, device=DEV) for r in x0], cost_fun=cost,
-                                dtype=torch.float32)
-    finally:
-        svgd_mod.STRICT_REFERENCE_QUIRKS = False
+    s = Sampler.get_sampler(Sampler.SVGD, particles=[torch.tensor(r, device=DEV) for r in x0], cost_fun=cost,
+                            dtype=torch.float32)
+    s.strict_reference_quirks = True
     s.sample_format = "device"
     for _ in range(600):
         sample, _ = next(s)
