@@ -1,0 +1,213 @@
+"""SURVEY 8(f) row 3 and 8(e) on the device.
+
+(f3) ``effective_sample_sizes`` / ``gelman_rubin`` / ``PYSGMCMCTrace.from_sampler`` / ``pymc3_multitrace``
+(``pysgmcmc/diagnostics/sample_chains.py:14-384``, ``sampler_diagnostics.py:47-194``) driven by HIP samplers on the
+reference's toy targets; results must equal the oracle's formulas evaluated on the very samples the chains produced.
+
+(e) the N > 1 path with the REAL kernels: 2 ranks on ``cuda:0`` over gloo (RCCL refuses two ranks on one GPU; the
+transport is the only stand-in): K1 chains, K4 Welford moments, ``rhat_pack`` -> all-reduce -> ``rhat_finish``
+(+ device-side summary), the non-blocking ``RhatExchange``, the ESS all-gather -- checked against
+``oracle.gelman_rubin`` / ``oracle.effective_n`` on the chains' samples, in f32 and f64.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+from itertools import islice
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _targets():
+    from pysgmcmc_amd.diagnostics.objective_functions import (
+        banana_log_likelihood, gmm1_log_likelihood, to_negative_log_likelihood)
+    return {
+        "banana": (to_negative_log_likelihood(banana_log_likelihood),
+                   lambda dev: [torch.tensor(0.0, device=dev), torch.tensor(6.0, device=dev)]),
+        "gmm1": (to_negative_log_likelihood(gmm1_log_likelihood), lambda dev: [torch.tensor(0.0, device=dev)]),
+    }
+
+
+def _factory(kind, target, gpu, counter):
+    """``get_sampler(session=...)`` of the reference's diagnostics entry points: a fresh chain per call, another
+    seed per chain (``sampler_diagnostics.py:47-60``)."""
+    from pysgmcmc_amd.samplers import RelativisticSGHMCSampler, SGHMCSampler, SGLDSampler
+    from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+    cost, make = _targets()[target]
+    ctor = {"sghmc": SGHMCSampler, "sgld": SGLDSampler, "rsghmc": RelativisticSGHMCSampler}[kind]
+
+    def get_sampler(session=None):
+        counter.append(1)
+        kw = {} if kind == "rsghmc" else {"burn_in_steps": 20}
+        eps = 0.01 if kind == "rsghmc" else 0.05
+        return ctor(params=make(gpu), cost_fun=cost, stepsize_schedule=ConstantStepsizeSchedule(eps),
+                    session=gpu, dtype=torch.float32, seed=100 + len(counter), **kw)
+    return get_sampler
+
+
+@pytest.mark.parametrize("kind", ["sghmc", "sgld", "rsghmc"])
+@pytest.mark.parametrize("target", ["banana", "gmm1"])
+def test_reference_diagnostics_entry_points_with_hip_samplers(gpu, oracle, kind, target):
+    from pysgmcmc_amd.diagnostics.sample_chains import MultiTrace, PYSGMCMCTrace, pymc3_multitrace
+    from pysgmcmc_amd.diagnostics.sampler_diagnostics import effective_sample_sizes, gelman_rubin
+    n_vars = 2 if target == "banana" else 1
+    # --- PYSGMCMCTrace.from_sampler on the device chain (sample_chains.py:127-180)
+    calls = []
+    s = _factory(kind, target, gpu, calls)()
+    trace = PYSGMCMCTrace.from_sampler(chain_id=3, sampler=s, n_samples=40)
+    assert len(trace) == 40 and trace.chain == 3 and trace.n_vars == n_vars
+    assert trace.varnames == [str(i) for i in range(n_vars)]                       # enumerated names, :80-90
+    assert s.n_iterations == 40
+    last = [float(v) for v in s.arena.row("theta").cpu()]
+    assert [float(v) for v in trace.samples[-1]] == last                           # the trace holds the chain's own samples
+    assert np.array_equal(trace.get_values("0", burn=10, thin=3),
+                          np.asarray([smp[0] for smp in trace.samples[10::3]]))
+    assert set(trace.point(5)) == set(trace.varnames)
+    # --- pymc3_multitrace: fresh chains one after another (sample_chains.py:338-384)
+    calls = []
+    mt = pymc3_multitrace(_factory(kind, target, gpu, calls), n_chains=3, samples_per_chain=120)
+    assert isinstance(mt, MultiTrace) and mt.nchains == 3 and len(calls) == 3 and len(mt) == 120
+    chains = np.stack([np.stack([np.asarray(v, np.float64) for v in mt.get_values(name, combine=False)])
+                       for name in mt.varnames], axis=-1)                          # (m, n, vars)
+    assert chains.shape == (3, 120, n_vars) and np.isfinite(chains).all()
+    assert not np.array_equal(chains[0], chains[1])                                # another seed per chain
+    # --- gelman_rubin / effective_sample_sizes (sampler_diagnostics.py:47-194): the factories are deterministic
+    # (seed = 100 + call index), so the entry points see exactly the chains collected above
+    calls = []
+    rhat = gelman_rubin(_factory(kind, target, gpu, calls), n_chains=3, samples_per_chain=120)
+    calls = []
+    ess = effective_sample_sizes(_factory(kind, target, gpu, calls), n_chains=3, samples_per_chain=120)
+    assert sorted(rhat) == sorted(ess) == sorted(mt.varnames)
+    want_rhat = oracle.gelman_rubin(chains)
+    for k, name in enumerate(mt.varnames):
+        assert np.isclose(float(rhat[name]), want_rhat[k], rtol=1e-10), (name, rhat[name], want_rhat[k])
+        assert int(ess[name]) == oracle.effective_n(chains[:, :, k]), (name, ess[name])
+        assert float(rhat[name]) > 0.9 and 1 <= int(ess[name]) <= 3 * 120 * 3
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 2 ranks on cuda:0 with the real kernels
+# --------------------------------------------------------------------------------------------------------------
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+WORKER = r"""
+import os, sys, json
+import numpy as np, torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+rank, world, dtname, out_dir = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[1], sys.argv[2]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+from itertools import islice
+from pysgmcmc_amd import _lib, kernels
+from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange, cross_chain_rhat, ess_across_ranks
+from pysgmcmc_amd.samplers import SGHMCSampler
+from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+assert kernels.sghmc_step.__module__ == "pysgmcmc_amd.kernels"          # the real ctypes front end, no shim
+dt = torch.float32 if dtname == "float32" else torch.float64
+n = 4099                                                                  # ragged: not a multiple of 4
+x = torch.full((n,), 3.0 * (rank - 0.5), dtype=dt, device=dev)            # over-dispersed start per chain
+s = SGHMCSampler(params=[x], cost_fun=lambda p: 0.5 * (p[0] ** 2).sum(), burn_in_steps=50, session=dev,
+                 stepsize_schedule=ConstantStepsizeSchedule(0.1), dtype=dt, seed=100 + rank)
+s.sample_format = "view"
+mom = ChainMoments(n, dev, dtype=dt)
+kept, trace = [], []
+for t, (sample, cost) in enumerate(islice(s, 650)):
+    if t >= 50 and t % 3 == 0:
+        mom.update(s.arena.row("theta"))                                  # K4 on the device
+        kept.append(sample.detach().cpu().numpy().copy())
+        trace.append([float(cost), float(sample[0]), float(sample[1])])
+rhat, summ = cross_chain_rhat(mom)                                        # pack -> all-reduce -> finish (+ K6 summary)
+assert rhat.is_cuda and rhat.dtype == dt
+ex = RhatExchange(n, dev, dtype=dt)
+ex.start(mom)
+next(s)                                                                   # the chain moves on while the collective runs
+rhat2, none = ex.finish()
+assert none is None and torch.equal(rhat, rhat2) and ex.summary.as_dict() == summ and not ex.pending
+ess = ess_across_ranks(torch.tensor(trace, dtype=torch.float32, device=dev))
+np.savez(os.path.join(out_dir, "rank%d.npz" % rank), kept=np.array(kept), rhat=rhat.cpu().numpy(),
+         rhat_mean=summ["mean"], rhat_max=summ["max"], ess=np.array(ess), trace=np.array(trace),
+         mean=mom.mean.cpu().numpy(), m2=mom.m2.cpu().numpy(), count=mom.count,
+         lib=_lib.lib_path())
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("dtname", ["float32", "float64"])
+def test_two_ranks_on_one_gpu_real_kernels_rhat_and_ess(gpu, oracle, tmp_path, dtname):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2",
+                   LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script), dtname, str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=500)[0] for p in procs]
+    for p, out in zip(procs, outs):
+        assert p.returncode == 0, out[-3000:]
+    r = [np.load(str(tmp_path / ("rank%d.npz" % k))) for k in range(2)]
+    npdt = np.float32 if dtname == "float32" else np.float64
+    chains = np.stack([r[0]["kept"], r[1]["kept"]])                      # (2, 200, n)
+    assert chains.shape == (2, 200, 4099) and not np.array_equal(chains[0], chains[1])
+    # both ranks hold the same R-hat; it equals the oracle's Gelman-Rubin on the very samples
+    assert np.array_equal(r[0]["rhat"], r[1]["rhat"])
+    want = oracle.gelman_rubin(chains)
+    tol = 2e-3 if npdt == np.float32 else 1e-9                           # f32: Welford + sum-form B in single precision
+    assert np.allclose(r[0]["rhat"], want, rtol=tol), np.abs(r[0]["rhat"] / want - 1).max()
+    assert np.isclose(float(r[0]["rhat_max"]), float(r[0]["rhat"].max()), rtol=1e-6)
+    assert np.isclose(float(r[0]["rhat_mean"]), float(r[0]["rhat"].astype(np.float64).mean()), rtol=1e-6)
+    # bit-exact leg: K4 moments == the C oracle's Welford on the same samples, pack/finish == the C oracle's
+    for k in range(2):
+        mean, m2 = np.zeros(4099, npdt), np.zeros(4099, npdt)
+        for c, smp in enumerate(r[k]["kept"]):
+            oracle.c_moments_update(np.ascontiguousarray(smp.astype(npdt)), mean, m2, c + 1)
+        assert np.array_equal(mean, r[k]["mean"]) and np.array_equal(m2, r[k]["m2"])
+    total = sum(oracle.c_rhat_pack(r[k]["mean"], r[k]["m2"], int(r[k]["count"])) for k in range(2))
+    assert np.array_equal(oracle.c_rhat_finish(total.astype(npdt), 2, int(r[0]["count"])), r[0]["rhat"])
+    # ESS of cost and two coordinates from the all-gathered thinned traces
+    traces = np.stack([r[0]["trace"], r[1]["trace"]])                    # (2, 200, 3)
+    assert np.array_equal(r[0]["ess"], r[1]["ess"])
+    for k in range(3):
+        assert int(r[0]["ess"][k]) == oracle.effective_n(traces[:, :, k].astype(np.float32).astype(np.float64))
+    assert str(r[0]["lib"]).endswith("libsgmcmc_hip.so")
+
+
+@pytest.mark.timeout(900)
+def test_bench_n2_path_on_one_gpu(gpu, tmp_path):
+    """``bench.py --gpus 2`` as the driver launches it (torch.distributed.run, one rank per process), with both ranks on
+    cuda:0 over gloo: the line carries the rank count, the exchange timings and an R-hat summary, and N = 2 runs the
+    same step code as N = 1."""
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "4",
+           "--rhat-every", "8", "--moments-every", "2", "--backend", "gloo", "--all-ranks-on-gpu0", "--no-update-only"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                              # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "samples/s" and d["steps"] == 24
+    assert d["value"] > 0 and np.isclose(d["value"], 2 * 24 / (d["ms_per_step"] * 24 / 1e3), rtol=1e-3)
+    rc = d["rccl"]
+    assert rc["ranks"] == 2 and rc["exchanges_timed"] >= 2 and rc["payload_bytes"] == 3 * 4 * d["config"]["params"]
+    assert rc["rhat_exchange_ms"]["start_to_finish"] > 0 and rc["collective_alone_ms"] > 0
+    assert d["rhat"]["max"] >= d["rhat"]["mean"] > 0
+    assert d["roofline"]["launches_timed"] == 24 and 0 < d["roofline"]["frac"] < 1.2
+    assert "cpu_baseline" not in d

@@ -106,8 +106,12 @@ def test_bnn_golden_trajectory(gpu, dtname):
 def test_seed_reproducibility_philox(gpu, name, target):
     """The reference's sampler test (tests/samplers/sampler_testing.py:29-59) on the HIP path."""
     fn, make = TARGETS[target]
-    seed = int(np.random.randint(0, 2 ** 31 - 1))
-    n_samples = int(np.random.randint(1, 100))
+    # like the reference's test the seed and the chain length are arbitrary; drawn from a SEEDED generator so that
+    # a red run can be reproduced
+    import zlib
+    rng = np.random.RandomState(zlib.crc32(("%s|%s" % (name, target)).encode()))
+    seed = int(rng.randint(0, 2 ** 31 - 1))
+    n_samples = int(rng.randint(1, 100))
 
     def fresh_chain(sd):
         s = CTORS[name](params=make(torch.float32), cost_fun=to_negative_log_likelihood(fn), seed=sd,
