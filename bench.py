@@ -52,7 +52,7 @@ PRIME_FROZEN = 4               # frozen steps of the prime phase (moments + trac
 N_HBM_RESIDENT = 49_826_818    # configs[4]'s parameter count: 1.2 GB per frozen SGHMC launch
 
 
-def pmc_traffic(mode, n):
+def pmc_traffic(mode, n, stats_variant=False):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of the CURRENT kernels
     (tools/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950
     correction of MI355X_MICROARCH.md, calibrated on launches with known byte counts). Returns
@@ -60,7 +60,8 @@ def pmc_traffic(mode, n):
     try:
         with open(PMC_TRAFFIC_FILE) as fh:
             doc = json.load(fh)
-        entry = doc["sizes"][str(n)][mode]
+        sizes = doc["sizes"][str(n)]
+        entry = sizes.get(mode + "_stats", sizes[mode]) if stats_variant else sizes[mode]
         return int(round(entry["bytes_per_param"] * n)), "profiles/r02_pmc_traffic.json (%s)" % doc.get("collected", "?")
     except (OSError, KeyError, ValueError):
         return None, "no PMC pass for n=%d in profiles/r02_pmc_traffic.json" % n
@@ -598,7 +599,7 @@ def main():
         alg_bytes = BYTES_PER_PARAM[mode] * n
         achieved = alg_bytes / (k_us * 1e-6) / 1e9  # conservative: computed from the RAW bracket
         big = alg_bytes > (640 << 20)
-        traffic, traffic_src = pmc_traffic(mode, n)
+        traffic, traffic_src = pmc_traffic(mode, n, stats_variant=True)   # the pipeline launches the STATS variant
         # per-step device time: from the end of one step's update kernel to the end of the next one's
         ends = [b for _, b in timer.pairs]
         step_ms = np.array([ends[j].elapsed_time(ends[j + 1]) for j in range(len(ends) - 1)]) if len(ends) > 1 else None

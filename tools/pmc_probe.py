@@ -24,6 +24,7 @@ mean, m2, out = torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.em
 # flush: touch 1 GiB so nothing of the working set is left in the 256 MiB Infinity Cache between kernels
 junk = torch.empty(1 << 28, device=dev)
 flush = lambda: junk.fill_(1.0)
+st = kernels.StepStats(n, dev)
 for r in range(reps):
     flush(); kernels.philox_normal(out, 1, r)
     flush(); kernels.moments_update(theta, mean, m2, r + 1)
@@ -32,5 +33,9 @@ for r in range(reps):
     flush(); kernels.sgld_step(theta, grad, None, None, None, minv, None, 0.01, 1.0, 1e5, False, seed=1, step=r)
     flush(); kernels.sgld_step(theta, grad, tau, gg, vh, minv, None, 0.01, 1.0, 1e5, True, seed=1, step=r)
     flush(); kernels.rsghmc_step(theta, V, grad, 0.001, 1.0, 1.0, 1.0, 0.0, seed=1, step=r)
+    # the variants the samplers launch in the pipeline: fused step statistics (STATS = true)
+    flush(); kernels.sghmc_step(theta, V, grad, None, None, None, minv, None, 0.01, 1e5, 0.05, False, seed=1, step=r, stats=st)
+    flush(); kernels.sgld_step(theta, grad, None, None, None, minv, None, 0.01, 1.0, 1e5, False, seed=1, step=r, stats=st)
+    flush(); kernels.rsghmc_step(theta, V, grad, 0.001, 1.0, 1.0, 1.0, 0.0, seed=1, step=r, stats=st)
 torch.cuda.synchronize()
 print("probe done n=%d reps=%d" % (n, reps))
