@@ -71,6 +71,9 @@ def load_c():
         f = getattr(lib, "oracle_moments_update_" + sfx)
         f.argtypes = [vp, vp, vp, sz, u64]
         f.restype = ci
+        f = getattr(lib, "oracle_rsghmc_toy_chain_" + sfx)
+        f.argtypes = [ci, vp, ci, vp, vp, ci, real, real, real, real, real, u64, u64, u64, u64, vp]
+        f.restype = ci
         f = getattr(lib, "oracle_rhat_pack_" + sfx)
         f.argtypes = [vp, vp, sz, u64, vp]
         f.restype = ci
@@ -177,6 +180,33 @@ def c_moments_update(theta, mean, m2, count):
     f = getattr(lib, "oracle_moments_update_" + _sfx(theta.dtype))
     rc = f(_p(theta), _p(mean), _p(m2), theta.size, count)
     assert rc == 0
+
+
+GMM_TARGETS = {   # pysgmcmc/diagnostics/objective_functions.py:62-98
+    "gmm1": ((-5., 0., 5.), (1., 1., 1.), (1 / 3., 1 / 3., 1 / 3.)),
+    "gmm2": ((-5., 0., 5.), (1. / 0.5, 0.5, 1. / 0.5), (1 / 3., 1 / 3., 1 / 3.)),
+    "gmm3": ((-5., 0., 5.), (1. / 0.3, 0.3, 1. / 0.3), (1 / 3., 1 / 3., 1 / 3.)),
+}
+
+
+def c_rsghmc_toy_chain(target, theta, p, eps, n_steps, keep_every=1, first_step=0, seed=0, mass=1.0, c=1.0, D=1.0,
+                       b_hat=0.0):
+    """Run ``n_steps`` relativistic-SGHMC steps on a toy target ("gmm1/2/3" or "banana") entirely in C, updating
+    ``theta`` / ``p`` (1-D float arrays) in place; returns the kept samples ``[ceil(n_steps / keep_every), dim]``
+    (theta after steps first_step, first_step + keep_every, ...: ``islice(sampler, 0, n_steps, keep_every)``)."""
+    lib = load_c()
+    dt = theta.dtype
+    dim = theta.size
+    if target == "banana":
+        tid, tp, k = 1, np.zeros(1, dt), 0
+    else:
+        mu, var, w = GMM_TARGETS[target]
+        tid, tp, k = 0, np.ascontiguousarray(np.concatenate([mu, var, w]).astype(dt)), len(mu)
+    kept = np.empty(((n_steps + keep_every - 1) // keep_every, dim), dt)
+    rc = getattr(lib, "oracle_rsghmc_toy_chain_" + _sfx(dt))(tid, _p(tp), k, _p(theta), _p(p), dim, eps, mass, c, D, b_hat,
+                                                             seed, first_step, n_steps, keep_every, _p(kept))
+    assert rc == 0
+    return kept
 
 
 def c_rhat_pack(mean, m2, count):
