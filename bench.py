@@ -31,6 +31,7 @@ timed region. ``cpu_baseline`` (N = 1 only) = the same full step on the host cor
 BNN gradient + the fused C oracle update), unit samples/s like ``value``.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -48,7 +49,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MI
 BYTES_PER_PARAM = {"sghmc_frozen": 24, "sghmc_adapt": 48, "sgld_frozen": 16, "sgld_adapt": 40, "rsghmc": 20}
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 PRIME_BURN_IN = 8              # adapting steps of the chain, run in the prime phase (never timed)
-PRIME_FROZEN = 4               # frozen steps of the prime phase (moments + trace appended every step)
+PRIME_FROZEN = 4               # frozen steps of the prime phase with a moments update + trace append each
+PRIME_STEADY = int(os.environ.get("BENCH_PRIME_STEADY", "124"))   # further frozen steps: ~30 ms of device work, after which
+                               # the step time has settled (measured: 0.237 ms/step right after start-up, 0.218 after 100 steps)
 N_HBM_RESIDENT = 49_826_818    # configs[4]'s parameter count: 1.2 GB per frozen SGHMC launch
 
 
@@ -94,6 +97,8 @@ def parse():
     ap.add_argument("--no-gemm-tuning", action="store_true",
                     help="keep the BLAS heuristics instead of letting TunableOp pick the GEMM solutions in warm-up")
     ap.add_argument("--eager", action="store_true", help="step eagerly instead of replaying one hipGraph per step")
+    ap.add_argument("--max-queue-depth", type=int, default=64,
+                    help="steps the host may run ahead of the device in the timed loop (0 = unbounded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-update-only", action="store_true", help="skip the kernel-only loops (for rocprof runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline leg")
@@ -504,7 +509,7 @@ def main():
     # thinned low-dimensional trace for ESS: [cost, theta[c0], theta[c1], theta[c2]] every moments_every steps,
     # appended on the device (no sync); gathered across chains AFTER the timed region
     coords = torch.tensor([0, n // 2, n - 1], device=dev)
-    total_steps = PRIME_BURN_IN + PRIME_FROZEN + args.steps + args.warmup
+    total_steps = PRIME_BURN_IN + PRIME_FROZEN + PRIME_STEADY + args.steps + args.warmup
     trace = torch.zeros(total_steps // max(args.moments_every, 1) + PRIME_FROZEN + 2, 4, device=dev)
     kept = [0]
     ex_events = []                                                     # (start, packed, finish-begin, finish-end) HIP events
@@ -546,12 +551,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Host hygiene: a full (generation-2) Python garbage collection walks every object torch and numpy created at
+    # import time and takes ~40 ms here -- it fired once per ~250 steps INSIDE long timed regions and starved the
+    # device. Collect now, BEFORE the prime phase (a pause after it would let the device clocks drop again), and
+    # freeze the survivors (gc stays enabled; later collections only see new objects).
+    gc.collect()
+    if os.environ.get("BENCH_NO_GC_FREEZE") != "1":
+        gc.freeze()
     # ---- phase 1: PRIME (untimed, independent of --warmup): burn-in, then every other code path once
     for i in range(PRIME_BURN_IN):
         one_step(i, every=1 << 30)
     assert not getattr(sampler, "_adapting", False), "prime phase must leave the chain in the frozen phase"
     for i in range(PRIME_FROZEN):
         one_step(i, every=1)                                           # frozen step + K4 + trace append
+    for i in range(PRIME_STEADY):
+        one_step(i, every=1 << 30)                                     # plain frozen steps until the device runs steadily
     if exchange is not None:
         rhat_start()
         rhat_finish()
@@ -571,8 +585,13 @@ def main():
     fence()
     t0 = time.perf_counter()
     host_stamps = [t0]
+    depth = args.max_queue_depth
     for i in range(args.steps):
         one_step(i)
+        if depth and i >= depth:
+            # host-side flow control: never run more than `depth` steps ahead of the device (the HIP runtime lets the
+            # host queue ~750 steps and then stalls host AND device for milliseconds while it recycles its pools)
+            timer.pairs[i - depth][1].synchronize()
         host_stamps.append(time.perf_counter())                        # host-side enqueue time of each step (no sync)
     if exchange is not None and exchange.pending:                      # inside the timed region
         rhat_finish()
@@ -614,7 +633,8 @@ def main():
             # host side of the timed region: enqueue time per step (the device runs asynchronously behind it) and
             # the time the closing fence waited for the device to drain
             "host_enqueue_ms": {"first_step": round(float(host_ms[0]), 4), "median": round(float(np.median(host_ms)), 4),
-                                "max": round(float(host_ms.max()), 4), "final_fence": round(final_fence_ms, 4)},
+                                "max": round(float(host_ms.max()), 4), "argmax": int(host_ms.argmax()),
+                                "final_fence": round(final_fence_ms, 4)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s (%s) full next(sampler) step: BNN fwd+bwd + fused update; "
@@ -625,7 +645,8 @@ def main():
                        "rhat_every": args.rhat_every if world > 1 else None,
                        "moments_every": args.moments_every, "hip_graph": bool(sampler.use_hip_graph),
                        "gemm_tuning": not args.no_gemm_tuning,
-                       "prime_steps": {"burn_in": PRIME_BURN_IN, "frozen": PRIME_FROZEN},
+                       "prime_steps": {"burn_in": PRIME_BURN_IN, "frozen": PRIME_FROZEN + PRIME_STEADY},
+                       "max_queue_depth": args.max_queue_depth,
                        "launch": kernels.get_launch_config()},
             # template args: <Op<float, ADAPT, INJECT>, quads per lane, NT, STATS, LOOP>
             "roofline": {"bound": "hbm", "kernel": "stream_quads_vec<%s<float,%s,false>,1,%s,true,false>" % (

@@ -14,11 +14,14 @@ Two independent restatements of the reference arithmetic live under oracle/:
   of the TF-CPU sampler available in an image without TensorFlow ("baseline A"
   of BASELINE.md section 3) and the cross-check that pins the fused C code.
 
-PARITY PINNING STATUS: sampler trajectories are *unpinned* against reference
-outputs (TensorFlow cannot be run here and the reference tests hold no golden
-trajectories -- pysgmcmc/tests/samplers/sampler_testing.py:55-59). Pinned:
-safe_divide/safe_sqrt doctests, the BNN prior golden constants, Philox KATs,
-C-vs-numpy bit equality. See sgmcmc_oracle.c header and DESIGN.md.
+PARITY PINNING STATUS: pinned STATISTICALLY against outputs of the reference itself for the
+relativistic sampler (the ESS-vs-stepsize data file the reference holds under docs/, reproduced
+within 1-3 %; tests/test_reference_outputs.py) and by ONE printed ``next(sampler)`` of the
+quickstart notebook for SGHMC; SGHMC / SGLD trajectories are otherwise *unpinned* (TensorFlow
+cannot be run here and the reference tests hold no golden trajectories --
+pysgmcmc/tests/samplers/sampler_testing.py:55-59). Also pinned: safe_divide/safe_sqrt doctests,
+the BNN prior golden constants, Philox KATs, C-vs-numpy bit equality. See sgmcmc_oracle.c header
+and DESIGN.md section 4.
 
 Reference citations are relative to the pysgmcmc repository root.
 """

@@ -1,8 +1,9 @@
-mkdir -p gpurun_out/r02
-for i in 1 2 3 4; do
-python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null > gpurun_out/r02/driver_cmd_$i.json
-python3 -c "
+show() { python3 -c "
 import json,sys
-d=json.loads(open('gpurun_out/r02/driver_cmd_$i.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['step_ms_median'], d['step_ms_max'], d['host_enqueue_ms'], d['cpu_baseline']['value'])"
-done
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$1', d['value'], d['ms_per_step'], d['step_ms_median'], d['step_ms_max'], d['host_enqueue_ms'], d['roofline']['frac'])"; }
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-update-only 2>/dev/null | show drv
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-update-only 2>/dev/null | show drv
+python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | show drv_full
+python3 bench.py --no-cpu-baseline --no-update-only 2>/dev/null | show default
+python3 bench.py --gpus 1 --steps 2000 --warmup 20 --no-cpu-baseline --no-update-only 2>/dev/null | show long2000_d64
