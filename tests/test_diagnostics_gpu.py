@@ -211,3 +211,82 @@ def test_bench_n2_path_on_one_gpu(gpu, tmp_path):
     assert d["rhat"]["max"] >= d["rhat"]["mean"] > 0
     assert d["roofline"]["launches_timed"] == 24 and 0 < d["roofline"]["frac"] < 1.2
     assert "cpu_baseline" not in d
+
+
+RCCL_WORKER = r"""
+import os, sys
+import numpy as np, torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)          # "nccl" IS RCCL on ROCm
+from pysgmcmc_amd import kernels
+from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments
+from pysgmcmc_amd.data_batches import Placeholder, generate_batches
+from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
+from pysgmcmc_amd.samplers import SGHMCSampler
+from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+g = torch.Generator(device=dev).manual_seed(0)
+X, y = torch.randn(4096, 64, device=dev, generator=g), torch.randn(4096, device=dev, generator=g)
+
+def chain(graph):
+    xp, yp = Placeholder(dtype=torch.float32, device=dev), Placeholder(dtype=torch.float32, device=dev)
+    params = init_mlp_params(64, hidden=(512, 512), seed=3, dtype=torch.float32, device=dev)
+    s = SGHMCSampler(params=params, cost_fun=BNNCost(xp, yp, batch_size=128, n_examples=4096),
+                     batch_generator=generate_batches(X, y, xp, yp, batch_size=128, seed=1), burn_in_steps=4,
+                     stepsize_schedule=ConstantStepsizeSchedule(0.01), scale_grad=4096.0, session=dev,
+                     dtype=torch.float32, seed=9)
+    s.sample_format = "view"
+    s.use_hip_graph = graph
+    return s
+
+# reference run without any collective, eager
+ref = chain(False)
+for _ in range(40):
+    next(ref)
+want = ref.arena.row("theta").clone()
+# the same chain, cost pipeline captured into a hipGraph WHILE the RCCL communicator (and its watchdog thread) is alive,
+# with an asynchronous 3P-float all-reduce in flight during the steps
+s = chain(True)
+n = s.arena.n
+mom = ChainMoments(n, dev)
+pack = torch.empty(3 * n, device=dev)
+works = []
+for t in range(40):
+    next(s)
+    mom.update(s.arena.row("theta"))
+    if t in (9, 25):
+        kernels.rhat_pack(mom.mean, mom.m2, mom.count, pack)
+        snap = pack.clone()
+        works.append((dist.all_reduce(pack, async_op=True), snap))           # RCCL stream, overlaps the next steps
+    if t in (14, 30):
+        w, snap = works.pop()
+        w.wait()                                                              # stream-level dependency, no host sync
+        assert torch.equal(pack, snap)                                        # SUM over one rank = identity
+        # finish on a 2-chain total built from this chain twice: R-hat = sqrt((n-1)/n) exactly where W > 0
+        total = pack * 2
+        rhat = torch.empty(n, device=dev)
+        out4, ws = torch.zeros(4, dtype=torch.float64, device=dev), kernels.summary_workspace(dev)
+        kernels.rhat_finish(total, n, 2, mom.count, rhat, out4, ws)
+        c = float(mom.count)
+        assert torch.allclose(rhat, torch.full_like(rhat, ((c - 1) / c) ** 0.5), rtol=1e-3)
+assert not works
+assert torch.equal(s.arena.row("theta"), want), "graph-stepped chain next to RCCL traffic differs from the eager chain"
+dist.barrier()
+dist.destroy_process_group()
+print("rccl-ok", torch.cuda.get_device_name(0))
+"""
+
+
+@pytest.mark.timeout(600)
+def test_rccl_communicator_next_to_hipgraph_stepping(gpu, tmp_path):
+    """One rank, backend "nccl" (= RCCL): the communicator and its watchdog thread are alive while the sampler captures
+    and replays its hipGraph, and asynchronous all-reduces of the 3P-float R-hat payload are in flight during the steps
+    (the configs[3] pattern). The chain must equal the eager chain bit for bit and the exchange must return the payload."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=500)
+    assert res.returncode == 0 and "rccl-ok" in res.stdout, (res.stdout[-2000:], res.stderr[-3000:])
