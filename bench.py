@@ -505,7 +505,11 @@ def main():
     from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange
     moments = ChainMoments(n, dev)
     exchange = RhatExchange(n, dev) if world > 1 else None
-    half = max(args.rhat_every // 2, 1)
+    # R-hat cadence: --rhat-every steps (configs[3]: 100). A timed region shorter than that would contain no
+    # collective at all, so one exchange is then placed mid-run: its cost is inside `value` at every N > 1.
+    # (started after 2/3 of the steps, collected before the end, so it overlaps with sampling like the periodic ones).
+    rhat_every = args.rhat_every if args.steps >= args.rhat_every else max((2 * args.steps + 2) // 3, 1)
+    half = max(rhat_every // 2, 1)
     # thinned low-dimensional trace for ESS: [cost, theta[c0], theta[c1], theta[c2]] every moments_every steps,
     # appended on the device (no sync); gathered across chains AFTER the timed region
     coords = torch.tensor([0, n // 2, n - 1], device=dev)
@@ -513,6 +517,7 @@ def main():
     trace = torch.zeros(total_steps // max(args.moments_every, 1) + PRIME_FROZEN + 2, 4, device=dev)
     kept = [0]
     ex_events = []                                                     # (start, packed, finish-begin, finish-end) HIP events
+    periodic_exchange = [False]                                        # the periodic R-hat exchange runs in the timed region only
 
     def one_step(i, every=None):
         every = args.moments_every if every is None else every
@@ -522,13 +527,13 @@ def main():
             trace[kept[0], 0:1].copy_(cost.reshape(1))
             torch.index_select(sampler.arena.row("theta"), 0, coords, out=trace[kept[0], 1:4])
             kept[0] += 1
-        if exchange is not None:
+        if exchange is not None and periodic_exchange[0]:
             # the only exchange on the path: ONE all-reduce of 3P floats over RCCL/xGMI, issued
             # asynchronously and collected half a period later, so it overlaps with sampling.
             # finish() leaves the R-hat summary on the device: no host synchronisation in the loop.
-            if (i + 1) % args.rhat_every == 0 and moments.count >= 2 and not exchange.pending:
+            if (i + 1) % rhat_every == 0 and moments.count >= 2 and not exchange.pending:
                 rhat_start()
-            elif exchange.pending and (i + 1) % args.rhat_every == half:
+            elif exchange.pending and (i + 1) % rhat_every == half % rhat_every:
                 rhat_finish()
 
     def rhat_start():
@@ -572,16 +577,16 @@ def main():
         exchange.summary.as_dict()
     prime_rhat_events = len(ex_events)
     fence()
-    # ---- phase 2: --warmup untimed steps
-    moments.reset()
+    # ---- phase 2: --warmup untimed steps (the Welford moments keep accumulating from the prime phase on, so an R-hat
+    # exchange is possible from the first timed step)
     kept[0] = 0
     for i in range(args.warmup):
         one_step(i)
     frozen_phase = not getattr(sampler, "_adapting", False)
-    moments.reset()
     kept[0] = 0
     # ---- phase 3: the timed region
     timer.enabled = True
+    periodic_exchange[0] = True
     fence()
     t0 = time.perf_counter()
     host_stamps = [t0]
@@ -642,7 +647,7 @@ def main():
                                        args.workload, kind.upper(), mode, "-".join(map(str, WORKLOADS[args.workload]["layers"])),
                                        n, BATCH),
                        "params": n, "batch": BATCH, "chains": world,
-                       "rhat_every": args.rhat_every if world > 1 else None,
+                       "rhat_every": rhat_every if world > 1 else None,
                        "moments_every": args.moments_every, "hip_graph": bool(sampler.use_hip_graph),
                        "gemm_tuning": not args.no_gemm_tuning,
                        "prime_steps": {"burn_in": PRIME_BURN_IN, "frozen": PRIME_FROZEN + PRIME_STEADY},

@@ -188,29 +188,44 @@ def test_two_ranks_on_one_gpu_real_kernels_rhat_and_ess(gpu, oracle, tmp_path, d
     assert str(r[0]["lib"]).endswith("libsgmcmc_hip.so")
 
 
-@pytest.mark.timeout(900)
-def test_bench_n2_path_on_one_gpu(gpu, tmp_path):
-    """``bench.py --gpus 2`` as the driver launches it (torch.distributed.run, one rank per process), with both ranks on
-    cuda:0 over gloo: the line carries the rank count, the exchange timings and an R-hat summary, and N = 2 runs the
-    same step code as N = 1."""
+def _bench_n2(extra):
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "4",
-           "--rhat-every", "8", "--moments-every", "2", "--backend", "gloo", "--all-ranks-on-gpu0", "--no-update-only"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra + [
+           "--backend", "gloo", "--all-ranks-on-gpu0", "--no-update-only"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
     assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                              # ONE JSON line, from rank 0
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_n2_path_on_one_gpu(gpu):
+    """``bench.py --gpus 2`` as the driver launches it (torch.distributed.run, one rank per process), with both ranks on
+    cuda:0 over gloo: the line carries the rank count, the exchange timings and an R-hat summary, and N = 2 runs the
+    same step code as N = 1."""
+    d = _bench_n2(["--steps", "24", "--warmup", "4", "--rhat-every", "8", "--moments-every", "2"])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "samples/s" and d["steps"] == 24
     assert d["value"] > 0 and np.isclose(d["value"], 2 * 24 / (d["ms_per_step"] * 24 / 1e3), rtol=1e-3)
     rc = d["rccl"]
-    assert rc["ranks"] == 2 and rc["exchanges_timed"] >= 2 and rc["payload_bytes"] == 3 * 4 * d["config"]["params"]
+    assert rc["ranks"] == 2 and rc["exchanges_timed"] == 3 and rc["payload_bytes"] == 3 * 4 * d["config"]["params"]
     assert rc["rhat_exchange_ms"]["start_to_finish"] > 0 and rc["collective_alone_ms"] > 0
     assert d["rhat"]["max"] >= d["rhat"]["mean"] > 0
     assert d["roofline"]["launches_timed"] == 24 and 0 < d["roofline"]["frac"] < 1.2
     assert "cpu_baseline" not in d
+
+
+@pytest.mark.timeout(900)
+def test_bench_n2_driver_arguments_contain_one_exchange(gpu):
+    """With the driver's arguments (20 steps, 5 warm-up, default cadences) the timed region is shorter than the R-hat
+    period of configs[3]; exactly ONE exchange is then placed inside it (started after 2/3 of the steps, collected
+    before the end), so the collective's cost is in ``value`` at every N > 1."""
+    d = _bench_n2(["--steps", "20", "--warmup", "5"])
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["config"]["rhat_every"] == 14 and d["config"]["moments_every"] == 10
+    assert d["rccl"]["exchanges_timed"] == 1 and d["rccl"]["rhat_exchange_ms"]["start_to_finish"] > 0
+    assert d["rhat"] is not None and d["roofline"]["launches_timed"] == 20
 
 
 RCCL_WORKER = r"""
