@@ -194,6 +194,7 @@ struct SghmcOp {
     T grad_decay;                  // gradient term grad_decay * theta added in registers (0 = off)
     NoiseKey nk;
     double *stats_part;            // nullable: per-block partials of {sum theta'^2, sum V'^2, sum minv, sum minv^2}
+    static constexpr unsigned stats_mask = 0xfu;     // which of the 4 statistics this operator produces
     __device__ __forceinline__ void prepare() { nk.resolve(); }
     template <typename RegsT>
     __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
@@ -269,6 +270,7 @@ struct SgldOp {
     T grad_decay;
     NoiseKey nk;
     double *stats_part;
+    static constexpr unsigned stats_mask = 0xdu;     // no momentum: {theta'^2, -, minv, minv^2}
     __device__ __forceinline__ void prepare() { nk.resolve(); }
     template <typename RegsT>
     __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
@@ -339,6 +341,7 @@ struct RsghmcOp {
     T grad_decay;
     NoiseKey nk;
     double *stats_part;
+    static constexpr unsigned stats_mask = 0x3u;     // {theta'^2, p'^2}
     __device__ __forceinline__ void prepare() { nk.resolve(); }
     template <typename RegsT>
     __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
@@ -393,6 +396,7 @@ struct NormalFillOp {
     typedef T real;
     T *out; NoiseKey nk;
     static constexpr double *stats_part = nullptr;
+    static constexpr unsigned stats_mask = 0u;
     __device__ __forceinline__ void prepare() { nk.resolve(); }
     struct Regs { T z[4]; };
     __device__ __forceinline__ void accumulate(const Regs &, int, double (&)[4]) const {}
@@ -408,6 +412,7 @@ struct MomentsOp {
     typedef T real;
     const T *theta; T *mean, *m2; T inv;
     static constexpr double *stats_part = nullptr;
+    static constexpr unsigned stats_mask = 0u;
     __device__ __forceinline__ void prepare() {}
     struct Regs { T x[4], mu[4], m2[4]; };
     __device__ __forceinline__ void accumulate(const Regs &, int, double (&)[4]) const {}
@@ -454,6 +459,25 @@ __device__ __forceinline__ double wave_sum_dpp_lane63(double v)
     v += dpp_mov_f64<0x118, 0xf>(v);
     v += dpp_mov_f64<0x142, 0xa>(v);
     v += dpp_mov_f64<0x143, 0xc>(v);
+    return v;
+}
+
+// The same in single precision: ONE v_add_f32 with a DPP operand per step (6 instructions per statistic instead of
+// 18 for a double). Used by the f32 step kernels: every lane contributes the f32 sum of one quad's 4 terms, the 64-lane
+// tree adds at most 6 roundings (relative error < 4e-7, typically 1e-7); blocks and launches are combined in double.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp_lane63(float v)
+{
+    v += dpp_mov_f32<0xB1, 0xf>(v);
+    v += dpp_mov_f32<0x4E, 0xf>(v);
+    v += dpp_mov_f32<0x114, 0xf>(v);
+    v += dpp_mov_f32<0x118, 0xf>(v);
+    v += dpp_mov_f32<0x142, 0xa>(v);
+    v += dpp_mov_f32<0x143, 0xc>(v);
     return v;
 }
 

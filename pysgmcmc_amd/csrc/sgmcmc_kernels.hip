@@ -52,20 +52,28 @@ namespace {
 // 32-byte partial per block. A second, tiny kernel adds the partials in block order,
 // so the result is bit-reproducible for a given launch geometry. Costs no extra HBM
 // pass: the values are already in registers.
+// T = the kernel's dtype: f32 kernels reduce across the wave in f32 (6 DPP adds per statistic), f64 kernels in f64;
+// MASK = the statistics the operator produces (the others are written as 0 without any reduction work).
+template <typename T, unsigned MASK>
 __device__ __forceinline__ void stats_block_write(double (&acc)[4], double *__restrict__ part)
 {
-    __shared__ double lds[4][4];
+    __shared__ T lds[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        double v = wave_sum_dpp_lane63(acc[k]);
-        if (lane == 63) lds[wave][k] = v;
+        if constexpr (((MASK >> 0) & 0xfu) != 0u) {
+            if ((MASK >> k) & 1u) {
+                T v = wave_sum_dpp_lane63((T)acc[k]);
+                if (lane == 63) lds[wave][k] = v;
+            }
+        }
     }
     __syncthreads();
     if (threadIdx.x < 4) {
         const int nw = blockDim.x >> 6;
         double v = 0.0;
-        for (int w = 0; w < nw; ++w) v += lds[w][threadIdx.x];
+        if ((MASK >> threadIdx.x) & 1u)
+            for (int w = 0; w < nw; ++w) v += (double)lds[w][threadIdx.x];
         // workspace = 32-byte header {number of partials} + statistic-major partials [4][gridDim.x]
         part[4 + (size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
     }
@@ -152,7 +160,7 @@ __global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t n
         op.store_part_(nq_full, tail_cnt, R);
         if constexpr (stats) op.accumulate(R, tail_cnt, acc);
     }
-    if constexpr (stats) stats_block_write(acc, op.stats_part);
+    if constexpr (stats) stats_block_write<typename Op::real, Op::stats_mask>(acc, op.stats_part);
 }
 
 // element-wise path for misaligned arrays: same quads, same results
@@ -174,7 +182,7 @@ __global__ void __launch_bounds__(256) stream_quads_scalar(const Op op_in, size_
         op.store_part_(q, cnt, R);
         if constexpr (stats) op.accumulate(R, cnt, acc);
     }
-    if constexpr (stats) stats_block_write(acc, op.stats_part);
+    if constexpr (stats) stats_block_write<typename Op::real, Op::stats_mask>(acc, op.stats_part);
 }
 
 // --------------------------------------------------------------------------
