@@ -89,6 +89,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rhat-every", type=int, default=100, help="R-hat exchange cadence (steps), N > 1")
     ap.add_argument("--moments-every", type=int, default=10, help="Welford moments cadence (steps)")
+    ap.add_argument("--rhat-mode", choices=["reduce_scatter", "allreduce"], default="reduce_scatter",
+                    help="R-hat exchange: parameter-sharded reduce-scatter (half the xGMI traffic; default) or all-reduce")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bnn10m-sghmc")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 code path "
@@ -504,7 +506,7 @@ def main():
     timer = KernelTimer(sampler)
     from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange
     moments = ChainMoments(n, dev)
-    exchange = RhatExchange(n, dev) if world > 1 else None
+    exchange = RhatExchange(n, dev, mode=args.rhat_mode) if world > 1 else None
     # R-hat cadence: --rhat-every steps (configs[3]: 100). A timed region shorter than that would contain no
     # collective at all, so one exchange is then placed mid-run: its cost is inside `value` at every N > 1.
     # (started after 2/3 of the steps, collected before the end, so it overlaps with sampling like the periodic ones).
@@ -675,7 +677,7 @@ def main():
         if exchange is not None:
             timed = ex_events[prime_rhat_events:]
             done = [ev for ev in timed if len(ev) == 5]
-            line["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+            line["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "mode": exchange.mode,
                             "exchanges_timed": len(done),
                             "payload_bytes": int(exchange.pack.numel() * exchange.pack.element_size())}
             if done:
@@ -694,10 +696,14 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         ts = []
+        native_rs = exchange.mode == "reduce_scatter" and exchange._native_rs
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            dist.all_reduce(exchange.pack)
+            if native_rs:
+                dist.reduce_scatter_tensor(exchange.shard_sum, exchange.pack)
+            else:
+                dist.all_reduce(exchange.pack)
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))

@@ -161,20 +161,27 @@ int sgmcmc_moments_update_f64(const double *theta, double *mean, double *m2, siz
                               uint64_t count, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
 
 /* R-hat exchange step (replaces what pysgmcmc/diagnostics/sampler_diagnostics.py:118-194
- * delegates to pymc3.diagnostics.gelman_rubin). pack: out3[0:n] = mean, out3[n:2n] = mean^2,
- * out3[2n:3n] = m2/(count-1). The caller all-reduces (SUM) out3 across the m chains over RCCL
- * (torch.distributed), then finish: rhat[i] = sqrt(((W (cnt-1)/cnt) + B/cnt) / W) with
- * W = S_var/m, B = cnt * (S_sq - S_mean^2/m)/(m-1); one IEEE rounding per operation in the dtype.
+ * delegates to pymc3.diagnostics.gelman_rubin). The library owns no communicator: the host issues the collective
+ * (torch.distributed, backend "nccl" = RCCL) between pack and finish.
+ *   pack:   every chain writes [mean | mean^2 | m2/(count-1)] of its Welford moments.
+ *           n_shards = 1, shard_len = n: out3 = 3n elements, for ONE all-reduce(SUM) across the m chains.
+ *           n_shards = m, shard_len = ceil(n/m) (any padding): out3 = m chunks of [3][shard_len]; chunk s holds the
+ *           three rows of parameters [s*shard_len, (s+1)*shard_len) (zeros beyond n). ONE reduce-scatter(SUM) then
+ *           leaves on rank s the summed rows of ITS parameter shard: 3n(m-1)/m elements cross xGMI per rank instead
+ *           of the all-reduce's 6n(m-1)/m, and every rank finishes only n/m parameters.
+ *   finish: on [S_mean | S_sq | S_var] with row pitch ld, n valid elements:
+ *           rhat[i] = sqrt(((W (cnt-1)/cnt) + B/cnt) / W), W = S_var/m, B = cnt (S_sq - S_mean^2/m)/(m-1);
+ *           one IEEE rounding per operation in the dtype.
  * summary_out4 / summary_ws (both NULL or both given; ws = sgmcmc_summary_workspace_bytes()):
  * the K6 summary {sum, sum of squares, min, max} of rhat is left in DEVICE memory on the same
  * stream -- the in-loop exchange never synchronises with the host.                              */
-int sgmcmc_rhat_pack_f32(const float *mean, const float *m2, size_t n, uint64_t count,
+int sgmcmc_rhat_pack_f32(const float *mean, const float *m2, size_t n, uint64_t count, size_t n_shards, size_t shard_len,
                          float *out3, sgmcmc_stream_t stream);
-int sgmcmc_rhat_pack_f64(const double *mean, const double *m2, size_t n, uint64_t count,
+int sgmcmc_rhat_pack_f64(const double *mean, const double *m2, size_t n, uint64_t count, size_t n_shards, size_t shard_len,
                          double *out3, sgmcmc_stream_t stream);
-int sgmcmc_rhat_finish_f32(const float *sum3, size_t n, int m_chains, uint64_t count,
+int sgmcmc_rhat_finish_f32(const float *sum3, size_t n, size_t ld, int m_chains, uint64_t count,
                            float *rhat, double *summary_out4, void *summary_ws, sgmcmc_stream_t stream);
-int sgmcmc_rhat_finish_f64(const double *sum3, size_t n, int m_chains, uint64_t count,
+int sgmcmc_rhat_finish_f64(const double *sum3, size_t n, size_t ld, int m_chains, uint64_t count,
                            double *rhat, double *summary_out4, void *summary_ws, sgmcmc_stream_t stream);
 
 /* K6 -- deterministic summary of an array: out4 (device, 4 doubles) = {sum, sum of
@@ -338,8 +345,10 @@ int sgmcmc_svgd_kernel_f64(const double *particles, size_t n_particles, size_t d
  *  6. sgmcmc_moments_update_*: as proposed (+ launch).
  *  7. sgmcmc_rhat_allreduce(ncclComm_t) is NOT exported: the library would have to own an RCCL
  *     communicator and link librccl; instead the exchange is split into sgmcmc_rhat_pack_* /
- *     sgmcmc_rhat_finish_* around ONE all-reduce the host issues through torch.distributed
- *     (backend "nccl" = RCCL), which already owns the communicator. No torch/RCCL types in the ABI.
+ *     sgmcmc_rhat_finish_* around ONE collective the host issues through torch.distributed
+ *     (backend "nccl" = RCCL), which already owns the communicator: an all-reduce, or -- the sharded
+ *     layout -- a reduce-scatter (+ an all-gather of R-hat only if the full vector is wanted), the
+ *     "reduce-scatter + all-gather" of SURVEY 8(e). No torch/RCCL types in the ABI.
  *  8. sgmcmc_cpu_* is NOT exported by the product library: the CPU restatement is test
  *     infrastructure (oracle/libsgmcmc_oracle.so: oracle_sghmc_step_f32, ...), never shipped as a
  *     fallback -- the product path fails loudly without a GPU.

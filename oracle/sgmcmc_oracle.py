@@ -78,10 +78,10 @@ def load_c():
         f.argtypes = [ci, vp, ci, vp, vp, ci, real, real, real, real, real, u64, u64, u64, u64, vp]
         f.restype = ci
         f = getattr(lib, "oracle_rhat_pack_" + sfx)
-        f.argtypes = [vp, vp, sz, u64, vp]
+        f.argtypes = [vp, vp, sz, u64, sz, sz, vp]
         f.restype = ci
         f = getattr(lib, "oracle_rhat_finish_" + sfx)
-        f.argtypes = [vp, sz, ci, u64, vp]
+        f.argtypes = [vp, sz, sz, ci, u64, vp]
         f.restype = ci
         f = getattr(lib, "oracle_philox_normal_" + sfx)
         f.argtypes = [u64, u64, sz, vp]
@@ -212,21 +212,25 @@ def c_rsghmc_toy_chain(target, theta, p, eps, n_steps, keep_every=1, first_step=
     return kept
 
 
-def c_rhat_pack(mean, m2, count):
-    """[mean | mean^2 | m2/(count-1)] of one chain, in the arrays' dtype (the R-hat all-reduce payload)."""
+def c_rhat_pack(mean, m2, count, n_shards=1, shard_len=None):
+    """[mean | mean^2 | m2/(count-1)] of one chain in the arrays' dtype: the all-reduce payload (``n_shards = 1``) or
+    ``n_shards`` chunks of ``[3][shard_len]`` for a reduce-scatter (zero beyond ``n``)."""
     lib = load_c()
-    out3 = np.empty(3 * mean.size, mean.dtype)
-    rc = getattr(lib, "oracle_rhat_pack_" + _sfx(mean.dtype))(_p(mean), _p(m2), mean.size, int(count), _p(out3))
+    shard_len = mean.size if shard_len is None else int(shard_len)
+    out3 = np.empty(3 * n_shards * shard_len, mean.dtype)
+    rc = getattr(lib, "oracle_rhat_pack_" + _sfx(mean.dtype))(_p(mean), _p(m2), mean.size, int(count), int(n_shards),
+                                                              shard_len, _p(out3))
     assert rc == 0
     return out3
 
 
-def c_rhat_finish(sum3, m_chains, count):
-    """R-hat per parameter from the chain-summed pack, in the pack's dtype."""
+def c_rhat_finish(sum3, m_chains, count, n=None, ld=None):
+    """R-hat per parameter from the chain-summed rows (row pitch ``ld``, ``n`` valid), in the rows' dtype."""
     lib = load_c()
-    n = sum3.size // 3
+    ld = sum3.size // 3 if ld is None else int(ld)
+    n = ld if n is None else int(n)
     rhat = np.empty(n, sum3.dtype)
-    rc = getattr(lib, "oracle_rhat_finish_" + _sfx(sum3.dtype))(_p(sum3), n, int(m_chains), int(count), _p(rhat))
+    rc = getattr(lib, "oracle_rhat_finish_" + _sfx(sum3.dtype))(_p(sum3), n, ld, int(m_chains), int(count), _p(rhat))
     assert rc == 0
     return rhat
 

@@ -74,10 +74,10 @@ def _declare(lib):
         f.argtypes = [_vp, _vp, _vp, _sz, _u64, _lp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_rhat_pack_" + sfx)
-        f.argtypes = [_vp, _vp, _sz, _u64, _vp, _vp]
+        f.argtypes = [_vp, _vp, _sz, _u64, _sz, _sz, _vp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_rhat_finish_" + sfx)
-        f.argtypes = [_vp, _sz, _ci, _u64, _vp, _vp, _vp, _vp]
+        f.argtypes = [_vp, _sz, _sz, _ci, _u64, _vp, _vp, _vp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_bnn_head_" + sfx)
         f.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz] + [ctypes.c_double] * 6 + [_ci, _vp, _vp, _vp, _vp, _vp, _vp]

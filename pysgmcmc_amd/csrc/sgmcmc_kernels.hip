@@ -258,25 +258,33 @@ __global__ void __launch_bounds__(SUMMARY_THREADS) summary_final(const Summary *
 // --------------------------------------------------------------------------
 
 // One IEEE rounding per operation in T (fp contract off): the C oracle's rhat_pack / rhat_finish give the same bits.
+// Sharded layout: the padded index range [0, n_shards * shard_len) is cut into n_shards chunks, chunk s holds
+// [mean | mean^2 | var] of parameters [s * shard_len, (s + 1) * shard_len) -- what reduce_scatter hands to rank s.
+// n_shards = 1, shard_len = n is the plain [mean | mean^2 | var] layout of an all-reduce. Padding is written as 0.
 template <typename T>
 __global__ void __launch_bounds__(256) rhat_pack_kernel(const T *__restrict__ mean, const T *__restrict__ m2,
-                                                        size_t n, T inv_cm1, T *__restrict__ out3)
+                                                        size_t n, T inv_cm1, size_t shard_len, size_t total,
+                                                        T *__restrict__ out3)
 {
     const size_t G = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += G) {
-        T mu = mean[i];
-        out3[i] = mu;
-        out3[n + i] = mu * mu;
-        out3[2 * n + i] = m2[i] * inv_cm1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += G) {
+        const size_t s = i / shard_len, j = i - s * shard_len;
+        T mu = T(0), var = T(0);
+        if (i < n) { mu = mean[i]; var = m2[i] * inv_cm1; }
+        T *o = out3 + s * 3 * shard_len + j;
+        o[0] = mu;
+        o[shard_len] = mu * mu;
+        o[2 * shard_len] = var;
     }
 }
+// sum3 = [S_mean | S_sq | S_var] with row pitch ld; n = valid elements of this (shard of the) buffer
 template <typename T>
-__global__ void __launch_bounds__(256) rhat_finish_kernel(const T *__restrict__ sum3, size_t n, T m, T cnt,
+__global__ void __launch_bounds__(256) rhat_finish_kernel(const T *__restrict__ sum3, size_t n, size_t ld, T m, T cnt,
                                                           T *__restrict__ rhat)
 {
     const size_t G = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += G) {
-        T s_mean = sum3[i], s_sq = sum3[n + i], s_var = sum3[2 * n + i];
+        T s_mean = sum3[i], s_sq = sum3[ld + i], s_var = sum3[2 * ld + i];
         T W = s_var / m;
         T B = cnt * ((s_sq - (s_mean * s_mean) / m) / (m - T(1)));
         T Vhat = W * ((cnt - T(1)) / cnt) + B / cnt;
@@ -942,25 +950,29 @@ int sgmcmc_moments_update_f64(const double *theta, double *mean, double *m2, siz
 }
 
 #define SGMCMC_RHAT(SFX, T)                                                                                           \
-    int sgmcmc_rhat_pack_##SFX(const T *mean, const T *m2, size_t n, uint64_t count, T *out3, sgmcmc_stream_t stream) \
+    int sgmcmc_rhat_pack_##SFX(const T *mean, const T *m2, size_t n, uint64_t count, size_t n_shards, size_t shard_len, \
+                               T *out3, sgmcmc_stream_t stream)                                                       \
     {                                                                                                                 \
         if (n == 0) return 0;                                                                                         \
         if (!mean || !m2 || !out3 || count < 2) return fail(SGMCMC_EINVAL, "rhat_pack: NULL argument or count < 2"); \
-        hipLaunchKernelGGL((rhat_pack_kernel<T>), dim3(small_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), \
-                           mean, m2, n, T(1) / (T)(count - 1), out3);                                                 \
+        if (n_shards == 0 || shard_len == 0 || n_shards * shard_len < n || (n_shards - 1) * shard_len >= n)           \
+            return fail(SGMCMC_EINVAL, "rhat_pack: n_shards * shard_len must cover n with no empty shard");          \
+        const size_t total = n_shards * shard_len;                                                                    \
+        hipLaunchKernelGGL((rhat_pack_kernel<T>), dim3(small_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream), \
+                           mean, m2, n, T(1) / (T)(count - 1), shard_len, total, out3);                               \
         hipError_t e = hipGetLastError();                                                                             \
         return e == hipSuccess ? 0 : hip_fail(e, "launch rhat_pack");                                                 \
     }                                                                                                                 \
-    int sgmcmc_rhat_finish_##SFX(const T *sum3, size_t n, int m_chains, uint64_t count, T *rhat, double *summary_out4, \
-                                 void *summary_ws, sgmcmc_stream_t stream)                                            \
+    int sgmcmc_rhat_finish_##SFX(const T *sum3, size_t n, size_t ld, int m_chains, uint64_t count, T *rhat,          \
+                                 double *summary_out4, void *summary_ws, sgmcmc_stream_t stream)                      \
     {                                                                                                                 \
         if (n == 0) return 0;                                                                                         \
-        if (!sum3 || !rhat || m_chains < 2 || count < 2)                                                              \
-            return fail(SGMCMC_EINVAL, "rhat_finish: NULL argument, m_chains < 2 or count < 2");                      \
+        if (!sum3 || !rhat || m_chains < 2 || count < 2 || ld < n)                                                    \
+            return fail(SGMCMC_EINVAL, "rhat_finish: NULL argument, m_chains < 2, count < 2 or ld < n");              \
         if ((summary_out4 == nullptr) != (summary_ws == nullptr))                                                     \
             return fail(SGMCMC_EINVAL, "rhat_finish: summary_out4 and summary_ws go together");                       \
         hipLaunchKernelGGL((rhat_finish_kernel<T>), dim3(small_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), \
-                           sum3, n, (T)m_chains, (T)count, rhat);                                                     \
+                           sum3, n, ld, (T)m_chains, (T)count, rhat);                                                 \
         hipError_t e = hipGetLastError();                                                                             \
         if (e != hipSuccess) return hip_fail(e, "launch rhat_finish");                                                \
         /* device-side summary {sum, sum of squares, min, max} of R-hat: no host synchronisation on the path */      \

@@ -25,7 +25,7 @@ import torch
 
 from pysgmcmc_amd import kernels
 
-__all__ = ["ChainMoments", "cross_chain_rhat", "RhatExchange", "RhatSummary", "gelman_rubin_from_chains", "ess_across_ranks", "effective_n",
+__all__ = ["ChainMoments", "cross_chain_rhat", "RhatExchange", "RhatSummary", "ShardedRhatSummary", "gelman_rubin_from_chains", "ess_across_ranks", "effective_n",
            "effective_sample_sizes", "gelman_rubin"]
 
 
@@ -109,23 +109,56 @@ def cross_chain_rhat(moments, group=None, pack=None, rhat=None, with_summary=Tru
 
 class RhatExchange(object):
     """Non-blocking form of :func:`cross_chain_rhat`: ``start`` packs a snapshot of the moments and
-    issues the all-reduce asynchronously on RCCL's own stream, sampling continues, ``finish`` waits
-    (stream-level) for the collective and computes R-hat. The snapshot buffer is private, so the chain may
+    issues the collective asynchronously on RCCL's own stream, sampling continues, ``finish`` waits
+    (stream-level) for it and computes R-hat. The snapshot buffer is private, so the chain may
     keep updating its moments in between (overlaps the only collective of the path with compute).
 
+    ``mode``:
+      * ``"allreduce"``: ONE all-reduce(SUM) of ``3 n`` elements; every rank finishes all ``n`` parameters and holds
+        the full R-hat vector (``exchange.rhat``). Per rank ``6 n (m-1)/m`` elements cross xGMI.
+      * ``"reduce_scatter"`` (reduce-scatter + all-gather): the pack is laid out in ``m`` parameter
+        shards, ONE reduce-scatter(SUM) leaves on rank ``r`` the summed rows of shard ``r`` (``3 n (m-1)/m`` elements
+        per rank: half the traffic), every rank finishes only ``n/m`` parameters (``exchange.rhat`` = its shard), and the
+        K6 summaries of the shards are combined with an all-gather of 4 doubles. ``gather()`` all-gathers the R-hat
+        shards into the full vector when it is wanted (then ``4 n (m-1)/m`` in total, still 2/3 of the all-reduce).
+
     ``finish()`` never synchronises with the host: the R-hat summary stays in device memory
-    (``exchange.summary``, a :class:`RhatSummary`) and is read when the caller asks for it.
+    (``exchange.summary``) and is read when the caller asks for it.
     ``finish(with_summary=True)`` reads it immediately (a ``.cpu()`` sync; end-of-run reporting)."""
 
-    def __init__(self, n, device, group=None, dtype=torch.float32):
+    def __init__(self, n, device, group=None, dtype=torch.float32, mode="allreduce"):
+        assert mode in ("allreduce", "reduce_scatter")
         self.n = int(n)
         self.group = group
-        self.pack = torch.empty(3 * self.n, dtype=dtype, device=device)
-        self.rhat = torch.empty(self.n, dtype=dtype, device=device)
-        self.summary = RhatSummary(self.n, device)
+        self.mode = mode
         self.exchanges = 0
         self._work = None
         self._count = 0
+        if mode == "allreduce":
+            self.n_shards, self.shard_len, self.n_valid, self.rank = 1, self.n, self.n, 0
+            self.pack = torch.empty(3 * self.n, dtype=dtype, device=device)
+            self.shard_sum = self.pack
+            self.rhat = torch.empty(self.n, dtype=dtype, device=device)
+            self.summary = RhatSummary(self.n, device)
+            return
+        dist = _dist()
+        if dist is None or dist.get_world_size(group) < 2:
+            raise RuntimeError("RhatExchange(mode='reduce_scatter') needs an initialised process group with >= 2 chains")
+        m, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        L = (self.n + m - 1) // m
+        L4 = (L + 3) // 4 * 4                                   # 16-byte shard boundaries when no shard becomes empty
+        if (m - 1) * L4 < self.n:
+            L = L4
+        if (m - 1) * L >= self.n:
+            raise ValueError("RhatExchange: fewer parameters (%d) than chains (%d)" % (self.n, m))
+        self.n_shards, self.shard_len = m, L
+        self.n_valid = max(0, min(L, self.n - self.rank * L))
+        self.pack = torch.empty(3 * m * L, dtype=dtype, device=device)
+        self.shard_sum = torch.empty(3 * L, dtype=dtype, device=device)
+        self.rhat = torch.empty(L, dtype=dtype, device=device)     # this rank's shard of R-hat (first n_valid entries)
+        self.summary = ShardedRhatSummary(self.n, m, device, group)
+        # gloo (CPU tests, single-GPU rehearsals) has no reduce-scatter: all-reduce the pack, keep the own chunk
+        self._native_rs = str(dist.get_backend(group)).lower() == "nccl"
 
     @property
     def pending(self):
@@ -136,18 +169,61 @@ class RhatExchange(object):
         if dist is None or dist.get_world_size(self.group) < 2:
             raise RuntimeError("RhatExchange needs an initialised process group with >= 2 chains")
         assert not self.pending, "finish() the previous exchange first"
-        kernels.rhat_pack(moments.mean, moments.m2, moments.count, self.pack)
+        kernels.rhat_pack(moments.mean, moments.m2, moments.count, self.pack, self.n_shards, self.shard_len)
         self._count = moments.count
-        self._work = dist.all_reduce(self.pack, group=self.group, async_op=True)
+        if self.mode == "reduce_scatter" and self._native_rs:
+            self._work = dist.reduce_scatter_tensor(self.shard_sum, self.pack, group=self.group, async_op=True)
+        else:
+            self._work = dist.all_reduce(self.pack, group=self.group, async_op=True)
 
     def finish(self, with_summary=False):
         dist = _dist()
         self._work.wait()                     # stream-level wait: the current stream now depends on the collective
         self._work = None
-        kernels.rhat_finish(self.pack, self.n, dist.get_world_size(self.group), self._count, self.rhat,
-                            self.summary.out4, self.summary.workspace)
+        m = dist.get_world_size(self.group)
+        if self.mode == "reduce_scatter" and not self._native_rs:
+            L3 = 3 * self.shard_len
+            self.shard_sum.copy_(self.pack[self.rank * L3:(self.rank + 1) * L3])
+        kernels.rhat_finish(self.shard_sum, self.n_valid, m, self._count, self.rhat,
+                            self.summary.out4, self.summary.workspace, ld=self.shard_len)
+        if self.mode == "reduce_scatter":
+            self.summary.combine()            # all-gather of 4 doubles per rank, still no host synchronisation
         self.exchanges += 1
         return self.rhat, (self.summary.as_dict() if with_summary else None)
+
+    def gather(self):
+        """The full R-hat vector on every rank (``mode="reduce_scatter"``: one all-gather of the shards)."""
+        if self.mode == "allreduce":
+            return self.rhat
+        dist = _dist()
+        m = dist.get_world_size(self.group)
+        full = torch.empty(m * self.shard_len, dtype=self.rhat.dtype, device=self.rhat.device)
+        if self._native_rs:
+            dist.all_gather_into_tensor(full, self.rhat, group=self.group)
+        else:
+            parts = [torch.empty_like(self.rhat) for _ in range(m)]
+            dist.all_gather(parts, self.rhat, group=self.group)
+            full = torch.cat(parts)
+        return full[:self.n]
+
+
+class ShardedRhatSummary(RhatSummary):
+    """Summary of an R-hat vector that is spread over the ranks: every rank reduces its shard (K6), ``combine``
+    all-gathers the 4 doubles of each rank; ``as_dict`` (the host read) merges them."""
+
+    def __init__(self, n, m, device, group=None):
+        super().__init__(n, device)
+        self.group = group
+        self.all4 = torch.zeros(m, 4, dtype=torch.float64, device=device)
+
+    def combine(self):
+        dist = _dist()
+        parts = list(self.all4.unbind(0))
+        dist.all_gather(parts, self.out4, group=self.group)
+
+    def as_dict(self):
+        a = self.all4.cpu().numpy()
+        return {"mean": float(a[:, 0].sum() / self.n), "max": float(a[:, 3].max())}
 
 
 def gelman_rubin_from_chains(chains):

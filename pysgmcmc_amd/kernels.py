@@ -203,26 +203,34 @@ def moments_update(theta, mean, m2, count, launch=None):
     check(rc, "sgmcmc_moments_update")
 
 
-def rhat_pack(mean, m2, count, out3):
-    """``out3 = [mean | mean^2 | m2 / (count - 1)]``: this chain's contribution to the R-hat all-reduce."""
-    if out3.numel() != 3 * mean.numel():
-        raise ValueError("out3 must hold 3*n elements")
+def rhat_pack(mean, m2, count, out3, n_shards=1, shard_len=None):
+    """This chain's contribution to the R-hat exchange: ``[mean | mean^2 | m2 / (count - 1)]``, either as one
+    ``3 n`` buffer (``n_shards = 1``: all-reduce) or as ``n_shards`` chunks of ``[3][shard_len]`` (reduce-scatter:
+    chunk ``s`` = the rows of parameters ``[s * shard_len, (s + 1) * shard_len)``, zero beyond ``n``)."""
+    n = mean.numel()
+    shard_len = n if shard_len is None else int(shard_len)
+    if out3.numel() != 3 * int(n_shards) * shard_len:
+        raise ValueError("out3 must hold 3 * n_shards * shard_len elements")
     f = getattr(lib(), "sgmcmc_rhat_pack_" + _sfx(mean))
     with _on(mean):
-        rc = f(_ptr(mean), _ptr(m2, mean), mean.numel(), int(count), _ptr(out3), _stream(mean))
+        rc = f(_ptr(mean), _ptr(m2, mean), n, int(count), int(n_shards), shard_len, _ptr(out3), _stream(mean))
     check(rc, "sgmcmc_rhat_pack")
 
 
-def rhat_finish(sum3, n, m_chains, count, rhat, summary_out4=None, summary_workspace=None):
-    """R-hat of every parameter from the all-reduced pack. With ``summary_out4`` (float64[4] device tensor) and
-    ``summary_workspace`` the K6 summary {sum, sum^2, min, max} of R-hat is left on the device (no host sync)."""
+def rhat_finish(sum3, n, m_chains, count, rhat, summary_out4=None, summary_workspace=None, ld=None):
+    """R-hat of ``n`` parameters from the chain-summed rows ``sum3 = [S_mean | S_sq | S_var]`` (row pitch ``ld``,
+    default ``n``). With ``summary_out4`` (float64[4] device tensor) and ``summary_workspace`` the K6 summary
+    {sum, sum^2, min, max} of R-hat is left on the device (no host sync)."""
     f = getattr(lib(), "sgmcmc_rhat_finish_" + _sfx(sum3))
     if rhat.dtype != sum3.dtype:
         raise TypeError("rhat and sum3 must share a dtype")
     if summary_out4 is not None and summary_out4.dtype != torch.float64:
         raise TypeError("summary_out4 must be float64")
+    ld = int(n if ld is None else ld)
+    if sum3.numel() < 2 * ld + int(n) or rhat.numel() < int(n):
+        raise ValueError("rhat_finish: buffers shorter than n / ld say")
     with _on(sum3):
-        rc = f(_ptr(sum3), int(n), int(m_chains), int(count), _ptr(rhat), _ptr(summary_out4), _ptr(summary_workspace),
+        rc = f(_ptr(sum3), int(n), ld, int(m_chains), int(count), _ptr(rhat), _ptr(summary_out4), _ptr(summary_workspace),
                _stream(sum3))
     check(rc, "sgmcmc_rhat_finish")
 

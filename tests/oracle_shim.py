@@ -97,14 +97,14 @@ def moments_update(theta, mean, m2, count, launch=None):
     O.c_moments_update(theta.detach().numpy(), mean.numpy(), m2.numpy(), int(count))
 
 
-def rhat_pack(mean, m2, count, out3):
-    out3.numpy()[:] = O.c_rhat_pack(mean.numpy(), m2.numpy(), count)
+def rhat_pack(mean, m2, count, out3, n_shards=1, shard_len=None):
+    out3.numpy()[:] = O.c_rhat_pack(mean.numpy(), m2.numpy(), count, n_shards, shard_len)
 
 
-def rhat_finish(sum3, n, m_chains, count, rhat, summary_out4=None, summary_workspace=None):
-    rhat.numpy()[:] = O.c_rhat_finish(sum3.numpy(), m_chains, count)
+def rhat_finish(sum3, n, m_chains, count, rhat, summary_out4=None, summary_workspace=None, ld=None):
+    rhat.numpy()[:n] = O.c_rhat_finish(np.ascontiguousarray(sum3.numpy()), m_chains, count, n=n, ld=n if ld is None else ld)
     if summary_out4 is not None:
-        summary_out4.copy_(summary(rhat))
+        summary_out4.copy_(summary(rhat[:n]))
 
 
 def summary_workspace(device):

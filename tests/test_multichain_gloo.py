@@ -60,6 +60,18 @@ def _worker(rank, world, port, out_dir):
     assert none is None and ex.exchanges == 1
     summ2 = ex.summary.as_dict()           # read when asked for
     assert torch.equal(rhat, rhat2) and summ == summ2 and not ex.pending
+    # SURVEY 8(e) "reduce-scatter + all-gather": parameter-sharded exchange (gloo has no reduce-scatter: the class
+    # all-reduces the sharded pack and keeps its own chunk -- same layout, same finish on the shard, same summary)
+    rs = RhatExchange(n, "cpu", mode="reduce_scatter")
+    assert rs.n_shards == world and rs.shard_len == 20 and rs.n_valid == (20 if rank == 0 else 17)
+    rs.start(mom)
+    shard, none = rs.finish()
+    assert none is None and shard.numel() == 20
+    lo = rank * rs.shard_len
+    assert torch.equal(shard[:rs.n_valid], rhat[lo:lo + rs.n_valid])        # this rank's shard of the same R-hat
+    assert torch.equal(rs.gather(), rhat)                                    # all-gather of the shards = full vector
+    ssum = rs.summary.as_dict()
+    assert np.isclose(ssum["mean"], summ["mean"], rtol=1e-12) and ssum["max"] == summ["max"]
     ess = ess_across_ranks(torch.tensor(trace, dtype=torch.float32))
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), kept=np.array(kept), rhat=rhat.numpy(),
              rhat_mean=summ["mean"], rhat_max=summ["max"], ess=np.array(ess), trace=np.array(trace),
