@@ -139,25 +139,49 @@ def build_chain(dev, rank, workload="bnn10m-sghmc", burn_in=8):
 
 
 class KernelTimer(object):
-    """HIP-event timing of the fused update launch, on the stream it is launched on."""
+    """HIP-event timing of the fused update launch, on the stream it is launched on, two ways at once:
+      * ``kernel``: the launch carries a pair of events that receive the KERNEL's own start / stop timestamps
+        (``sgmcmc_launch_t.start_event / stop_event`` -> hipExtLaunchKernel; what rocprofv3 reports as the kernel's
+        duration) -- this is `roofline.achieved`;
+      * ``bracket``: a hipEventRecord pair around the call (r01's method; includes ~3-5 us of barrier-packet and
+        dispatch latency) -- reported next to it as the conservative figure."""
 
     def __init__(self, sampler):
         from pysgmcmc_amd import kernels
+        self.kernels = kernels
         self.pairs = []
+        self.kevents = []
+        self.pool = []
         self.enabled = False
+        self.bracket = os.environ.get("BENCH_BRACKET", "0") == "1"    # also put a hipEventRecord pair around each launch
         for name in ("sghmc_step", "sgld_step", "rsghmc_step"):   # each is ONE launch: the fused update kernel
             setattr(kernels, name, self._wrap(getattr(kernels, name)))
+
+    def reserve(self, n):
+        """Create the events of ``n`` timed launches up front (no hipEventCreate inside the timed region)."""
+        self.pool = [(self.kernels.KernelEvents(), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                     for _ in range(n)]
 
     def _wrap(self, inner):
         def timed(*a, **kw):
             if not self.enabled:
                 return inner(*a, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            kev, e0, e1 = self.pool.pop() if self.pool else (
+                self.kernels.KernelEvents(), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            base = kw.get("launch")
+            geom = base.as_dict() if base is not None else {}
+            kw["launch"] = self.kernels.LaunchConfig(events=kev, **geom)
+            if self.bracket:
+                e0.record()
             inner(*a, **kw)
-            e1.record()
-            self.pairs.append((e0, e1))
+            if self.bracket:
+                e1.record()
+                self.pairs.append((e0, e1))
+            self.kevents.append(kev)
         return timed
+
+    def kernel_us(self):
+        return np.array([k.elapsed_us() for k in self.kevents])
 
     @staticmethod
     def event_pair_overhead_us(reps=200):
@@ -207,8 +231,8 @@ def update_only(sampler, iters=200):
 
 def hbm_resident_roofline(dev, n=N_HBM_RESIDENT, iters=40):
     """The update kernels on a working set that cannot live in the 256 MiB Infinity Cache (configs[4]'s
-    49 826 818 parameters: 0.8-2.4 GB per launch). Every launch is bracketed by its own HIP event pair on the
-    stream it runs on (raw, conservative: includes the ~5 us event-pair overhead); state is synthetic
+    49 826 818 parameters: 0.8-2.4 GB per launch). Every launch carries its own HIP event pair that receives the
+    kernel's start/stop timestamps (plus a hipEventRecord bracket around it for comparison); state is synthetic
     (theta ~ N(0, 0.02^2), grad ~ N(0, 0.1^2), minv ~ U(0.5, 2)), in-register Philox noise."""
     from pysgmcmc_amd import kernels
     g = torch.Generator(device=dev).manual_seed(0)
@@ -217,33 +241,35 @@ def hbm_resident_roofline(dev, n=N_HBM_RESIDENT, iters=40):
     minv = torch.rand(n, device=dev, generator=g) * 1.5 + 0.5
     tau, gg, vh = (torch.ones(n, device=dev) for _ in range(3))
     calls = {
-        "sghmc_frozen": lambda i: kernels.sghmc_step(theta, V, grad, None, None, None, minv, None, 0.01, float(N_DATA),
-                                                     0.05, False, seed=1, step=i),
-        "sghmc_adapt": lambda i: kernels.sghmc_step(theta, V, grad, tau, gg, vh, minv, None, 0.01, float(N_DATA),
-                                                    0.05, True, seed=1, step=i),
-        "sgld_frozen": lambda i: kernels.sgld_step(theta, grad, None, None, None, minv, None, 1e-3, 1.0, float(N_DATA),
-                                                   False, seed=1, step=i),
-        "sgld_adapt": lambda i: kernels.sgld_step(theta, grad, tau, gg, vh, minv, None, 1e-3, 1.0, float(N_DATA),
-                                                  True, seed=1, step=i),
-        "rsghmc": lambda i: kernels.rsghmc_step(theta, V, grad, 1e-3, 1.0, 1.0, 1.0, 0.0, seed=1, step=i),
+        "sghmc_frozen": lambda i, L: kernels.sghmc_step(theta, V, grad, None, None, None, minv, None, 0.01, float(N_DATA),
+                                                        0.05, False, seed=1, step=i, launch=L),
+        "sghmc_adapt": lambda i, L: kernels.sghmc_step(theta, V, grad, tau, gg, vh, minv, None, 0.01, float(N_DATA),
+                                                       0.05, True, seed=1, step=i, launch=L),
+        "sgld_frozen": lambda i, L: kernels.sgld_step(theta, grad, None, None, None, minv, None, 1e-3, 1.0, float(N_DATA),
+                                                      False, seed=1, step=i, launch=L),
+        "sgld_adapt": lambda i, L: kernels.sgld_step(theta, grad, tau, gg, vh, minv, None, 1e-3, 1.0, float(N_DATA),
+                                                     True, seed=1, step=i, launch=L),
+        "rsghmc": lambda i, L: kernels.rsghmc_step(theta, V, grad, 1e-3, 1.0, 1.0, 1.0, 0.0, seed=1, step=i, launch=L),
     }
     out = {}
     for name, call in calls.items():
         for i in range(5):
-            call(i)
+            call(i, None)
         torch.cuda.synchronize()
-        pairs = []
+        pairs, kevs = [], [kernels.KernelEvents() for _ in range(iters)]
         for i in range(iters):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            call(5 + i)
+            call(5 + i, kernels.LaunchConfig(events=kevs[i]))
             e1.record()
             pairs.append((e0, e1))
         torch.cuda.synchronize()
-        us = np.array([a.elapsed_time(b) for a, b in pairs]) * 1e3
+        us = np.array([k.elapsed_us() for k in kevs])                   # the kernels' own timestamps
+        bracket = np.array([a.elapsed_time(b) for a, b in pairs]) * 1e3
         alg = BYTES_PER_PARAM[name] * n
         traffic, src = pmc_traffic(name, n)
         out[name] = {"us_per_launch_mean": round(float(us.mean()), 2), "us_per_launch_median": round(float(np.median(us)), 2),
+                     "us_bracket_mean": round(float(bracket.mean()), 2),
                      "algorithmic_bytes_per_launch": alg, "achieved": round(alg / (us.mean() * 1e-6) / 1e9, 1),
                      "frac": round(alg / (us.mean() * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "launches_timed": iters}
@@ -256,7 +282,8 @@ def hbm_resident_roofline(dev, n=N_HBM_RESIDENT, iters=40):
             "traffic": head["traffic"], "traffic_source": pmc_traffic("sghmc_frozen", n)[1],
             "params": n, "working_set_note": "%.2f GB per frozen SGHMC launch: HBM-resident, cannot be served by the 256 MiB "
                                              "Infinity Cache" % (head["algorithmic_bytes_per_launch"] / 1e9),
-            "timing": "hipEvent pair around every launch, back to back, after the timed region (not part of `value`)",
+            "timing": "kernel start/stop timestamps (hipExtLaunchKernel events) of every launch, back to back, after the "
+                      "timed region (not part of `value`); us_bracket_mean = hipEventRecord pair around the call",
             "kernels": out}
 
 
@@ -587,6 +614,7 @@ def main():
     frozen_phase = not getattr(sampler, "_adapting", False)
     kept[0] = 0
     # ---- phase 3: the timed region
+    timer.reserve(args.steps)
     timer.enabled = True
     periodic_exchange[0] = True
     fence()
@@ -598,7 +626,7 @@ def main():
         if depth and i >= depth:
             # host-side flow control: never run more than `depth` steps ahead of the device (the HIP runtime lets the
             # host queue ~750 steps and then stalls host AND device for milliseconds while it recycles its pools)
-            timer.pairs[i - depth][1].synchronize()
+            timer.kevents[i - depth].synchronize()
         host_stamps.append(time.perf_counter())                        # host-side enqueue time of each step (no sync)
     if exchange is not None and exchange.pending:                      # inside the timed region
         rhat_finish()
@@ -620,15 +648,17 @@ def main():
     if rank == 0:
         mode = "rsghmc" if kind == "rsghmc" else "%s_%s" % (kind, "frozen" if frozen_phase else "adapt")
         op_name = {"sghmc": "SghmcOp", "sgld": "SgldOp", "rsghmc": "RsghmcOp"}[kind]
-        k_us = timer.mean_us()                      # raw hipEvent bracket, includes the event-pair overhead
+        b_us = timer.mean_us()                      # hipEventRecord bracket around the call (BENCH_BRACKET=1), else None
         ev_us = timer.event_pair_overhead_us()
+        kern = timer.kernel_us()                    # the kernel's own start/stop timestamps, one pair per launch
+        k_us = float(kern.mean())
         alg_bytes = BYTES_PER_PARAM[mode] * n
-        achieved = alg_bytes / (k_us * 1e-6) / 1e9  # conservative: computed from the RAW bracket
+        achieved = alg_bytes / (k_us * 1e-6) / 1e9
         big = alg_bytes > (640 << 20)
         traffic, traffic_src = pmc_traffic(mode, n, stats_variant=True)   # the pipeline launches the STATS variant
         # per-step device time: from the end of one step's update kernel to the end of the next one's
-        ends = [b for _, b in timer.pairs]
-        step_ms = np.array([ends[j].elapsed_time(ends[j + 1]) for j in range(len(ends) - 1)]) if len(ends) > 1 else None
+        kv = timer.kevents
+        step_ms = np.array([kv[j].us_until(kv[j + 1]) for j in range(len(kv) - 1)]) * 1e-3 if len(kv) > 1 else None
         line = {
             "metric": "MCMC samples/sec + fused-update HBM GB/s (% roofline), BNN 10M params",
             "value": round(world * args.steps / elapsed, 2),
@@ -662,17 +692,23 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "us_per_launch_mean": round(k_us, 2), "us_per_launch_median": round(timer.median_us(), 2),
-                         "launches_timed": len(timer.pairs),
-                         "us_event_pair_overhead": round(ev_us, 2),
-                         "achieved_minus_event_overhead": round(alg_bytes / ((k_us - ev_us) * 1e-6) / 1e9, 1),
+                         "us_per_launch_mean": round(k_us, 2), "us_per_launch_median": round(float(np.median(kern)), 2),
+                         "us_per_launch_max": round(float(kern.max()), 2),
+                         "launches_timed": len(timer.kevents),
+                         # the conservative figure of round 1: hipEventRecord pair AROUND the call
+                         "bracket": None if b_us is None else {
+                             "us_per_launch_mean": round(b_us, 2), "us_per_launch_median": round(timer.median_us(), 2),
+                             "us_empty_event_pair": round(ev_us, 2),
+                             "achieved": round(alg_bytes / (b_us * 1e-6) / 1e9, 1),
+                             "frac": round(alg_bytes / (b_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
                          "cache_note": ("%.0f MB per launch: HBM-resident (larger than the 256 MiB Infinity Cache)" if big else
                                         "%.0f MB per launch fits the 256 MiB Infinity Cache: part of this rate is cache-"
                                         "assisted (it exceeds the 6.29 TB/s HBM copy ceiling of MI355X_MICROARCH.md); the "
                                         "HBM-resident figure is `roofline_hbm_resident`") % (alg_bytes / 1e6),
-                         "timing": "hipEvent pair around every launch of the timed region, in-pipeline (after the "
-                                   "GEMMs evicted part of the state from the Infinity Cache); rocprofv3 kernel-only "
-                                   "durations are in profiles/"},
+                         "timing": "every launch of the timed region carries a HIP event pair that receives the kernel's own "
+                                   "start/stop timestamps (hipExtLaunchKernel; the duration rocprofv3 reports, cf. "
+                                   "profiles/r02_bench10m_kernel_stats.csv), in-pipeline (after the GEMMs evicted part "
+                                   "of the state from the Infinity Cache); `bracket` = hipEventRecord pair around the call"},
         }
         if exchange is not None:
             timed = ex_events[prime_rhat_events:]

@@ -69,7 +69,19 @@ typedef struct sgmcmc_launch {
     int quads_per_thread;
     int max_blocks;
     int nontemporal;
+    /* Launch instrumentation (both NULL = none): hipEvent_t handles that receive the KERNEL's own start and stop
+     * timestamps (hipExtLaunchKernel: taken from the dispatch packet, the duration rocprofv3 reports), instead of
+     * the stream-position timestamps of hipEventRecord brackets, which add ~3 us of barrier-packet and dispatch
+     * latency around a launch. Read them with sgmcmc_event_elapsed_ms() after the stream has been synchronised.   */
+    void *start_event;
+    void *stop_event;
 } sgmcmc_launch_t;
+
+/* hipEvent_t helpers for the instrumentation above (timing-enabled events of the CURRENT device).                 */
+int sgmcmc_event_create(void **event_out);
+int sgmcmc_event_destroy(void *event);
+int sgmcmc_event_elapsed_ms(void *start_event, void *stop_event, float *ms_out);
+int sgmcmc_event_synchronize(void *event);      /* host waits until the event has completed */
 
 /* K1 -- fused SGHMC step. Replaces the op chain pysgmcmc/samplers/sghmc.py:165-251
  * (+ constants :111-117) and the burn-in switch pysgmcmc/samplers/base_classes.py:432-456.

@@ -47,7 +47,8 @@ _vp = ctypes.c_void_p
 
 class LaunchStruct(ctypes.Structure):
     """``sgmcmc_launch_t``: per-call launch geometry (0 / -1 = default)."""
-    _fields_ = [("block_threads", _ci), ("quads_per_thread", _ci), ("max_blocks", _ci), ("nontemporal", _ci)]
+    _fields_ = [("block_threads", _ci), ("quads_per_thread", _ci), ("max_blocks", _ci), ("nontemporal", _ci),
+                ("start_event", _vp), ("stop_event", _vp)]
 
 
 _lp = ctypes.POINTER(LaunchStruct)
@@ -57,6 +58,14 @@ def _declare(lib):
     lib.sgmcmc_abi_version.restype = _ci
     lib.sgmcmc_last_error.restype = ctypes.c_char_p
     lib.sgmcmc_device_count.restype = _ci
+    lib.sgmcmc_event_create.argtypes = [ctypes.POINTER(_vp)]
+    lib.sgmcmc_event_create.restype = _ci
+    lib.sgmcmc_event_destroy.argtypes = [_vp]
+    lib.sgmcmc_event_destroy.restype = _ci
+    lib.sgmcmc_event_elapsed_ms.argtypes = [_vp, _vp, ctypes.POINTER(ctypes.c_float)]
+    lib.sgmcmc_event_elapsed_ms.restype = _ci
+    lib.sgmcmc_event_synchronize.argtypes = [_vp]
+    lib.sgmcmc_event_synchronize.restype = _ci
     for sfx, real in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
         f = getattr(lib, "sgmcmc_sghmc_step_" + sfx)
         f.argtypes = [_vp] * 8 + [_sz, real, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp, _lp, _vp]

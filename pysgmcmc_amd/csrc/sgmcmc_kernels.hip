@@ -27,6 +27,7 @@
 //   * K6 (summary) is the only kernel with a reduction: wave shuffles ->
 //     LDS -> per-block partials -> fixed-order final pass.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -542,7 +543,16 @@ struct LaunchCfg {
     int max_blocks = 1 << 20;
     int nt = 2;                   // 0 = plain, 1 = nt, 2 = auto by working-set size
     int bt = 256;                 // resolved block size of this launch (set by launch_inner)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // kernel start / stop timestamps (hipExtLaunchKernel), both or none
 };
+// hipLaunchKernelGGL, or the timestamping launch when the caller passed events
+#define SGMCMC_LAUNCH(KERNEL, GRID, BLOCK, STREAM, CFG, ...)                                                         \
+    do {                                                                                                             \
+        if ((CFG).ev0 != nullptr || (CFG).ev1 != nullptr)                                                            \
+            hipExtLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, STREAM, (CFG).ev0, (CFG).ev1, 0, __VA_ARGS__); \
+        else                                                                                                         \
+            hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, STREAM, __VA_ARGS__);                             \
+    } while (0)
 // validates *in (0 / -1 fields keep the default); returns 0 or SGMCMC_EINVAL
 inline int resolve_launch(const sgmcmc_launch_t *in, LaunchCfg &c)
 {
@@ -566,6 +576,8 @@ inline int resolve_launch(const sgmcmc_launch_t *in, LaunchCfg &c)
             return fail(SGMCMC_EINVAL, "launch.nontemporal must be -1 (default), 0 (off), 1 (on) or 2 (auto)");
         c.nt = in->nontemporal;
     }
+    c.ev0 = static_cast<hipEvent_t>(in->start_event);
+    c.ev1 = static_cast<hipEvent_t>(in->stop_event);
     return 0;
 }
 // Above this many bytes touched per launch the arrays cannot stay in the 256 MiB
@@ -624,17 +636,17 @@ int launch_vec(const Op &op, size_t n, const LaunchCfg &cfg, hipStream_t st)
     if constexpr (QPT == 1) {
         if (want <= cap) {                                 // one quad per lane, whole array in one pass
             if (with_stats)
-                hipLaunchKernelGGL((stream_quads_vec<Op, 1, NT, true, false>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
+                SGMCMC_LAUNCH((stream_quads_vec<Op, 1, NT, true, false>), grid, bt, st, cfg, op, nq_full, tail);
             else
-                hipLaunchKernelGGL((stream_quads_vec<Op, 1, NT, false, false>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
+                SGMCMC_LAUNCH((stream_quads_vec<Op, 1, NT, false, false>), grid, bt, st, cfg, op, nq_full, tail);
             hipError_t e1 = hipGetLastError();
             return e1 == hipSuccess ? 0 : hip_fail(e1, "launch stream_quads_vec");
         }
     }
     if (with_stats)
-        hipLaunchKernelGGL((stream_quads_vec<Op, QPT, NT, true, true>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
+        SGMCMC_LAUNCH((stream_quads_vec<Op, QPT, NT, true, true>), grid, bt, st, cfg, op, nq_full, tail);
     else
-        hipLaunchKernelGGL((stream_quads_vec<Op, QPT, NT, false, true>), dim3(grid), dim3(bt), 0, st, op, nq_full, tail);
+        SGMCMC_LAUNCH((stream_quads_vec<Op, QPT, NT, false, true>), grid, bt, st, cfg, op, nq_full, tail);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch stream_quads_vec");
 }
@@ -648,9 +660,9 @@ int launch_scalar(const Op &op, size_t n, const LaunchCfg &cfg, hipStream_t st)
     size_t cap = (size_t)cfg.max_blocks;
     unsigned grid = (unsigned)(want < cap ? want : cap);
     if (op.stats_part != nullptr)
-        hipLaunchKernelGGL((stream_quads_scalar<Op, true>), dim3(grid), dim3(bt), 0, st, op, n);
+        SGMCMC_LAUNCH((stream_quads_scalar<Op, true>), grid, bt, st, cfg, op, n);
     else
-        hipLaunchKernelGGL((stream_quads_scalar<Op, false>), dim3(grid), dim3(bt), 0, st, op, n);
+        SGMCMC_LAUNCH((stream_quads_scalar<Op, false>), grid, bt, st, cfg, op, n);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch stream_quads_scalar");
 }
@@ -837,6 +849,35 @@ extern "C" {
 
 int sgmcmc_abi_version(void) { return SGMCMC_ABI_VERSION; }
 const char *sgmcmc_last_error(void) { return g_err; }
+
+int sgmcmc_event_create(void **event_out)
+{
+    if (!event_out) return fail(SGMCMC_EINVAL, "event_create: event_out is NULL");
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipEventCreate(&ev);
+    if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+    *event_out = ev;
+    return 0;
+}
+int sgmcmc_event_destroy(void *event)
+{
+    if (!event) return 0;
+    hipError_t e = hipEventDestroy(static_cast<hipEvent_t>(event));
+    return e == hipSuccess ? 0 : hip_fail(e, "hipEventDestroy");
+}
+int sgmcmc_event_elapsed_ms(void *start_event, void *stop_event, float *ms_out)
+{
+    if (!start_event || !stop_event || !ms_out) return fail(SGMCMC_EINVAL, "event_elapsed_ms: NULL argument");
+    hipError_t e = hipEventElapsedTime(ms_out, static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event));
+    return e == hipSuccess ? 0 : hip_fail(e, "hipEventElapsedTime");
+}
+
+int sgmcmc_event_synchronize(void *event)
+{
+    if (!event) return fail(SGMCMC_EINVAL, "event_synchronize: NULL argument");
+    hipError_t e = hipEventSynchronize(static_cast<hipEvent_t>(event));
+    return e == hipSuccess ? 0 : hip_fail(e, "hipEventSynchronize");
+}
 
 int sgmcmc_device_count(void)
 {

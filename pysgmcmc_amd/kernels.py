@@ -15,7 +15,7 @@ from pysgmcmc_amd._lib import SgmcmcLibraryError, check, lib
 __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
-    "LaunchConfig", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
+    "LaunchConfig", "KernelEvents", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
     "bnn_fused_sgld_steps", "window_gather", "tanh_rowdot", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
 ]
 
@@ -103,16 +103,55 @@ class LaunchConfig(object):
     everywhere = the library's measured defaults. There is no process-wide setting in the C ABI; the
     module-level default below exists for the sweep tools and is plain Python state of the caller."""
 
-    __slots__ = ("_c",)
+    __slots__ = ("_c", "events")
 
-    def __init__(self, block_threads=0, quads_per_thread=0, max_blocks=0, nontemporal=-1):
+    def __init__(self, block_threads=0, quads_per_thread=0, max_blocks=0, nontemporal=-1, events=None):
         from pysgmcmc_amd._lib import LaunchStruct
-        self._c = LaunchStruct(int(block_threads), int(quads_per_thread), int(max_blocks), int(nontemporal))
+        # events: a KernelEvents pair that receives the kernel's own start/stop timestamps (hipExtLaunchKernel)
+        self.events = events
+        self._c = LaunchStruct(int(block_threads), int(quads_per_thread), int(max_blocks), int(nontemporal),
+                               None if events is None else events.start, None if events is None else events.stop)
 
     def as_dict(self):
         c = self._c
         return {"block_threads": c.block_threads, "quads_per_thread": c.quads_per_thread,
                 "max_blocks": c.max_blocks, "nontemporal": c.nontemporal}
+
+
+class KernelEvents(object):
+    """A pair of HIP events that a launch fills with the KERNEL's own start and stop timestamps (the duration
+    rocprofv3 reports for the kernel), via ``LaunchConfig(events=...)``. ``elapsed_us()`` after a synchronise."""
+
+    def __init__(self):
+        import ctypes
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        check(lib().sgmcmc_event_create(ctypes.byref(a)), "sgmcmc_event_create")
+        check(lib().sgmcmc_event_create(ctypes.byref(b)), "sgmcmc_event_create")
+        self.start, self.stop = a.value, b.value
+
+    def elapsed_us(self):
+        import ctypes
+        ms = ctypes.c_float()
+        check(lib().sgmcmc_event_elapsed_ms(self.start, self.stop, ctypes.byref(ms)), "sgmcmc_event_elapsed_ms")
+        return float(ms.value) * 1e3
+
+    def us_until(self, later):
+        """Microseconds from the end of this kernel to the end of the kernel ``later`` timed."""
+        import ctypes
+        ms = ctypes.c_float()
+        check(lib().sgmcmc_event_elapsed_ms(self.stop, later.stop, ctypes.byref(ms)), "sgmcmc_event_elapsed_ms")
+        return float(ms.value) * 1e3
+
+    def synchronize(self):
+        """Block the host until the kernel has finished."""
+        check(lib().sgmcmc_event_synchronize(self.stop), "sgmcmc_event_synchronize")
+
+    def __del__(self):
+        try:
+            lib().sgmcmc_event_destroy(self.start)
+            lib().sgmcmc_event_destroy(self.stop)
+        except Exception:                     # interpreter shutdown
+            pass
 
 
 _default_launch = None

@@ -217,9 +217,86 @@ def test_register_noise_equals_injected_stream(gpu, oracle, npdt, thdt):
                 assert torch.equal(a.theta, b.theta) and torch.equal(a.V, b.V)
             results.append(a.theta.clone())
     finally:
-        kernels.set_launch_config(-1, 1, 1 << 20, 2)
+        kernels.set_launch_config()           # back to the library defaults (a Python-side default, not library state)
     for r in results[1:]:
         assert torch.equal(results[0], r)     # geometry never changes the samples
+
+
+def test_concurrent_host_threads_with_their_own_launch_geometry(gpu, oracle):
+    """the ABI holds no mutable state, so one host thread per chain is safe. Four threads step four chains
+    concurrently, each with its OWN per-call launch geometry (ABI v2: `const sgmcmc_launch_t *launch`) and its own HIP
+    stream; every chain must equal the chain stepped alone with the default geometry, and a bad geometry in one
+    thread raises there without disturbing the others."""
+    import threading
+    from pysgmcmc_amd import kernels
+    from pysgmcmc_amd._lib import SgmcmcLibraryError
+    n, steps = 200003, 25
+    rng = np.random.default_rng(5)
+    th0 = rng.normal(size=n).astype(np.float32)
+    grad = _dev(rng.normal(size=n).astype(np.float32), gpu)
+
+    def run(seed, launch, stream, out, k):
+        try:
+            st = GpuState(oracle.CState(th0, np.float32), gpu)
+            with torch.cuda.stream(stream):
+                for t in range(steps):
+                    kernels.sghmc_step(st.theta, st.V, grad, st.tau, st.g, st.v_hat, st.minv, None, 0.01, 50.0, 0.05,
+                                       t < 5, seed=seed, step=t, launch=launch)
+                stream.synchronize()
+            out[k] = st.theta
+        except Exception as exc:                   # noqa: BLE001 - reported to the main thread
+            out[k] = exc
+    torch.cuda.synchronize()                       # th0 / grad uploads done before the side streams read them
+    alone = {}
+    for k in range(4):
+        run(100 + k, None, torch.cuda.current_stream(), alone, k)
+    geoms = [kernels.LaunchConfig(64, 1, 0, 0), kernels.LaunchConfig(128, 2, 40, 1), kernels.LaunchConfig(256, 4, 7, 0),
+             kernels.LaunchConfig(192, 1, 0, 1)]
+    together = {}
+    threads = [threading.Thread(target=run, args=(100 + k, geoms[k], torch.cuda.Stream(device=gpu), together, k))
+               for k in range(4)]
+    bad = {}
+    threads.append(threading.Thread(target=run, args=(1, kernels.LaunchConfig(100, 0, 0, -1), torch.cuda.Stream(device=gpu), bad, 0)))
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for k in range(4):
+        assert isinstance(together[k], torch.Tensor), together[k]
+        assert torch.equal(together[k], alone[k]), "chain %d differs when stepped next to other threads" % k
+    assert isinstance(bad[0], SgmcmcLibraryError) and "block_threads" in str(bad[0])
+    assert kernels.get_launch_config() == {"block_threads": -1, "quads_per_thread": 1, "max_blocks": 1 << 20, "nontemporal": 2}
+
+
+def test_kernel_timestamp_events(gpu, oracle):
+    """``LaunchConfig(events=KernelEvents())``: the launch goes through hipExtLaunchKernel and the events receive the
+    kernel's own start/stop timestamps. Results are unchanged (bit-equal to a plain launch); the kernel duration is
+    positive, below the duration of a hipEventRecord bracket around the same launch, and in the physically possible
+    range for the bytes moved."""
+    from pysgmcmc_amd import kernels
+    n = 4_000_003
+    rng = np.random.default_rng(3)
+    th0 = rng.normal(size=n).astype(np.float32)
+    grad = _dev(rng.normal(size=n).astype(np.float32), gpu)
+    a, b = GpuState(oracle.CState(th0, np.float32), gpu), GpuState(oracle.CState(th0, np.float32), gpu)
+    durs, brackets = [], []
+    for t in range(12):
+        kev = kernels.KernelEvents()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        kernels.sghmc_step(a.theta, a.V, grad, a.tau, a.g, a.v_hat, a.minv, None, 0.01, 50.0, 0.05, t < 4, seed=8, step=t,
+                           launch=kernels.LaunchConfig(events=kev))
+        e1.record()
+        kernels.sghmc_step(b.theta, b.V, grad, b.tau, b.g, b.v_hat, b.minv, None, 0.01, 50.0, 0.05, t < 4, seed=8, step=t)
+        torch.cuda.synchronize()
+        durs.append(kev.elapsed_us())
+        brackets.append(e0.elapsed_time(e1) * 1e3)
+    for name in ("theta", "V", "tau", "g", "v_hat", "minv"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    frozen = np.array(durs[4:])
+    # 24 B x 4 M = 96 MB: 12 us at 8 TB/s; anything from 10 us (cache-assisted) to 200 us is a sane kernel duration
+    assert np.all(frozen > 10.0) and np.all(frozen < 200.0), frozen
+    assert np.median(frozen) <= np.median(brackets[4:]) + 0.5, (frozen, brackets)
 
 
 def test_moments_and_summary(gpu, oracle):

@@ -1,6 +1,13 @@
-# Round-2 profile refresh on the final kernels. Run through gpurun from the repo root.
+# Round-2 evidence on the final kernels. Run through gpurun from the repo root.
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r02; mkdir -p $O
+O=gpurun_out/r02; rm -rf $O; mkdir -p $O
+# (0) the driver's command, twice, and the long forms
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd_a.json 2> $O/bench.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd_b.json 2>> $O/bench.err
+python3 bench.py > $O/bench_default.json 2>> $O/bench.err
+python3 bench.py --steps 2000 --warmup 20 --no-cpu-baseline --no-update-only > $O/bench_2000.json 2>> $O/bench.err
+python3 bench.py --workload bnn50m-sgld --steps 100 --warmup 10 > $O/bench_50m_sgld.json 2>> $O/bench.err
+python3 bench.py --workload bnn50m-rsghmc --steps 100 --warmup 10 > $O/bench_50m_rsghmc.json 2>> $O/bench.err
 # (a) kernel-trace stats of the bench commands (program directly after --)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench10m -o b -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/prof_bench10m.json 2> $O/prof_bench10m.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench50m_sgld -o b -- python3 bench.py --workload bnn50m-sgld --steps 100 --warmup 10 --no-cpu-baseline > $O/prof_bench50m_sgld.json 2> $O/prof_bench50m_sgld.err
@@ -15,5 +22,15 @@ done
 find $O -name "*kernel_trace.csv" -path "*prof_bench*" -delete
 find $O -name "*kernel_trace.csv" -path "*probe_*" -delete
 find $O -name "*agent_info.csv" -delete
-ls -la $O $O/*/ | head -80
-tail -2 $O/prof_bench10m.err
+python3 tools/stats_variant_cost.py > $O/stats_variant_cost.txt 2>&1
+for ex in examples/*.py; do echo "== $ex"; timeout 300 python3 $ex 2>&1 | tail -4; done > $O/examples.txt 2>&1
+python3 -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
+python3 - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r02/bench_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1])
+        print(f, d['value'], d['ms_per_step'], d.get('step_ms_median'), d.get('step_ms_max'), d['roofline']['frac'], d['roofline'].get('traffic'), d.get('roofline_hbm_resident',{}).get('frac'), (d.get('cpu_baseline') or {}).get('value'))
+    except Exception as e: print(f, 'ERR', e)
+PY
+tail -3 $O/bench.err
