@@ -601,9 +601,19 @@ def main():
     for i in range(PRIME_STEADY):
         one_step(i, every=1 << 30)                                     # plain frozen steps until the device runs steadily
     if exchange is not None:
-        rhat_start()
-        rhat_finish()
-        exchange.summary.as_dict()
+        try:
+            rhat_start()
+            rhat_finish()
+            exchange.summary.as_dict()
+        except RuntimeError as exc:                                    # e.g. a backend without reduce-scatter support
+            if exchange.mode != "reduce_scatter":
+                raise
+            print("bench: reduce-scatter exchange failed (%s); falling back to the all-reduce exchange" % exc, file=sys.stderr)
+            exchange = RhatExchange(n, dev, mode="allreduce")
+            del ex_events[:]
+            rhat_start()
+            rhat_finish()
+            exchange.summary.as_dict()
     prime_rhat_events = len(ex_events)
     fence()
     # ---- phase 2: --warmup untimed steps (the Welford moments keep accumulating from the prime phase on, so an R-hat

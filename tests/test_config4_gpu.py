@@ -125,3 +125,63 @@ def test_config4_philox_chains_are_deterministic(gpu, kind):
     assert not torch.equal(t1, t3)
     # the two chains share theta_0 and gradients at step 0, so they differ only through the noise: about N(0, tiny)
     assert float((t1 - t3).abs().max()) > 0.0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[2] (the headline workload): SGHMC on the 10 002 434-parameter BNN, through the public API
+# ------------------------------------------------------------------------------------------------------------------
+
+def test_config2_sghmc_trajectory_windows_bit_equal_to_oracle(gpu, oracle):
+    """The bench workload (784-2048-2048-2048-1 + log-variance = 10 002 434 parameters, batch 256, eps 0.01, mdecay 0.05,
+    scale_grad = N) stepped through ``next(sampler)`` with injected noise across the burn-in -> frozen switch: four windows
+    of every state row stay bit-equal to the oracle (``sghmc.py:165-251``, ``base_classes.py:393-456``), in the eager mode
+    and with the cost pipeline replayed from a hipGraph; the fused step statistics equal the recomputed sums."""
+    from pysgmcmc_amd.data_batches import Placeholder, generate_batches
+    from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
+    from pysgmcmc_amd.samplers import SGHMCSampler
+    from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+    layers, n_data, burn, steps = (784, 2048, 2048, 2048), 8192, 3, 7
+    g0 = torch.Generator(device=gpu).manual_seed(0)
+    X = torch.randn(n_data, layers[0], device=gpu, generator=g0)
+    y = torch.randn(n_data, device=gpu, generator=g0)
+
+    def chain():
+        xp, yp = Placeholder(dtype=torch.float32, device=gpu), Placeholder(dtype=torch.float32, device=gpu)
+        params = init_mlp_params(layers[0], hidden=layers[1:], seed=1000, dtype=torch.float32, device=gpu)
+        s = SGHMCSampler(params=params, cost_fun=BNNCost(xp, yp, batch_size=BATCH, n_examples=n_data),
+                         batch_generator=generate_batches(X, y, xp, yp, batch_size=BATCH, seed=0),
+                         stepsize_schedule=ConstantStepsizeSchedule(0.01), mdecay=0.05, scale_grad=float(n_data),
+                         burn_in_steps=burn, session=gpu, dtype=torch.float32, seed=1234)
+        s.sample_format = "view"
+        return s
+    s = chain()
+    assert s.arena.n == 10_002_434
+    a = s.arena
+    gx = torch.Generator(device=gpu).manual_seed(5)
+    xi_buf = torch.empty(a.n, device=gpu)
+    s.noise_source = lambda step, n: xi_buf.normal_(generator=gx)
+    wins = _windows(s)
+    states = [oracle.CState(_host(a.row("theta"), lo, hi), np.float32) for lo, hi in wins]
+    for t in range(steps):
+        adapting = s._adapting
+        assert adapting == (t < burn)
+        next(s)
+        for (lo, hi), st in zip(wins, states):
+            oracle.c_sghmc_step(st, _host(a.row("grad"), lo, hi), 0.01, float(n_data), 0.05, adapting, _host(xi_buf, lo, hi),
+                                grad_decay=s._grad_decay)
+            for name in ("theta", "V", "minv") + (("tau", "g", "v_hat") if adapting else ()):
+                got = _host(a.row(name), lo, hi)
+                assert np.array_equal(got.view(np.uint32), getattr(st, name).view(np.uint32)), (t, lo, name)
+    st = s.stats
+    assert np.isclose(st["theta_sq"], float((a.row("theta").double() ** 2).sum()), rtol=5e-7)
+    assert np.isclose(st["momentum_sq"], float((a.row("V").double() ** 2).sum()), rtol=5e-7)
+    assert np.isclose(st["minv_sum"], float(a.row("minv").double().sum()), rtol=5e-7)
+    # Philox noise: graph-stepped chain == eager chain, bit for bit, across the switch
+    e, g = chain(), chain()
+    g.use_hip_graph = True
+    for _ in range(steps):
+        ce = next(e)[1]
+        cg = next(g)[1]
+        assert float(ce) == float(cg)
+    for row in ("theta", "V", "minv", "tau"):
+        assert torch.equal(e.arena.row(row), g.arena.row(row)), row
