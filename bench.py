@@ -519,7 +519,8 @@ def main():
     if not args.no_gemm_tuning:
         from pysgmcmc_amd.models.bayesian_neural_network import enable_gemm_tuning
         try:
-            enable_gemm_tuning(True)                           # rocBLAS/hipBLASLt solution per shape, tuned in warm-up
+            enable_gemm_tuning(True, max_duration_ms=int(os.environ.get("BENCH_TUNE_MS", "30")),
+                               max_iterations=int(os.environ.get("BENCH_TUNE_ITERS", "20")))   # rocBLAS/hipBLASLt solution per shape, tuned in the prime phase
         except Exception as exc:                               # tuning is an optimisation, never a requirement
             print("bench: GEMM tuning unavailable (%s); using the BLAS heuristics" % exc, file=sys.stderr)
             args.no_gemm_tuning = True

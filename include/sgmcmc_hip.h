@@ -301,9 +301,31 @@ int sgmcmc_bnn_fused_sgld_steps_f64(double *theta, double *grad, double *tau, do
                                     uint64_t seed_base, const double *xi, double *cost_out, sgmcmc_stream_t stream);
 
 /* Forward of the last hidden layer fused with a single-output layer above it (models/bayesian_neural_network.py:
- * 48-56): a[rows][cols] = tanh(a) in place, out[r] = sum_c a[r][c] * w[c] (no bias: sgmcmc_bnn_head_* adds it). */
-int sgmcmc_tanh_rowdot_f32(float *a, const float *w, size_t rows, size_t cols, float *out, sgmcmc_stream_t stream);
-int sgmcmc_tanh_rowdot_f64(double *a, const double *w, size_t rows, size_t cols, double *out, sgmcmc_stream_t stream);
+ * 48-56): a[rows][cols] = tanh(a) in place, out[r] = sum_c a[r][c] * w[c] (no bias: the loss head adds it).
+ * stats_ws / tsq_parts (both NULL or both given): the first min(16, rows) workgroups also add up one slice each of
+ * the sum(theta^2) partials of the previous step kernel's statistics workspace into tsq_parts[0..15] (doubles), for
+ * sgmcmc_bnn_head_last_layer_backward_*.                                                                          */
+int sgmcmc_tanh_rowdot_f32(float *a, const float *w, size_t rows, size_t cols, float *out, const void *stats_ws,
+                           double *tsq_parts, sgmcmc_stream_t stream);
+int sgmcmc_tanh_rowdot_f64(double *a, const double *w, size_t rows, size_t cols, double *out, const void *stats_ws,
+                           double *tsq_parts, sgmcmc_stream_t stream);
+
+/* sgmcmc_bnn_head_* and sgmcmc_bnn_last_layer_backward_* in ONE launch (every dependent launch of the step costs
+ * ~5 us): `mean` [rows] is the single-output layer's pre-bias output (sgmcmc_tanh_rowdot_*), tsq_parts the slices of
+ * sum(theta^2) it left; d cost/d mean is formed on the fly by every workgroup, workgroup 0 writes the head's scalar
+ * outputs. Arguments as in the two separate entry points (fold_prior_grad: the same bit mask).                    */
+int sgmcmc_bnn_head_last_layer_backward_f32(
+    const float *mean, const float *y, const float *log_var, const double *tsq_parts, const float *last_bias, size_t rows,
+    size_t cols, double batch_size, double n_examples, double n_params, double wdecay, double prior_mean, double prior_var,
+    int fold_prior_grad, const float *w, const float *h, const float *bias_prev, float beta, float *cost_out,
+    float *grad_log_var_out, float *grad_last_bias_out, float *mse_out, float *delta_prev, float *colsum, float *gw,
+    sgmcmc_stream_t stream);
+int sgmcmc_bnn_head_last_layer_backward_f64(
+    const double *mean, const double *y, const double *log_var, const double *tsq_parts, const double *last_bias, size_t rows,
+    size_t cols, double batch_size, double n_examples, double n_params, double wdecay, double prior_mean, double prior_var,
+    int fold_prior_grad, const double *w, const double *h, const double *bias_prev, double beta, double *cost_out,
+    double *grad_log_var_out, double *grad_last_bias_out, double *mse_out, double *delta_prev, double *colsum, double *gw,
+    sgmcmc_stream_t stream);
 
 /* Minibatch window [start, start + batch) of the device-resident dataset copied into the (static) feed buffers with
  * ONE launch: x_out[batch][dim] = X[start ..][:], y_out[batch] = y[start ..] (pysgmcmc/data_batches.py:118-123).   */

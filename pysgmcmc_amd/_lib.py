@@ -105,7 +105,10 @@ def _declare(lib):
                       + [ctypes.c_double] * 5 + [real, real, real, _u64, _u64, _u64, _u64, _vp, _vp, _vp])
         f.restype = _ci
         f = getattr(lib, "sgmcmc_tanh_rowdot_" + sfx)
-        f.argtypes = [_vp, _vp, _sz, _sz, _vp, _vp]
+        f.argtypes = [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_bnn_head_last_layer_backward_" + sfx)
+        f.argtypes = ([_vp] * 5 + [_sz, _sz] + [ctypes.c_double] * 6 + [_ci, _vp, _vp, _vp, real] + [_vp] * 7 + [_vp])
         f.restype = _ci
         f = getattr(lib, "sgmcmc_window_gather_" + sfx)
         f.argtypes = [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]

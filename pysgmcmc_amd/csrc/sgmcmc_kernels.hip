@@ -401,32 +401,37 @@ __global__ void __launch_bounds__(256) tanh_backward_kernel(T *__restrict__ delt
 }
 
 // Fused tanh backward + bias gradient of the layer below: delta[r][c] *= 1 - h[r][c]^2 and
-// colsum[c] = sum_r delta[r][c] (+ beta * bias[c]). One block of 1024 lanes owns 64 columns:
-// lane = column, the 16 waves stride over the rows, LDS combines the 16 row-partials in a fixed
-// order (deterministic, no atomics). Row-major [rows][cols].
+// colsum[c] = sum_r delta[r][c] (+ beta * bias[c]). Row-major [rows][cols].
+// One block of 1024 lanes owns COLS_PER_BLOCK = 16 columns (64-byte row segments): lane & 15 = column, the other 64
+// "row lanes" (4 per wave x 16 waves) stride over the rows, so a 256 x 2048 matrix is 128 blocks (one per two CUs)
+// instead of the 32 a 64-column block gives, and every lane has its 4 rows' loads in flight at once. The row lanes
+// of a wave are combined by two shuffles, the 16 waves through LDS in a fixed order (deterministic, no atomics).
+constexpr int CS_COLS = 16;
 template <typename T>
 __global__ void __launch_bounds__(1024) tanh_backward_colsum_kernel(T *__restrict__ delta, const T *__restrict__ h,
                                                                      size_t rows, size_t cols, const T *__restrict__ bias,
                                                                      T beta, T *__restrict__ colsum)
 {
-    __shared__ T lds[16][64];
+    __shared__ T lds[16][CS_COLS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t c = (size_t)blockIdx.x * 64 + lane;
+    const int cl = lane & (CS_COLS - 1);
+    const size_t c = (size_t)blockIdx.x * CS_COLS + cl;
+    const size_t rl = (size_t)wave * 4 + (lane >> 4);          // row lane 0..63
     T acc = T(0);
     if (c < cols) {
-        size_t r = wave;
-        for (; r + 48 < rows; r += 64) {                      // 4 rows per trip: 8 loads in flight per lane
+        size_t r = rl;
+        for (; r + 192 < rows; r += 256) {                    // 4 rows per trip: 8 loads in flight per lane
             T hv[4], dv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const size_t i = (r + 16 * u) * cols + c; hv[u] = h[i]; dv[u] = delta[i]; }
+            for (int u = 0; u < 4; ++u) { const size_t i = (r + 64 * u) * cols + c; hv[u] = h[i]; dv[u] = delta[i]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 T d = dv[u] * (T(1) - hv[u] * hv[u]);
-                delta[(r + 16 * u) * cols + c] = d;
+                delta[(r + 64 * u) * cols + c] = d;
                 acc += d;
             }
         }
-        for (; r < rows; r += 16) {
+        for (; r < rows; r += 64) {
             const size_t i = r * cols + c;
             T hv = h[i];
             T d = delta[i] * (T(1) - hv * hv);
@@ -434,9 +439,11 @@ __global__ void __launch_bounds__(1024) tanh_backward_colsum_kernel(T *__restric
             acc += d;
         }
     }
-    lds[wave][lane] = acc;
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    if (lane < CS_COLS) lds[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && c < cols) {
+    if (wave == 0 && lane < CS_COLS && c < cols) {
         T tot = T(0);
 #pragma unroll
         for (int w = 0; w < 16; ++w) tot += lds[w][lane];
@@ -450,23 +457,76 @@ __global__ void __launch_bounds__(1024) tanh_backward_colsum_kernel(T *__restric
 __device__ __forceinline__ float tanh_dev(float x) { return tanhf(x); }
 __device__ __forceinline__ double tanh_dev(double x) { return tanh(x); }
 
+// 4 consecutive elements per lane per trip (16-byte accesses when the row pitch allows; all loads of a lane issued
+// before the first tanh), one 256-lane workgroup per row.
+// Optional side job (stats_ws != NULL): workgroups 0 .. min(TSQ_SLICES, rows) - 1 also add up one contiguous slice each of
+// the sum(theta^2) partials the previous step kernel left in its statistics workspace and write it to tsq_parts[slice];
+// the fused head (head_last_layer_backward_kernel) adds the slices in order. Saves the loss head's own pass over the
+// ~10 k partials, and with it the separate head launch (each dependent launch of the step costs ~5 us).
+constexpr int TSQ_SLICES = 16;
 template <typename T>
 __global__ void __launch_bounds__(256) tanh_rowdot_kernel(T *__restrict__ a, const T *__restrict__ w, size_t cols,
-                                                          T *__restrict__ out)
+                                                          T *__restrict__ out, const double *__restrict__ stats_ws,
+                                                          double *__restrict__ tsq_parts)
 {
     __shared__ T lds[4];
+    __shared__ double lds_d[4];
+    const unsigned n_slices = gridDim.x < (unsigned)TSQ_SLICES ? gridDim.x : (unsigned)TSQ_SLICES;
+    double tsq = 0.0;
+    if (stats_ws != nullptr && blockIdx.x < n_slices) {
+        const unsigned nparts = (unsigned)reinterpret_cast<const unsigned long long *>(stats_ws)[0];
+        const double *__restrict__ p = stats_ws + 4;
+        const unsigned len = (nparts + n_slices - 1) / n_slices;
+        const unsigned lo = blockIdx.x * len, hi = (lo + len < nparts) ? lo + len : nparts;
+        for (unsigned i = lo + threadIdx.x; i < hi; i += 256) tsq += p[i];
+    }
     T *row = a + (size_t)blockIdx.x * cols;
     T acc = T(0);
-    for (size_t c = threadIdx.x; c < cols; c += 256) {
-        const T h = tanh_dev(row[c]);
-        row[c] = h;
-        acc += h * w[c];
+    const bool vec = (cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w)) % (4 * sizeof(T)) == 0);
+    if (vec) {
+        struct alignas(4 * sizeof(T)) Q { T v[4]; };
+        Q *rq = reinterpret_cast<Q *>(row);
+        const Q *wq = reinterpret_cast<const Q *>(w);
+        const size_t nq = cols / 4;
+        size_t q = threadIdx.x;
+        for (; q + 256 < nq; q += 512) {                      // two quads per lane in flight
+            Q x0 = rq[q], x1 = rq[q + 256], w0 = wq[q], w1 = wq[q + 256];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x0.v[j] = tanh_dev(x0.v[j]); x1.v[j] = tanh_dev(x1.v[j]); }
+            rq[q] = x0; rq[q + 256] = x1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += x0.v[j] * w0.v[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += x1.v[j] * w1.v[j];
+        }
+        for (; q < nq; q += 256) {
+            Q x0 = rq[q], w0 = wq[q];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x0.v[j] = tanh_dev(x0.v[j]);
+            rq[q] = x0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += x0.v[j] * w0.v[j];
+        }
+    } else {
+        for (size_t c = threadIdx.x; c < cols; c += 256) {
+            const T h = tanh_dev(row[c]);
+            row[c] = h;
+            acc += h * w[c];
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (stats_ws != nullptr && blockIdx.x < n_slices) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) tsq += __shfl_down(tsq, off, 64);
+        if ((threadIdx.x & 63) == 0) lds_d[threadIdx.x >> 6] = tsq;
+    }
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+        if (stats_ws != nullptr && blockIdx.x < n_slices) tsq_parts[blockIdx.x] = ((lds_d[0] + lds_d[1]) + lds_d[2]) + lds_d[3];
+    }
 }
 
 // Backward of a single-output last layer fused with the tanh backward of the layer below:
@@ -481,13 +541,29 @@ __global__ void __launch_bounds__(1024) last_layer_backward_kernel(const T *__re
                                                                     T *__restrict__ delta_prev, T *__restrict__ colsum,
                                                                     T *__restrict__ gw)
 {
-    __shared__ T lds[2][16][64];
+    // same block shape as tanh_backward_colsum_kernel: 16 columns x 64 row lanes
+    __shared__ T lds[2][16][CS_COLS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t c = (size_t)blockIdx.x * 64 + lane;
+    const int cl = lane & (CS_COLS - 1);
+    const size_t c = (size_t)blockIdx.x * CS_COLS + cl;
+    const size_t rl = (size_t)wave * 4 + (lane >> 4);
     T acc_b = T(0), acc_w = T(0);
     if (c < cols) {
         const T wc = w[c];
-        for (size_t r = wave; r < rows; r += 16) {
+        size_t r = rl;
+        for (; r + 192 < rows; r += 256) {
+            T hv[4], dr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { hv[u] = h[(r + 64 * u) * cols + c]; dr[u] = dvec[r + 64 * u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T d = (dr[u] * wc) * (T(1) - hv[u] * hv[u]);
+                delta_prev[(r + 64 * u) * cols + c] = d;
+                acc_b += d;
+                acc_w += hv[u] * dr[u];
+            }
+        }
+        for (; r < rows; r += 64) {
             const size_t i = r * cols + c;
             const T hv = h[i], dr = dvec[r];
             const T d = (dr * wc) * (T(1) - hv * hv);
@@ -496,15 +572,108 @@ __global__ void __launch_bounds__(1024) last_layer_backward_kernel(const T *__re
             acc_w += hv * dr;
         }
     }
-    lds[0][wave][lane] = acc_b;
-    lds[1][wave][lane] = acc_w;
+    acc_b += __shfl_xor(acc_b, 16, 64); acc_b += __shfl_xor(acc_b, 32, 64);
+    acc_w += __shfl_xor(acc_w, 16, 64); acc_w += __shfl_xor(acc_w, 32, 64);
+    if (lane < CS_COLS) { lds[0][wave][lane] = acc_b; lds[1][wave][lane] = acc_w; }
     __syncthreads();
-    if (wave == 0 && c < cols) {
+    if (wave == 0 && lane < CS_COLS && c < cols) {
         T tb = T(0), tw = T(0);
 #pragma unroll
         for (int k = 0; k < 16; ++k) { tb += lds[0][k][lane]; tw += lds[1][k][lane]; }
         colsum[c] = (beta != T(0)) ? tb + beta * bias_prev[c] : tb;
         gw[c] = (beta != T(0)) ? tw + beta * w[c] : tw;
+    }
+}
+
+// The loss head (bnn_head_kernel) folded into the backward of a single-output last layer: dvec[r] = d cost / d mean_r is a
+// function of the residual and the scalar log-variance only, so every workgroup forms it on the fly; workgroup 0 also
+// reduces the residuals and writes the head's scalar outputs (cost, d cost/d log_var, mse, last bias gradient).
+// sum(theta^2) arrives as the n_tsq slices tanh_rowdot_kernel left in tsq_parts. One launch less per step.
+template <typename T>
+__global__ void __launch_bounds__(1024) head_last_layer_backward_kernel(
+    const T *__restrict__ mean, const T *__restrict__ y, const T *__restrict__ s_ptr, const double *__restrict__ tsq_parts,
+    int n_tsq, const T *__restrict__ last_bias, BnnHeadConsts k, T *__restrict__ cost_out, T *__restrict__ grad_s_out,
+    T *__restrict__ grad_bias_out, T *__restrict__ mse_out, const T *__restrict__ w, const T *__restrict__ h, size_t rows,
+    size_t cols, const T *__restrict__ bias_prev, T beta, T *__restrict__ delta_prev, T *__restrict__ colsum,
+    T *__restrict__ gw)
+{
+    __shared__ T lds[2][16][CS_COLS];
+    __shared__ double lds_h[2][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double s = (double)*s_ptr;
+    const double es = exp(s);
+    const double inv = 1.0 / (es + 1e-16);                       // :369
+    const double dscale = -(inv / k.batch_size);
+    const double bias_add = (k.add_last_bias && last_bias != nullptr) ? (double)*last_bias : 0.0;
+    auto dvec = [&](size_t r) -> T { return (T)(((double)y[r] - ((double)mean[r] + bias_add)) * dscale); };
+    const int cl = lane & (CS_COLS - 1);
+    const size_t c = (size_t)blockIdx.x * CS_COLS + cl;
+    const size_t rl = (size_t)wave * 4 + (lane >> 4);
+    T acc_b = T(0), acc_w = T(0);
+    if (c < cols) {
+        const T wc = w[c];
+        size_t r = rl;
+        for (; r + 192 < rows; r += 256) {
+            T hv[4], dr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { hv[u] = h[(r + 64 * u) * cols + c]; dr[u] = dvec(r + 64 * u); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T d = (dr[u] * wc) * (T(1) - hv[u] * hv[u]);
+                delta_prev[(r + 64 * u) * cols + c] = d;
+                acc_b += d;
+                acc_w += hv[u] * dr[u];
+            }
+        }
+        for (; r < rows; r += 64) {
+            const size_t i = r * cols + c;
+            const T hv = h[i], dr = dvec(r);
+            const T d = (dr * wc) * (T(1) - hv * hv);
+            delta_prev[i] = d;
+            acc_b += d;
+            acc_w += hv * dr;
+        }
+    }
+    acc_b += __shfl_xor(acc_b, 16, 64); acc_b += __shfl_xor(acc_b, 32, 64);
+    acc_w += __shfl_xor(acc_w, 16, 64); acc_w += __shfl_xor(acc_w, 32, 64);
+    if (lane < CS_COLS) { lds[0][wave][lane] = acc_b; lds[1][wave][lane] = acc_w; }
+    // the head's reductions, workgroup 0 only (same arithmetic as bnn_head_kernel)
+    double sse = 0.0, sumr = 0.0;
+    if (blockIdx.x == 0) {
+        for (size_t i = threadIdx.x; i < rows; i += blockDim.x) {
+            double r = (double)y[i] - ((double)mean[i] + bias_add);
+            sse += r * r;                                            // :370
+            sumr += r;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { sse += __shfl_down(sse, off, 64); sumr += __shfl_down(sumr, off, 64); }
+        if (lane == 0) { lds_h[0][wave] = sse; lds_h[1][wave] = sumr; }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < CS_COLS && c < cols) {
+        T tb = T(0), tw = T(0);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) { tb += lds[0][kk][lane]; tw += lds[1][kk][lane]; }
+        colsum[c] = (beta != T(0)) ? tb + beta * bias_prev[c] : tb;
+        gw[c] = (beta != T(0)) ? tw + beta * w[c] : tw;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double tot = 0.0, rs = 0.0, tq = 0.0;
+        for (int wv = 0; wv < 16; ++wv) { tot += lds_h[0][wv]; rs += lds_h[1][wv]; }
+        for (int j = 0; j < n_tsq; ++j) tq += tsq_parts[j];
+        const double Bd = (double)rows;
+        double log_like = (-(tot * (0.5 * inv)) - 0.5 * s * Bd) / k.batch_size;            // :371-377
+        double d = s - k.ln_prior_mean;
+        double lvp = -(d * d) / k.lvp_den - 0.5 * k.ln_prior_var;                           // :102-107
+        double wp = (-0.5 * k.wdecay) * tq / k.wp_den;                                      // :131-141
+        double cost = -(log_like + lvp / k.n_examples + wp / k.n_examples);                 // :380-388
+        double prior_coef = k.fold_prior_grad ? 0.0 : k.wdecay / (k.wp_den * k.n_examples);
+        double ds = -((tot * (0.5 * es * inv * inv) - 0.5 * Bd) / k.batch_size
+                      + (-2.0 * d / k.lvp_den) / k.n_examples) + prior_coef * s;
+        *cost_out = (T)cost;
+        *grad_s_out = (T)ds;
+        *mse_out = (T)(tot / Bd);
+        if (grad_bias_out != nullptr) *grad_bias_out = (T)(rs * dscale + prior_coef * (double)*last_bias);
     }
 }
 
@@ -606,10 +775,16 @@ __global__ void window_gather_kernel(const T *__restrict__ X, const T *__restric
                                      T *__restrict__ xb, T *__restrict__ yb)
 {
     const size_t nx = B * D;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nx + B; i += (size_t)gridDim.x * blockDim.x) {
-        if (i < nx) xb[i] = X[start * D + i];
-        else yb[i - nx] = y[start + (i - nx)];
-    }
+    const T *__restrict__ src = X + start * D;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, G = (size_t)gridDim.x * blockDim.x;
+    // 16-byte copies when source window and destination are 16-byte aligned (4 elements of f32, 2 of f64 per access)
+    constexpr size_t V = 16 / sizeof(T);
+    struct alignas(16) Q { T v[V]; };
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(xb)) & 15u) == 0;
+    const size_t nq = vec ? nx / V : 0;
+    for (size_t q = gid; q < nq; q += G) reinterpret_cast<Q *>(xb)[q] = reinterpret_cast<const Q *>(src)[q];
+    for (size_t i = nq * V + gid; i < nx; i += G) xb[i] = src[i];
+    for (size_t i = gid; i < B; i += G) yb[i] = y[start + i];
 }
 
 // Upper bound of the grid any launch of n elements can use (sizes the stats workspace).
@@ -820,10 +995,35 @@ int last_layer_backward_impl(const T *dvec, const T *w, const T *h, size_t rows,
     if (rows == 0 || cols == 0) return 0;
     if (!dvec || !w || !h || !delta_prev || !colsum || !gw || (beta != T(0) && !bias_prev))
         return fail(SGMCMC_EINVAL, "last_layer_backward: NULL argument");
-    hipLaunchKernelGGL((last_layer_backward_kernel<T>), dim3((unsigned)((cols + 63) / 64)), dim3(1024), 0, st, dvec, w, h,
+    hipLaunchKernelGGL((last_layer_backward_kernel<T>), dim3((unsigned)((cols + CS_COLS - 1) / CS_COLS)), dim3(1024), 0, st, dvec, w, h,
                        rows, cols, bias_prev, beta, delta_prev, colsum, gw);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch last_layer_backward");
+}
+
+template <typename T>
+int head_last_layer_backward_impl(const T *mean, const T *y, const T *s_ptr, const double *tsq_parts, const T *last_bias,
+                                  size_t rows, size_t cols, double batch_size, double n_examples, double n_params,
+                                  double wdecay, double prior_mean, double prior_var, int flags, const T *w, const T *h,
+                                  const T *bias_prev, T beta, T *cost_out, T *grad_s_out, T *grad_bias_out, T *mse_out,
+                                  T *delta_prev, T *colsum, T *gw, hipStream_t st)
+{
+    if (!mean || !y || !s_ptr || !tsq_parts || !w || !h || !cost_out || !grad_s_out || !mse_out || !delta_prev || !colsum ||
+        !gw || rows == 0 || cols == 0 || (grad_bias_out && !last_bias) || (beta != T(0) && !bias_prev))
+        return fail(SGMCMC_EINVAL, "bnn_head_last_layer_backward: NULL argument or empty matrix");
+    BnnHeadConsts k;
+    k.batch_size = batch_size; k.n_examples = n_examples; k.wdecay = wdecay;
+    k.wp_den = n_params + (2.0 * 1e-16 + 1e-16);                 /* safe_divide, n_params > 0 */
+    k.lvp_den = 2.0 * prior_var + (2.0 * 1e-16 + 1e-16);
+    k.ln_prior_mean = std::log(prior_mean); k.ln_prior_var = std::log(prior_var);
+    k.fold_prior_grad = (flags & 1) ? 1 : 0;
+    k.add_last_bias = (flags & 2) ? 1 : 0;
+    const int n_tsq = (int)(rows < (size_t)TSQ_SLICES ? rows : (size_t)TSQ_SLICES);   // what tanh_rowdot wrote (one workgroup per row)
+    hipLaunchKernelGGL((head_last_layer_backward_kernel<T>), dim3((unsigned)((cols + CS_COLS - 1) / CS_COLS)), dim3(1024), 0, st,
+                       mean, y, s_ptr, tsq_parts, n_tsq, last_bias, k, cost_out, grad_s_out, grad_bias_out, mse_out, w, h,
+                       rows, cols, bias_prev, beta, delta_prev, colsum, gw);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch head_last_layer_backward");
 }
 
 template <typename T>
@@ -833,7 +1033,7 @@ int tanh_backward_colsum_impl(T *delta, const T *h, size_t rows, size_t cols, co
     if (rows == 0 || cols == 0) return 0;
     if (!delta || !h || !colsum || (beta != T(0) && !bias))
         return fail(SGMCMC_EINVAL, "tanh_backward_colsum: NULL argument");
-    hipLaunchKernelGGL((tanh_backward_colsum_kernel<T>), dim3((unsigned)((cols + 63) / 64)), dim3(1024), 0, st, delta, h,
+    hipLaunchKernelGGL((tanh_backward_colsum_kernel<T>), dim3((unsigned)((cols + CS_COLS - 1) / CS_COLS)), dim3(1024), 0, st, delta, h,
                        rows, cols, bias, beta, colsum);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch tanh_backward_colsum");
@@ -1037,7 +1237,7 @@ int sgmcmc_counter_add_u64(uint64_t *counter, uint64_t inc, sgmcmc_stream_t stre
     {                                                                                                                \
         if (!X || !y || !x_out || !y_out) return fail(SGMCMC_EINVAL, "window_gather: NULL argument");               \
         if (batch == 0 || start + batch > n_data) return fail(SGMCMC_EINVAL, "window_gather: window outside the data"); \
-        const size_t total = batch * dim + batch;                                                                    \
+        const size_t total = (batch * dim) / (16 / sizeof(T)) + batch;    /* 16-byte copies: see the kernel */            \
         const size_t blocks = (total + 255) / 256;                                                                   \
         hipLaunchKernelGGL((window_gather_kernel<T>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, \
                            static_cast<hipStream_t>(stream), X, y, start, batch, dim, x_out, y_out);                 \
@@ -1049,15 +1249,31 @@ SGMCMC_WINDOW_GATHER(f64, double)
 #undef SGMCMC_WINDOW_GATHER
 
 #define SGMCMC_TANH_ROWDOT(SFX, T)                                                                                   \
-    int sgmcmc_tanh_rowdot_##SFX(T *a, const T *w, size_t rows, size_t cols, T *out, sgmcmc_stream_t stream)       \
+    int sgmcmc_tanh_rowdot_##SFX(T *a, const T *w, size_t rows, size_t cols, T *out, const void *stats_ws,          \
+                                 double *tsq_parts, sgmcmc_stream_t stream)                                          \
     {                                                                                                                \
         if (rows == 0 || cols == 0) return 0;                                                                        \
         if (!a || !w || !out) return fail(SGMCMC_EINVAL, "tanh_rowdot: NULL argument");                             \
+        if ((stats_ws == nullptr) != (tsq_parts == nullptr))                                                         \
+            return fail(SGMCMC_EINVAL, "tanh_rowdot: stats_ws and tsq_parts go together");                           \
         if (rows > 0x7fffffffull) return fail(SGMCMC_EINVAL, "tanh_rowdot: too many rows");                          \
         hipLaunchKernelGGL((tanh_rowdot_kernel<T>), dim3((unsigned)rows), dim3(256), 0, static_cast<hipStream_t>(stream), \
-                           a, w, cols, out);                                                                         \
+                           a, w, cols, out, static_cast<const double *>(stats_ws), tsq_parts);                       \
         hipError_t e = hipGetLastError();                                                                            \
         return e == hipSuccess ? 0 : hip_fail(e, "launch tanh_rowdot");                                              \
+    }                                                                                                                \
+    int sgmcmc_bnn_head_last_layer_backward_##SFX(                                                                   \
+        const T *mean, const T *y, const T *log_var, const double *tsq_parts, const T *last_bias, size_t rows,       \
+        size_t cols, double batch_size, double n_examples, double n_params, double wdecay, double prior_mean,        \
+        double prior_var, int fold_prior_grad, const T *w, const T *h, const T *bias_prev, T beta, T *cost_out,      \
+        T *grad_log_var_out, T *grad_last_bias_out, T *mse_out, T *delta_prev, T *colsum, T *gw,                     \
+        sgmcmc_stream_t stream)                                                                                      \
+    {                                                                                                                \
+        return head_last_layer_backward_impl<T>(mean, y, log_var, tsq_parts, last_bias, rows, cols, batch_size,      \
+                                                n_examples, n_params, wdecay, prior_mean, prior_var, fold_prior_grad, \
+                                                w, h, bias_prev, beta, cost_out, grad_log_var_out,                   \
+                                                grad_last_bias_out, mse_out, delta_prev, colsum, gw,                 \
+                                                static_cast<hipStream_t>(stream));                                   \
     }
 SGMCMC_TANH_ROWDOT(f32, float)
 SGMCMC_TANH_ROWDOT(f64, double)

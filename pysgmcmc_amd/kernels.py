@@ -16,7 +16,7 @@ __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
     "LaunchConfig", "KernelEvents", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
-    "bnn_fused_sgld_steps", "window_gather", "tanh_rowdot", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
+    "bnn_fused_sgld_steps", "window_gather", "tanh_rowdot", "bnn_head_last_layer_backward", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
 ]
 
 _SFX = {torch.float32: "f32", torch.float64: "f64"}
@@ -389,15 +389,36 @@ def bnn_fused_sgld_steps(theta, grad, tau, g, v_hat, minv, layer_sizes, X, y, wi
     return cost_out
 
 
-def tanh_rowdot(a, w, out):
-    """``a = tanh(a)`` in place (``[rows, cols]``) and ``out[r] = a[r] . w`` in one launch."""
+def tanh_rowdot(a, w, out, stats_workspace=None, tsq_parts=None):
+    """``a = tanh(a)`` in place (``[rows, cols]``) and ``out[r] = a[r] . w`` in one launch. With ``stats_workspace``
+    (a ``StepStats.workspace``) and ``tsq_parts`` (float64[16] device tensor) the launch also adds up the
+    sum(theta^2) partials into 16 slices for :func:`bnn_head_last_layer_backward`."""
     f = getattr(lib(), "sgmcmc_tanh_rowdot_" + _sfx(a))
     rows, cols = int(a.shape[0]), int(a.shape[1])
     if w.numel() != cols or out.numel() != rows:
         raise ValueError("pysgmcmc_amd: tanh_rowdot shapes do not match")
+    if tsq_parts is not None and (tsq_parts.dtype != torch.float64 or tsq_parts.numel() < 16):
+        raise TypeError("tsq_parts must be a float64 device tensor of 16 elements")
     with _on(a):
-        rc = f(_ptr(a), _ptr(w), rows, cols, _ptr(out), _stream(a))
+        rc = f(_ptr(a), _ptr(w), rows, cols, _ptr(out), _ptr(stats_workspace), _ptr(tsq_parts), _stream(a))
     check(rc, "sgmcmc_tanh_rowdot")
+
+
+def bnn_head_last_layer_backward(mean, y, log_var, tsq_parts, last_bias, batch_size, n_examples, n_params, wdecay,
+                                 prior_mean, prior_var, w, h, bias_prev, beta, cost_out, grad_log_var_out,
+                                 grad_last_bias_out, mse_out, delta_prev, colsum, gw, fold_prior_grad=False,
+                                 add_last_bias=True):
+    """Loss head + backward of the single-output last layer (+ tanh backward and bias gradient of the layer below) in
+    ONE launch; see ``include/sgmcmc_hip.h``. ``mean`` = the pre-bias outputs of :func:`tanh_rowdot`."""
+    f = getattr(lib(), "sgmcmc_bnn_head_last_layer_backward_" + _sfx(h))
+    rows, cols = h.shape
+    with _on(h):
+        rc = f(_ptr(mean), _ptr(y, mean), _ptr(log_var), _ptr(tsq_parts), _ptr(last_bias), rows, cols, float(batch_size),
+               float(n_examples), float(n_params), float(wdecay), float(prior_mean), float(prior_var),
+               int(bool(fold_prior_grad)) | (2 if add_last_bias else 0), _ptr(w), _ptr(h), _ptr(bias_prev), float(beta),
+               _ptr(cost_out), _ptr(grad_log_var_out), _ptr(grad_last_bias_out), _ptr(mse_out), _ptr(delta_prev, h),
+               _ptr(colsum), _ptr(gw), _stream(h))
+    check(rc, "sgmcmc_bnn_head_last_layer_backward")
 
 
 def window_gather(X, y, start, x_out, y_out):

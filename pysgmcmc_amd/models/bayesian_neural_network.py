@@ -185,6 +185,8 @@ class BNNCost(object):
         self.use_hip_kernels = True
         # tanh of the last hidden layer fused with the single output unit's dot product (one launch instead of two)
         self.fuse_tanh_rowdot = True                      # measured 228.2 vs 231.3 us per step at 10 M parameters
+        # loss head folded into the single-output layer's backward launch (every dependent launch of the step costs ~5 us)
+        self.fuse_head = True
         # (Forking the weight-gradient GEMMs onto a second stream inside the captured graph was measured
         # on MI355X at batch 256: 291 us/step vs 275 us on one stream -- not kept.)
 
@@ -220,6 +222,7 @@ class BNNCost(object):
             mk = lambda w: torch.empty(B, w, dtype=dt, device=dev)
             ws = {"h": [mk(w) for w in widths], "d": [mk(w) for w in widths],
                   "ones": torch.ones(B, dtype=dt, device=dev),
+                  "tsq_parts": torch.zeros(16, dtype=torch.float64, device=dev),
                   "cost": torch.zeros(1, dtype=dt, device=dev), "mse": torch.zeros(1, dtype=dt, device=dev)}
             self._ws = {key: ws}
         return ws
@@ -260,6 +263,9 @@ class BNNCost(object):
         # forward; a single-output last layer is a plain GEMV whose bias the loss head adds
         h = X
         fuse_top = single_out and self.fuse_tanh_rowdot
+        # loss head folded into the last layer's backward (one launch less): needs the sum(theta^2) partials of the
+        # previous step kernel, which the rowdot launch reduces to 16 slices on the side
+        fuse_head = fuse_top and self.fuse_head and theta_sumsq_partials is not None
         for l in range(n_layers):
             W, b = params[2 * l], params[2 * l + 1]
             if l == L and single_out:
@@ -269,7 +275,9 @@ class BNNCost(object):
                 torch.addmm(b, h, W, out=hs[l])
             if l == L - 1 and fuse_top:
                 # tanh of the last hidden layer and the output unit's dot product in one launch
-                kernels.tanh_rowdot(hs[l], params[2 * L].view(-1), hs[L].view(-1))
+                kernels.tanh_rowdot(hs[l], params[2 * L].view(-1), hs[L].view(-1),
+                                    stats_workspace=theta_sumsq_partials if fuse_head else None,
+                                    tsq_parts=ws["tsq_parts"] if fuse_head else None)
             elif l < L:
                 torch.tanh_(hs[l])
             h = hs[l]
@@ -281,18 +289,28 @@ class BNNCost(object):
         prior_coef = self.wdecay / ((n_params + 3e-16) * self.n_examples)
         self.grad_theta_coef = prior_coef if self.fold_prior else 0.0
         beta = 0.0 if self.fold_prior else prior_coef
-        # loss head: delta_L, cost, d/d log_var, mse and (single-output net) the last bias gradient
-        kernels.bnn_head(hs[L].view(-1), Y.reshape(-1), params[-1], theta_sumsq, self.batch_size, self.n_examples,
-                         n_params, self.wdecay, self.prior_mean, self.prior_var,
-                         ds[L].view(-1), ws["cost"], grad_views[-1], ws["mse"], fold_prior_grad=self.fold_prior,
-                         stats_workspace=theta_sumsq_partials,
-                         last_bias=params[2 * L + 1] if single_out else None,
-                         grad_last_bias_out=grad_views[2 * L + 1] if single_out else None,
-                         add_last_bias=single_out)
+        if fuse_head:
+            # loss head + gW_L + delta_{L-1} (incl. tanh') + gb_{L-1} + gb_L + d/d log_var in ONE launch
+            kernels.bnn_head_last_layer_backward(
+                hs[L].view(-1), Y.reshape(-1), params[-1], ws["tsq_parts"], params[2 * L + 1], self.batch_size,
+                self.n_examples, n_params, self.wdecay, self.prior_mean, self.prior_var, params[2 * L].view(-1), hs[L - 1],
+                params[2 * (L - 1) + 1], beta, ws["cost"], grad_views[-1], grad_views[2 * L + 1], ws["mse"], ds[L - 1],
+                grad_views[2 * (L - 1) + 1], grad_views[2 * L].view(-1), fold_prior_grad=self.fold_prior, add_last_bias=True)
+        else:
+            # loss head: delta_L, cost, d/d log_var, mse and (single-output net) the last bias gradient
+            kernels.bnn_head(hs[L].view(-1), Y.reshape(-1), params[-1], theta_sumsq, self.batch_size, self.n_examples,
+                             n_params, self.wdecay, self.prior_mean, self.prior_var,
+                             ds[L].view(-1), ws["cost"], grad_views[-1], ws["mse"], fold_prior_grad=self.fold_prior,
+                             stats_workspace=theta_sumsq_partials,
+                             last_bias=params[2 * L + 1] if single_out else None,
+                             grad_last_bias_out=grad_views[2 * L + 1] if single_out else None,
+                             add_last_bias=single_out)
         self.last_mse = ws["mse"]
         for l in range(L, -1, -1):
             h_in = X if l == 0 else hs[l - 1]
             W, b = params[2 * l], params[2 * l + 1]
+            if l == L and fuse_head:
+                continue
             if l == L and single_out:
                 # gW_L, delta_{L-1} (incl. tanh') and gb_{L-1} in one launch
                 kernels.bnn_last_layer_backward(ds[l].view(-1), W.view(-1), hs[l - 1], ds[l - 1],

@@ -327,6 +327,42 @@ def test_bnn_cost_path_hip_equals_autograd(gpu, dt):
                     assert float((a - full).abs().max()) <= tol * float(a.abs().max()) + (1e-9 if dt == torch.float32 else 1e-15)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_fused_head_launch_equals_separate_kernels(gpu, dt):
+    """The loss head folded into the last layer's backward launch (``BNNCost.fuse_head``; sum(theta^2) slices from the
+    rowdot launch) against the separate head + backward kernels: every gradient bit-equal, cost / mse to the last bits
+    (sum(theta^2) is added in another order), for batches smaller and larger than the 16 slices and ragged widths."""
+    from pysgmcmc_amd import kernels
+    from pysgmcmc_amd.data_batches import Placeholder
+    from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
+    torch.manual_seed(1)
+    for hidden, B, D in (((50, 50, 50), 20, 1), ((2048, 2048), 256, 784), ((70,), 5, 3), ((33, 17), 300, 4)):
+        params = init_mlp_params(D, hidden=hidden, seed=2, dtype=dt, device=gpu)
+        for p in params[1::2]:
+            p.normal_()
+        n = sum(p.numel() for p in params)
+        # a statistics workspace like the one a step kernel leaves: many partials
+        flat = torch.cat([p.reshape(-1) for p in params])
+        st = kernels.StepStats(n, gpu)
+        zeros = torch.zeros_like(flat)
+        kernels.rsghmc_step(flat.clone(), zeros.clone(), zeros, 0.0, 1.0, 1.0, 0.0, 0.0, xi=zeros, stats=st)   # theta' = theta
+        xp = Placeholder().feed(torch.randn(B, D, dtype=dt, device=gpu))
+        yp = Placeholder().feed(torch.randn(B, 1, dtype=dt, device=gpu))
+        for fold in (False, True):
+            outs = []
+            for fuse in (False, True):
+                c = BNNCost(xp, yp, batch_size=20, n_examples=1000, fold_prior=fold)
+                c.fuse_head = fuse
+                gv = [torch.full_like(p, float("nan")) for p in params]
+                cost = c.cost_and_grad(params, gv, theta_sumsq_partials=st.workspace)
+                outs.append((float(cost), float(c.last_mse), [g.clone() for g in gv]))
+            (c0, m0, g0), (c1, m1, g1) = outs
+            rel = 1e-6 if dt == torch.float32 else 1e-14
+            assert abs(c0 - c1) <= rel * abs(c0) and abs(m0 - m1) <= rel * abs(m0), (hidden, B, fold, c0, c1)
+            for a, b in zip(g0, g1):
+                assert torch.isfinite(b).all() and torch.equal(a, b), (hidden, B, fold)
+
+
 def test_draw_noise_sample_api(gpu):
     s = SGHMCSampler(params=[torch.zeros(3, 2)], cost_fun=lambda p: (p[0] ** 2).sum(), session=gpu,
                      dtype=torch.float32, seed=4)
