@@ -1,0 +1,20 @@
+#!/bin/bash
+# Turn the output of tools/gpu/r02_profiles.sh (merged into gpurun_out/r02/) into the tracked files under profiles/.
+set -e
+O=gpurun_out/r02; R=${1:-r02}
+python3 tools/pmc_traffic.py profiles/${R}_pmc_traffic $O/pmc_10002434 $O/pmc_49826818 > /dev/null
+python3 tools/kernel_stats_summary.py $O/prof_bench10m/b_kernel_stats.csv profiles/${R}_bench10m_kernel_stats.csv
+python3 tools/kernel_stats_summary.py $O/prof_bench50m_sgld/b_kernel_stats.csv profiles/${R}_bench50m_sgld_kernel_stats.csv 16 60
+python3 tools/kernel_stats_summary.py $O/prof_bench50m_rsghmc/b_kernel_stats.csv profiles/${R}_bench50m_rsghmc_kernel_stats.csv 16 60
+python3 tools/kernel_stats_summary.py $O/probe_10002434_stats/s_kernel_stats.csv profiles/${R}_probe_10m_cold_kernel_stats.csv
+python3 tools/kernel_stats_summary.py $O/probe_49826818_stats/s_kernel_stats.csv profiles/${R}_probe_50m_cold_kernel_stats.csv
+cp $O/bench_driver_cmd_a.json profiles/${R}_bench_driver_cmd_a.json
+cp $O/bench_driver_cmd_b.json profiles/${R}_bench_driver_cmd_b.json
+cp $O/bench_default.json profiles/${R}_bench_n1.json
+cp $O/bench_2000.json profiles/${R}_bench_2000.json
+cp $O/bench_50m_sgld.json profiles/${R}_bench_50m_sgld.json
+cp $O/bench_50m_rsghmc.json profiles/${R}_bench_50m_rsghmc.json
+cp $O/prof_bench10m.json profiles/${R}_bench_n1_under_rocprof.json
+cp $O/stats_variant_cost.txt profiles/${R}_stats_variant_cost.txt
+cp $O/pytest_gpu.txt profiles/${R}_pytest_gpu.txt
+cp $O/examples.txt profiles/${R}_examples.txt
