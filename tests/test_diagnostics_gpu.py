@@ -118,7 +118,7 @@ from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
 assert kernels.sghmc_step.__module__ == "pysgmcmc_amd.kernels"          # the real ctypes front end, no shim
 dt = torch.float32 if dtname == "float32" else torch.float64
 n = 4099                                                                  # ragged: not a multiple of 4
-x = torch.full((n,), 3.0 * (rank - 0.5), dtype=dt, device=dev)            # over-dispersed start per chain
+x = torch.full((n,), 3.0 * (rank - 0.5 * (world - 1)) / max(world - 1, 1), dtype=dt, device=dev)   # over-dispersed starts
 s = SGHMCSampler(params=[x], cost_fun=lambda p: 0.5 * (p[0] ** 2).sum(), burn_in_steps=50, session=dev,
                  stepsize_schedule=ConstantStepsizeSchedule(0.1), dtype=dt, seed=100 + rank)
 s.sample_format = "view"
@@ -138,14 +138,19 @@ rhat2, none = ex.finish()
 assert none is None and torch.equal(rhat, rhat2) and ex.summary.as_dict() == summ and not ex.pending
 # parameter-sharded exchange (reduce-scatter layout; over gloo the class all-reduces the sharded pack)
 rs = RhatExchange(n, dev, dtype=dt, mode="reduce_scatter")
-assert rs.n_shards == 2 and rs.shard_len == 2052 and rs.n_valid == (2052 if rank == 0 else 2047)
+L = ((n + world - 1) // world + 3) // 4 * 4
+assert rs.n_shards == world and rs.shard_len == L and rs.n_valid == min(L, n - rank * L)
 rs.start(mom)
 next(s)
 shard, _ = rs.finish()
 lo = rank * rs.shard_len
-assert torch.equal(shard[:rs.n_valid], rhat[lo:lo + rs.n_valid]) and torch.equal(rs.gather(), rhat)
+# (two ranks: a + b is order-independent, so the layouts agree bit for bit; with more ranks the transport adds the
+# chains in a chunk-dependent order and the last bits may differ)
+same = torch.equal if world == 2 else (lambda a, b: torch.allclose(a, b, rtol=1e-5, atol=0))
+assert same(shard[:rs.n_valid], rhat[lo:lo + rs.n_valid]) and same(rs.gather(), rhat)
 ssum = rs.summary.as_dict()
-assert abs(ssum["mean"] - summ["mean"]) <= 1e-12 * abs(summ["mean"]) and ssum["max"] == summ["max"]
+assert abs(ssum["mean"] - summ["mean"]) <= (1e-12 if world == 2 else 1e-6) * abs(summ["mean"])
+assert ssum["max"] == summ["max"] if world == 2 else abs(ssum["max"] - summ["max"]) <= 1e-5 * summ["max"]
 ess = ess_across_ranks(torch.tensor(trace, dtype=torch.float32, device=dev))
 np.savez(os.path.join(out_dir, "rank%d.npz" % rank), kept=np.array(kept), rhat=rhat.cpu().numpy(),
          rhat_mean=summ["mean"], rhat_max=summ["max"], ess=np.array(ess), trace=np.array(trace),
@@ -157,48 +162,53 @@ dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("dtname", ["float32", "float64"])
-def test_two_ranks_on_one_gpu_real_kernels_rhat_and_ess(gpu, oracle, tmp_path, dtname):
+@pytest.mark.parametrize("dtname,world", [("float32", 2), ("float64", 2), ("float32", 8)])
+def test_two_ranks_on_one_gpu_real_kernels_rhat_and_ess(gpu, oracle, tmp_path, dtname, world):
+    """2 ranks (f32, f64) and the configs[3] rank count, 8 (f32), all on cuda:0."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2",
+    for rank in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                    LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, str(script), dtname, str(tmp_path)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=500)[0] for p in procs]
     for p, out in zip(procs, outs):
         assert p.returncode == 0, out[-3000:]
-    r = [np.load(str(tmp_path / ("rank%d.npz" % k))) for k in range(2)]
+    r = [np.load(str(tmp_path / ("rank%d.npz" % k))) for k in range(world)]
     npdt = np.float32 if dtname == "float32" else np.float64
-    chains = np.stack([r[0]["kept"], r[1]["kept"]])                      # (2, 200, n)
-    assert chains.shape == (2, 200, 4099) and not np.array_equal(chains[0], chains[1])
-    # both ranks hold the same R-hat; it equals the oracle's Gelman-Rubin on the very samples
-    assert np.array_equal(r[0]["rhat"], r[1]["rhat"])
+    chains = np.stack([r[k]["kept"] for k in range(world)])               # (m, 200, n)
+    assert chains.shape == (world, 200, 4099) and not np.array_equal(chains[0], chains[1])
+    # every rank holds the same R-hat; it equals the oracle's Gelman-Rubin on the very samples
+    assert all(np.array_equal(r[0]["rhat"], r[k]["rhat"]) for k in range(1, world))
     want = oracle.gelman_rubin(chains)
     tol = 2e-3 if npdt == np.float32 else 1e-9                           # f32: Welford + sum-form B in single precision
     assert np.allclose(r[0]["rhat"], want, rtol=tol), np.abs(r[0]["rhat"] / want - 1).max()
     assert np.isclose(float(r[0]["rhat_max"]), float(r[0]["rhat"].max()), rtol=1e-6)
     assert np.isclose(float(r[0]["rhat_mean"]), float(r[0]["rhat"].astype(np.float64).mean()), rtol=1e-6)
     # bit-exact leg: K4 moments == the C oracle's Welford on the same samples, pack/finish == the C oracle's
-    for k in range(2):
+    for k in range(world):
         mean, m2 = np.zeros(4099, npdt), np.zeros(4099, npdt)
         for c, smp in enumerate(r[k]["kept"]):
             oracle.c_moments_update(np.ascontiguousarray(smp.astype(npdt)), mean, m2, c + 1)
         assert np.array_equal(mean, r[k]["mean"]) and np.array_equal(m2, r[k]["m2"])
-    total = sum(oracle.c_rhat_pack(r[k]["mean"], r[k]["m2"], int(r[k]["count"])) for k in range(2))
-    assert np.array_equal(oracle.c_rhat_finish(total.astype(npdt), 2, int(r[0]["count"])), r[0]["rhat"])
+    if world == 2:      # (the sum of more than two packs depends on the transport's reduction order: f32 compared above)
+        total = sum(oracle.c_rhat_pack(r[k]["mean"], r[k]["m2"], int(r[k]["count"])) for k in range(2))
+        assert np.array_equal(oracle.c_rhat_finish(total.astype(npdt), 2, int(r[0]["count"])), r[0]["rhat"])
     # the sharded layout: chunk s of the pack = rows of parameter shard s; finishing the chunks gives the same R-hat
-    L = 2052
-    tot = sum(oracle.c_rhat_pack(r[k]["mean"], r[k]["m2"], int(r[k]["count"]), 2, L) for k in range(2)).astype(npdt)
-    parts = [oracle.c_rhat_finish(np.ascontiguousarray(tot[s * 3 * L:(s + 1) * 3 * L]), 2, int(r[0]["count"]),
-                                  n=min(L, 4099 - s * L), ld=L) for s in range(2)]
-    assert np.array_equal(np.concatenate(parts), r[0]["rhat"])
+    L = ((4099 + world - 1) // world + 3) // 4 * 4
+    tot = sum(oracle.c_rhat_pack(r[k]["mean"], r[k]["m2"], int(r[k]["count"]), world, L) for k in range(world)).astype(npdt)
+    parts = [oracle.c_rhat_finish(np.ascontiguousarray(tot[s * 3 * L:(s + 1) * 3 * L]), world, int(r[0]["count"]),
+                                  n=min(L, 4099 - s * L), ld=L) for s in range(world)]
+    if world == 2:
+        assert np.array_equal(np.concatenate(parts), r[0]["rhat"])
+    else:
+        assert np.allclose(np.concatenate(parts), r[0]["rhat"], rtol=1e-5)
     # ESS of cost and two coordinates from the all-gathered thinned traces
-    traces = np.stack([r[0]["trace"], r[1]["trace"]])                    # (2, 200, 3)
-    assert np.array_equal(r[0]["ess"], r[1]["ess"])
+    traces = np.stack([r[k]["trace"] for k in range(world)])              # (m, 200, 3)
+    assert all(np.array_equal(r[0]["ess"], r[k]["ess"]) for k in range(1, world))
     for k in range(3):
         assert int(r[0]["ess"][k]) == oracle.effective_n(traces[:, :, k].astype(np.float32).astype(np.float64))
     assert str(r[0]["lib"]).endswith("libsgmcmc_hip.so")
