@@ -159,6 +159,27 @@ def test_train_predict_sinc(gpu, method, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("normalize", [True, False])
+def test_train_predict_sinc_with_and_without_normalisation(gpu, normalize):
+    """The reference's own loop (tests/bayesian_neural_network/test_train_predict.py:27-48): the same training with
+    ``normalize_input = normalize_output`` True and False, float64 like the reference, test MSE within 0.1."""
+    rng = np.random.RandomState(7)
+    X = rng.rand(100, 1)
+    y = np.sinc(X * 10 - 5).sum(axis=1)
+    X_test = np.linspace(0, 1, 100)[:, None]
+    y_test = np.sinc(X_test * 10 - 5).sum(axis=1)
+    bnn = BayesianNeuralNetwork(session=gpu, dtype=torch.float64, burn_in_steps=1000, n_nets=10, seed=2,
+                                normalize_input=normalize, normalize_output=normalize)
+    assert not bnn.is_trained
+    with pytest.raises(ValueError):
+        bnn.predict(X_test)                                   # test_predict_before_train_error, :51-72
+    bnn.train(X, y)
+    assert bnn.is_trained
+    mean, var = bnn.predict(X_test)
+    assert np.mean((y_test - mean) ** 2) < 0.1
+
+
+@pytest.mark.gpu
 def test_train_is_seed_reproducible_and_graph_equals_eager(gpu):
     rng = np.random.RandomState(2)
     X, y = rng.rand(60, 2), rng.rand(60)
