@@ -365,3 +365,11 @@ def test_arena_rebind_and_param_alignment():
     assert arena.grad_views[1].data_ptr() == arena.row("grad")[5:].data_ptr()
     padded = FlatArena([torch.zeros(5), torch.zeros(70), torch.zeros(3)], (), torch.float32, "cpu", param_align=64)
     assert padded.offsets == [0, 64, 192] and padded.n == 256
+
+
+def test_get_sampler_import_missing():
+    """The reference's tests/test_sampling.py:8-23: a method the enum accepts but `get_sampler` has no import for raises
+    ValueError (the reference's message, format placeholder and all)."""
+    from pysgmcmc_amd.sampling import Sampler
+    with pytest.raises(ValueError, match="missing an `import` statement"):
+        Sampler.get_sampler("NEW_SAMPLER")
