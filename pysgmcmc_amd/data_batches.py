@@ -118,6 +118,14 @@ class WindowBatches(object):
         # one vectorised draw = the same values as n successive scalar randint calls (same RandomState stream)
         return self._rng.randint(0, hi, size=int(n)).astype(np.int32)
 
+    def state_dict(self):
+        """Position in the window stream (the RandomState), for ``sampler.state_dict()``: a resumed chain sees the same
+        minibatches as the uninterrupted one."""
+        return {"rng": self._rng.get_state()}
+
+    def load_state_dict(self, state):
+        self._rng.set_state(state["rng"])
+
     def __next__(self):
         start = int(self.next_starts(1)[0])
         return {

@@ -439,9 +439,15 @@ class MCMCSampler(object):
 
     # ------------------------------------------------------------------ state
     def state_dict(self):
-        """Everything needed to resume the chain bit-exactly (the reference cannot checkpoint)."""
-        return {"arena": self.arena.state_dict(), "n_iterations": self.n_iterations,
-                "philox_seed": self._philox_seed, "epsilon": self.epsilon}
+        """Everything needed to resume the chain bit-exactly (the reference cannot checkpoint): the arena, the step
+        counter and Philox key, and -- when they can report it -- the position of the minibatch generator's window
+        stream and of the stepsize schedule."""
+        state = {"arena": self.arena.state_dict(), "n_iterations": self.n_iterations,
+                 "philox_seed": self._philox_seed, "epsilon": self.epsilon}
+        for key, obj in (("batch_generator", self.batch_generator), ("stepsize_schedule", self.stepsize_schedule)):
+            if hasattr(obj, "state_dict"):
+                state[key] = obj.state_dict()
+        return state
 
     def load_state_dict(self, state):
         self.arena.load_state_dict(state["arena"])
@@ -449,6 +455,9 @@ class MCMCSampler(object):
         self.n_iterations = int(state["n_iterations"])
         self._philox_seed = int(state["philox_seed"])
         self.epsilon = state["epsilon"]
+        for key, obj in (("batch_generator", self.batch_generator), ("stepsize_schedule", self.stepsize_schedule)):
+            if key in state and hasattr(obj, "load_state_dict"):
+                obj.load_state_dict(state[key])
 
 
 class BurnInMCMCSampler(MCMCSampler):

@@ -75,6 +75,12 @@ class BurnInRampStepsizeSchedule(StepsizeSchedule):
         self._t += 1
         return self.initial_value + (self.final_value - self.initial_value) * frac
 
+    def state_dict(self):
+        return {"t": self._t}
+
+    def load_state_dict(self, state):
+        self._t = int(state["t"])
+
     def __str__(self):
         return "BurnInRampStepsizeSchedule(initial={}, final={}, burn_in_steps={})".format(
             self.initial_value, self.final_value, self.burn_in_steps)

@@ -363,6 +363,42 @@ def test_fused_head_launch_equals_separate_kernels(gpu, dt):
                 assert torch.isfinite(b).all() and torch.equal(a, b), (hidden, B, fold)
 
 
+def test_checkpoint_resume_with_minibatches_and_schedule(gpu):
+    """A BNN chain with a minibatch generator and a stepsize ramp, checkpointed across the burn-in -> frozen switch and
+    resumed in a FRESH sampler: same windows, same stepsizes, same Philox stream -> bit-equal chain (eager and graph)."""
+    from pysgmcmc_amd.data_batches import Placeholder, generate_batches
+    from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
+    from pysgmcmc_amd.stepsize_schedules import BurnInRampStepsizeSchedule
+    rng = np.random.RandomState(0)
+    X, y = rng.rand(300, 4), rng.rand(300)
+
+    def chain(graph):
+        xp, yp = Placeholder(dtype=torch.float32, device=gpu), Placeholder(dtype=torch.float32, device=gpu)
+        params = init_mlp_params(4, hidden=(32, 32), seed=5, dtype=torch.float32, device=gpu)
+        s = SGLDSampler(params=params, cost_fun=BNNCost(xp, yp, batch_size=16, n_examples=300),
+                        batch_generator=generate_batches(X, y, xp, yp, batch_size=16, seed=2),
+                        stepsize_schedule=BurnInRampStepsizeSchedule(1e-4, 1e-2, burn_in_steps=9), burn_in_steps=9,
+                        scale_grad=300.0, session=gpu, dtype=torch.float32, seed=9)
+        s.sample_format = "view"
+        s.use_hip_graph = graph
+        return s
+    for graph in (False, True):
+        full = chain(graph)
+        costs = [float(next(full)[1]) for _ in range(20)]
+        a = chain(graph)
+        for _ in range(6):
+            next(a)
+        ckpt = a.state_dict()
+        assert "batch_generator" in ckpt and ckpt["stepsize_schedule"] == {"t": 6}
+        b = chain(graph)
+        b.load_state_dict(ckpt)
+        resumed = [float(next(b)[1]) for _ in range(14)]
+        assert resumed == costs[6:], (graph, resumed[:3], costs[6:9])
+        for row in ("theta", "minv", "tau"):
+            assert torch.equal(b.arena.row(row), full.arena.row(row)), (graph, row)
+        assert b.n_iterations == 20 and not b.is_burning_in
+
+
 def test_draw_noise_sample_api(gpu):
     s = SGHMCSampler(params=[torch.zeros(3, 2)], cost_fun=lambda p: (p[0] ** 2).sum(), session=gpu,
                      dtype=torch.float32, seed=4)
