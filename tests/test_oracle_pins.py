@@ -221,3 +221,13 @@ def test_svgd_oracle_known_answers_and_golden(oracle):
         # the reference's sign contracts the cloud, the repulsive sign keeps it spread
     spread = {s: d["banana|10|float64|%d|x" % s][-1].std(axis=0).max() for s in (1, -1)}
     assert spread[1] < spread[-1]
+
+
+def test_c_oracle_is_clean_under_address_and_ub_sanitizers():
+    """SURVEY section 5 (race detection / sanitizers): every entry point of the C oracle, ragged sizes, sharded R-hat
+    layout and the toy chains, built with -fsanitize=address,undefined (errors abort) and run once."""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    res = subprocess.run(["make", "-s", "-C", here, "sanitize"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "sanitize: ok" in res.stdout, (res.stdout[-2000:], res.stderr[-2000:])
