@@ -138,72 +138,6 @@ def build_chain(dev, rank, workload="bnn10m-sghmc", burn_in=8):
                                     mass=1.0, speed_of_light=1.0, D=1.0, Bhat=0.0, **common)
 
 
-class KernelTimer(object):
-    """HIP-event timing of the fused update launch, on the stream it is launched on, two ways at once:
-      * ``kernel``: the launch carries a pair of events that receive the KERNEL's own start / stop timestamps
-        (``sgmcmc_launch_t.start_event / stop_event`` -> hipExtLaunchKernel; what rocprofv3 reports as the kernel's
-        duration) -- this is `roofline.achieved`;
-      * ``bracket``: a hipEventRecord pair around the call (r01's method; includes ~3-5 us of barrier-packet and
-        dispatch latency) -- reported next to it as the conservative figure."""
-
-    def __init__(self, sampler):
-        from pysgmcmc_amd import kernels
-        self.kernels = kernels
-        self.pairs = []
-        self.kevents = []
-        self.pool = []
-        self.enabled = False
-        self.bracket = os.environ.get("BENCH_BRACKET", "0") == "1"    # also put a hipEventRecord pair around each launch
-        for name in ("sghmc_step", "sgld_step", "rsghmc_step"):   # each is ONE launch: the fused update kernel
-            setattr(kernels, name, self._wrap(getattr(kernels, name)))
-
-    def reserve(self, n):
-        """Create the events of ``n`` timed launches up front (no hipEventCreate inside the timed region)."""
-        self.pool = [(self.kernels.KernelEvents(), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                     for _ in range(n)]
-
-    def _wrap(self, inner):
-        def timed(*a, **kw):
-            if not self.enabled:
-                return inner(*a, **kw)
-            kev, e0, e1 = self.pool.pop() if self.pool else (
-                self.kernels.KernelEvents(), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            base = kw.get("launch")
-            geom = base.as_dict() if base is not None else {}
-            kw["launch"] = self.kernels.LaunchConfig(events=kev, **geom)
-            if self.bracket:
-                e0.record()
-            inner(*a, **kw)
-            if self.bracket:
-                e1.record()
-                self.pairs.append((e0, e1))
-            self.kevents.append(kev)
-        return timed
-
-    def kernel_us(self):
-        return np.array([k.elapsed_us() for k in self.kevents])
-
-    @staticmethod
-    def event_pair_overhead_us(reps=200):
-        """Elapsed time of an EMPTY event pair on the same stream: the fixed cost every bracketed
-        launch carries (barrier packets + dispatch latency). Reported next to the raw numbers."""
-        torch.cuda.synchronize()
-        pairs = []
-        for _ in range(reps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            e1.record()
-            pairs.append((e0, e1))
-        torch.cuda.synchronize()
-        return float(np.median([a.elapsed_time(b) for a, b in pairs])) * 1e3
-
-    def mean_us(self):
-        return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) * 1e3 if self.pairs else None
-
-    def median_us(self):
-        return float(np.median([a.elapsed_time(b) for a, b in self.pairs])) * 1e3 if self.pairs else None
-
-
 def update_only(sampler, iters=200):
     """Back-to-back launches of the fused kernel alone on the chain's own arrays (no gradient work)."""
     from pysgmcmc_amd import kernels
@@ -531,7 +465,10 @@ def main():
     sampler.sample_format = "view"                             # no D2H copy of 40 MB per sample
     sampler.use_hip_graph = not args.eager
     n = sampler.arena.n
-    timer = KernelTimer(sampler)
+    from pysgmcmc_amd.profiling import UpdateKernelTimer
+    # per-launch kernel timestamps of the update kernel; BENCH_BRACKET=1 also records a hipEventRecord pair around each call
+    timer = UpdateKernelTimer(bracket=os.environ.get("BENCH_BRACKET", "0") == "1")
+    sampler.kernel_timer = timer
     from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange
     moments = ChainMoments(n, dev)
     exchange = RhatExchange(n, dev, mode=args.rhat_mode) if world > 1 else None
@@ -659,8 +596,9 @@ def main():
     if rank == 0:
         mode = "rsghmc" if kind == "rsghmc" else "%s_%s" % (kind, "frozen" if frozen_phase else "adapt")
         op_name = {"sghmc": "SghmcOp", "sgld": "SgldOp", "rsghmc": "RsghmcOp"}[kind]
-        b_us = timer.mean_us()                      # hipEventRecord bracket around the call (BENCH_BRACKET=1), else None
-        ev_us = timer.event_pair_overhead_us()
+        br = timer.bracket_us()                     # hipEventRecord bracket around the call (BENCH_BRACKET=1), else empty
+        b_us = float(br.mean()) if br.size else None
+        ev_us = timer.empty_bracket_us()
         kern = timer.kernel_us()                    # the kernel's own start/stop timestamps, one pair per launch
         k_us = float(kern.mean())
         alg_bytes = BYTES_PER_PARAM[mode] * n
@@ -668,8 +606,7 @@ def main():
         big = alg_bytes > (640 << 20)
         traffic, traffic_src = pmc_traffic(mode, n, stats_variant=True)   # the pipeline launches the STATS variant
         # per-step device time: from the end of one step's update kernel to the end of the next one's
-        kv = timer.kevents
-        step_ms = np.array([kv[j].us_until(kv[j + 1]) for j in range(len(kv) - 1)]) * 1e-3 if len(kv) > 1 else None
+        step_ms = timer.step_us() * 1e-3 if len(timer.kevents) > 1 else None
         line = {
             "metric": "MCMC samples/sec + fused-update HBM GB/s (% roofline), BNN 10M params",
             "value": round(world * args.steps / elapsed, 2),
@@ -708,7 +645,7 @@ def main():
                          "launches_timed": len(timer.kevents),
                          # the conservative figure of round 1: hipEventRecord pair AROUND the call
                          "bracket": None if b_us is None else {
-                             "us_per_launch_mean": round(b_us, 2), "us_per_launch_median": round(timer.median_us(), 2),
+                             "us_per_launch_mean": round(b_us, 2), "us_per_launch_median": round(float(np.median(br)), 2),
                              "us_empty_event_pair": round(ev_us, 2),
                              "achieved": round(alg_bytes / (b_us * 1e-6) / 1e9, 1),
                              "frac": round(alg_bytes / (b_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},

@@ -1,0 +1,85 @@
+"""Timing of a sampler's fused update kernel, launch by launch (the reference has no profiling hooks, SURVEY.md
+section 5; this is what ``bench.py`` builds its ``roofline`` entry from).
+
+    timer = UpdateKernelTimer(reserve=200)
+    sampler.kernel_timer = timer
+    timer.enabled = True
+    for _ in range(200):
+        next(sampler)
+    torch.cuda.synchronize()
+    timer.kernel_us()          # duration of every update launch, from the kernel's own start/stop timestamps
+
+Every timed launch carries a pair of HIP events (``sgmcmc_launch_t.start_event / stop_event`` -> ``hipExtLaunchKernel``)
+that receive the KERNEL's start and stop timestamps -- the duration rocprofv3 reports for the kernel. ``bracket=True``
+additionally records a ``hipEventRecord`` pair around the call on the same stream (it includes ~3-5 us of barrier-packet
+and dispatch latency). Timing applies to direct launches (eager stepping and ``use_hip_graph = True``); a launch captured
+into a hipGraph (``use_hip_graph = "full"``) cannot carry events and is not timed.
+"""
+import numpy as np
+import torch
+
+from pysgmcmc_amd import kernels
+
+__all__ = ["UpdateKernelTimer"]
+
+
+class UpdateKernelTimer(object):
+    def __init__(self, reserve=0, bracket=False):
+        self.enabled = False
+        self.bracket = bool(bracket)
+        self.kevents = []          # one KernelEvents per timed launch, in launch order
+        self.pairs = []            # (torch event, torch event) brackets, when bracket=True
+        self._pool = []
+        self._current = None
+        if reserve:
+            self.reserve(reserve)
+
+    def reserve(self, n):
+        """Create the events of ``n`` timed launches up front (no event creation inside a timed loop)."""
+        self._pool = [(kernels.KernelEvents(), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                      for _ in range(int(n))]
+
+    # -- called by the sampler around its update launch --
+    def begin(self):
+        self._current = self._pool.pop() if self._pool else (
+            kernels.KernelEvents(), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        if self.bracket:
+            self._current[1].record()
+
+    def launch_config(self, base):
+        """The launch geometry ``base`` (or the defaults) plus this launch's timestamp events."""
+        geom = base.as_dict() if base is not None else {}
+        return kernels.LaunchConfig(events=self._current[0], **geom)
+
+    def end(self):
+        kev, e0, e1 = self._current
+        if self.bracket:
+            e1.record()
+            self.pairs.append((e0, e1))
+        self.kevents.append(kev)
+        self._current = None
+
+    # -- results (after the stream has been synchronised) --
+    def kernel_us(self):
+        return np.array([k.elapsed_us() for k in self.kevents])
+
+    def step_us(self):
+        """Time from the end of each timed update kernel to the end of the next: the device time of a whole step."""
+        kv = self.kevents
+        return np.array([kv[j].us_until(kv[j + 1]) for j in range(len(kv) - 1)])
+
+    def bracket_us(self):
+        return np.array([a.elapsed_time(b) * 1e3 for a, b in self.pairs])
+
+    @staticmethod
+    def empty_bracket_us(reps=200):
+        """Elapsed time of an EMPTY hipEventRecord pair: the fixed cost every bracketed launch carries."""
+        torch.cuda.synchronize()
+        pairs = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        return float(np.median([a.elapsed_time(b) for a, b in pairs])) * 1e3

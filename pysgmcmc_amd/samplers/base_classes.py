@@ -107,6 +107,8 @@ class MCMCSampler(object):
         self.sample_format = "numpy"
         # launch geometry of this chain's update kernel (kernels.LaunchConfig; None = library defaults)
         self.launch = None
+        # pysgmcmc_amd.profiling.UpdateKernelTimer (or None): per-launch kernel timestamps of the update kernel
+        self.kernel_timer = None
 
         params = list(params)
         for p in params:
@@ -309,6 +311,24 @@ class MCMCSampler(object):
     def _kernel_step(self, eps, xi):
         raise NotImplementedError
 
+    def _launch(self):
+        """Launch configuration of the update kernel for THIS launch: the chain's geometry, plus the timestamp events
+        of an attached, enabled kernel timer (never inside a graph capture)."""
+        t = self.kernel_timer
+        if t is not None and t._current is not None:
+            return t.launch_config(self.launch)
+        return self.launch
+
+    def _timed_kernel_step(self, eps, xi):
+        t = self.kernel_timer
+        if t is None or not t.enabled or self._capturing:
+            return self._kernel_step(eps, xi)
+        t.begin()
+        try:
+            self._kernel_step(eps, xi)
+        finally:
+            t.end()
+
     def _step(self, feed_dict):
         assert (feed_dict is None or hasattr(feed_dict, "update"))
         if feed_dict is None:
@@ -321,7 +341,7 @@ class MCMCSampler(object):
         cost = self._cost_and_grad()          # U(theta_{t-1}) and its gradient
         self.cost = cost
         with torch.no_grad():
-            self._kernel_step(eps, self._draw_noise())
+            self._timed_kernel_step(eps, self._draw_noise())
         sample = self._format_sample()        # theta_t
         cost_out = self._format_cost(cost)
         self.stepsize_schedule.update(sample, cost_out)
@@ -400,7 +420,7 @@ class MCMCSampler(object):
             self._ctr_value += 1
         else:
             with torch.no_grad():
-                self._kernel_step(eps, None)
+                self._timed_kernel_step(eps, None)
         self.cost = cost
         sample = self._format_sample()
         cost_out = self._format_cost(cost)

@@ -137,7 +137,7 @@ class RelativisticSGHMCSampler(MCMCSampler):
         kernels.rsghmc_step(
             a.row("theta"), a.row("p"), a.row("grad"),
             eps, self.mass, self.speed_of_light, self.D, self.Bhat,
-            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, launch=self.launch, **self._noise_args())
+            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, launch=self._launch(), **self._noise_args())
         if self._stats is not None:
             self._stats_valid = True          # the workspace now holds this step's per-block partials
             self._stats_out_valid = False     # K7 runs lazily (sampler.stats); the BNN head reads the partials

@@ -58,7 +58,7 @@ class SGLDSampler(FusedBNNStepsMixin, BurnInMCMCSampler):
             a.row("theta"), a.row("grad"),
             a.row("tau"), a.row("g"), a.row("v_hat"), a.row("minv"), self._r_row(),
             eps, self.A, self.scale_grad, self._adapting,
-            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, launch=self.launch, **self._noise_args())
+            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, launch=self._launch(), **self._noise_args())
         if self._stats is not None:
             self._stats_valid = True          # the workspace now holds this step's per-block partials
             self._stats_out_valid = False     # K7 runs lazily (sampler.stats); the BNN head reads the partials

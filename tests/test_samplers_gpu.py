@@ -399,6 +399,36 @@ def test_checkpoint_resume_with_minibatches_and_schedule(gpu):
         assert b.n_iterations == 20 and not b.is_burning_in
 
 
+def test_update_kernel_timer_through_the_sampler(gpu):
+    """pysgmcmc_amd.profiling.UpdateKernelTimer attached to a sampler: one kernel-timestamp pair per update launch in
+    eager and cost-graph stepping, none while disabled; the chain is unchanged by the instrumentation."""
+    from pysgmcmc_amd.profiling import UpdateKernelTimer
+
+    def chain(graph, timed):
+        s = SGHMCSampler(params=[torch.zeros(500_000, device=gpu)], cost_fun=lambda p: 0.5 * (p[0] ** 2).sum(),
+                         burn_in_steps=3, session=gpu, dtype=torch.float32, seed=4)
+        s.sample_format = "view"
+        s.use_hip_graph = graph
+        t = UpdateKernelTimer(reserve=4, bracket=True)
+        s.kernel_timer = t
+        for _ in range(3):
+            next(s)                                   # not enabled yet: nothing recorded
+        assert not t.kevents
+        t.enabled = timed
+        for _ in range(7):
+            next(s)
+        torch.cuda.synchronize()
+        return s, t
+    ref, _ = chain(False, False)
+    for graph in (False, True):
+        s, t = chain(graph, True)
+        us, steps, br = t.kernel_us(), t.step_us(), t.bracket_us()
+        assert us.shape == (7,) and steps.shape == (6,) and br.shape == (7,)
+        assert np.all(us > 1.0) and np.all(us < 500.0) and np.all(steps >= us[1:] * 0.99)
+        assert torch.equal(s.arena.row("theta"), ref.arena.row("theta"))
+    assert UpdateKernelTimer.empty_bracket_us(20) >= 0.0
+
+
 def test_draw_noise_sample_api(gpu):
     s = SGHMCSampler(params=[torch.zeros(3, 2)], cost_fun=lambda p: (p[0] ** 2).sum(), session=gpu,
                      dtype=torch.float32, seed=4)
