@@ -1,0 +1,55 @@
+"""configs[3] in ~40 lines: one independent SGHMC chain per GPU, cross-chain R-hat over RCCL every 100 steps.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/multi_gpu_chains.py
+
+(The reference runs its chains one after another in fresh TF graphs, pysgmcmc/diagnostics/sample_chains.py:369-382, and
+hands them to pymc3.diagnostics.gelman_rubin.) Rehearsal on ONE GPU: add `--gloo-one-gpu` (every rank on cuda:0, gloo).
+"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pysgmcmc_amd.data_batches import Placeholder, generate_batches  # noqa: E402
+from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange  # noqa: E402
+from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params  # noqa: E402
+from pysgmcmc_amd.samplers import SGHMCSampler  # noqa: E402
+from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule  # noqa: E402
+
+if int(os.environ.get("WORLD_SIZE", "1")) < 2:
+    print("multi_gpu_chains.py needs >= 2 ranks: launch it through torch.distributed.run (see the docstring)")
+    sys.exit(0)
+one_gpu = "--gloo-one-gpu" in sys.argv
+rank, local = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+dev = torch.device("cuda", 0 if one_gpu else local)
+torch.cuda.set_device(dev)
+if one_gpu:
+    dist.init_process_group("gloo")
+else:
+    dist.init_process_group("nccl", device_id=dev)                      # "nccl" is RCCL on ROCm
+g = torch.Generator(device=dev).manual_seed(0)                          # the same synthetic data set on every rank
+X, y = torch.randn(20_000, 64, device=dev, generator=g), torch.randn(20_000, device=dev, generator=g)
+xp, yp = Placeholder(dtype=torch.float32, device=dev), Placeholder(dtype=torch.float32, device=dev)
+params = init_mlp_params(64, hidden=(512, 512), seed=100 + rank, dtype=torch.float32, device=dev)   # over-dispersed starts
+sampler = SGHMCSampler(params=params, cost_fun=BNNCost(xp, yp, batch_size=256, n_examples=20_000),
+                       batch_generator=generate_batches(X, y, xp, yp, batch_size=256, seed=rank),
+                       stepsize_schedule=ConstantStepsizeSchedule(0.01), burn_in_steps=200, scale_grad=20_000.0,
+                       session=dev, dtype=torch.float32, seed=1234 + rank)
+sampler.sample_format = "view"                                          # samples stay in HBM
+sampler.use_hip_graph = True
+moments = ChainMoments(sampler.arena.n, dev)
+exchange = RhatExchange(sampler.arena.n, dev, mode="reduce_scatter")    # half the xGMI traffic of an all-reduce
+for step in range(1, 1201):
+    next(sampler)
+    if step > 200 and step % 10 == 0:
+        moments.update(sampler.arena.row("theta"))                      # Welford mean / M2 of this chain (kernel K4)
+    if step > 400 and step % 100 == 0:
+        exchange.start(moments)                                         # pack + async reduce-scatter on RCCL's stream
+    elif exchange.pending and step % 100 == 50:
+        exchange.finish()                                               # stream-level wait, R-hat of this rank's shard
+        if rank == 0:
+            print("step %4d  R-hat over %d chains: %s" % (step, dist.get_world_size(), exchange.summary.as_dict()))
+dist.barrier()
+dist.destroy_process_group()
