@@ -32,8 +32,11 @@ BNN gradient + the fused C oracle update), unit samples/s like ``value``.
 """
 import argparse
 import gc
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,7 +50,8 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:35
 # algorithmic bytes per parameter per launch, fp32
 BYTES_PER_PARAM = {"sghmc_frozen": 24, "sghmc_adapt": 48, "sgld_frozen": 16, "sgld_adapt": 40, "rsghmc": 20}
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix-core peak, /opt/skills/guides/MI355X_MICROARCH.md
 PRIME_BURN_IN = 8              # adapting steps of the chain, run in the prime phase (never timed)
 PRIME_FROZEN = 4               # frozen steps of the prime phase with a moments update + trace append each
 PRIME_STEADY = int(os.environ.get("BENCH_PRIME_STEADY", "124"))   # further frozen steps: ~30 ms of device work, after which
@@ -55,19 +59,36 @@ PRIME_STEADY = int(os.environ.get("BENCH_PRIME_STEADY", "124"))   # further froz
 N_HBM_RESIDENT = 49_826_818    # configs[4]'s parameter count: 1.2 GB per frozen SGHMC launch
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources of the library (csrc/*.hip, *.hpp and the C ABI header): identifies the build a
+    PMC traffic table was collected with (tools/pmc_traffic.py stores it; there is no .git on the GPU box)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "pysgmcmc_amd", "csrc")
+    files = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp")))
+    for path in [os.path.join(csrc, f) for f in files] + [os.path.join(ROOT, "include", "sgmcmc_hip.h")]:
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(mode, n, stats_variant=False):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of the CURRENT kernels
-    (tools/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950
-    correction of MI355X_MICROARCH.md, calibrated on launches with known byte counts). Returns
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py: separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, calibrated on launches with
+    known byte counts) -- but ONLY if that table was collected with the kernel sources this run uses (source hash
+    recorded in the file); a stale table yields None rather than an old byte count next to fresh timings. Returns
     (bytes per launch or None, source string)."""
+    name = os.path.relpath(PMC_TRAFFIC_FILE, ROOT)
     try:
         with open(PMC_TRAFFIC_FILE) as fh:
             doc = json.load(fh)
+        have, want = doc.get("kernel_source_hash"), kernel_source_hash()
+        if have != want:
+            return None, "%s was collected with kernel sources %s, this build is %s: traffic not reported" % (name, have, want)
         sizes = doc["sizes"][str(n)]
         entry = sizes.get(mode + "_stats", sizes[mode]) if stats_variant else sizes[mode]
-        return int(round(entry["bytes_per_param"] * n)), "profiles/r02_pmc_traffic.json (%s)" % doc.get("collected", "?")
+        return int(round(entry["bytes_per_param"] * n)), "%s (%s, kernel sources %s)" % (name, doc.get("collected", "?"), have)
     except (OSError, KeyError, ValueError):
-        return None, "no PMC pass for n=%d in profiles/r02_pmc_traffic.json" % n
+        return None, "no PMC pass for n=%d in %s" % (n, name)
 BATCH = 256
 N_DATA = 100_000
 # workloads: the default is BASELINE.json configs[2]; the 50 M ones are configs[4]'s two samplers
@@ -101,6 +122,12 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="step eagerly instead of replaying one hipGraph per step")
     ap.add_argument("--max-queue-depth", type=int, default=64,
                     help="steps the host may run ahead of the device in the timed loop (0 = unbounded)")
+    ap.add_argument("--overlap", choices=["on", "off"], default=os.environ.get("BENCH_OVERLAP", "off"),
+                    help="off (default): one update launch after the backward pass. on: update the arena layer by layer on a "
+                         "side stream under the remaining backward GEMMs -- bit-identical chain, measured SLOWER on MI355X "
+                         "(profiles/r03_overlap_probe.txt); kept to reproduce that result")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="N > 1 started without a launcher: wall-clock limit of the ranks this process spawns (s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-update-only", action="store_true", help="skip the kernel-only loops (for rocprof runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline leg")
@@ -211,7 +238,7 @@ def hbm_resident_roofline(dev, n=N_HBM_RESIDENT, iters=40):
         V.zero_()
     assert torch.isfinite(theta).all()
     head = out["sghmc_frozen"]
-    return {"bound": "hbm", "kernel": "stream_quads_vec<SghmcOp<float,false,false>,1,true,false,false> (128-lane blocks, nt)",
+    return {"bound": "hbm", "kernel": "stream_quads_vec<SghmcOp<float,false,false>,1,true,0,false,false> (128-lane blocks, nt)",
             "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
             "traffic": head["traffic"], "traffic_source": pmc_traffic("sghmc_frozen", n)[1],
             "params": n, "working_set_note": "%.2f GB per frozen SGHMC launch: HBM-resident, cannot be served by the 256 MiB "
@@ -235,7 +262,11 @@ def usable_cores():
 
 
 def cpu_baseline(n, budget_s):
-    """The fused C oracle (kind "port") on the host cores: frozen SGHMC update, Philox noise, same n."""
+    """The CPU port (kind "port") on the host cores. `value` = the COMPLETE step (numpy/BLAS BNN gradient + fused C
+    update), samples/s like the GPU `value`. The update is the port a CPU user would run: one Philox call per quad and
+    single-precision Box-Muller (oracle_baseline_sghmc_frozen_step_f32). The PARITY oracle's update -- which evaluates
+    the f32 noise stream element by element through double-precision libm so that it matches the device stream to
+    4e-6 -- is timed next to it and labelled as what it is: a checker, ~20x slower, not a baseline."""
     from oracle import sgmcmc_oracle as O
     lib = O.load_c()
     cores = usable_cores()
@@ -244,29 +275,37 @@ def cpu_baseline(n, budget_s):
     st = O.CState(rng.standard_normal(n, dtype=np.float32) * 0.02, np.float32)
     st.minv[:] = rng.random(n, dtype=np.float32) * 1.5 + 0.5
     grad = rng.standard_normal(n, dtype=np.float32) * 0.1
-    O.c_sghmc_step(st, grad, 0.01, float(N_DATA), 0.05, False, None, seed=1, step=0)     # warm
+    fast = lambda state, g, step: O.baseline_sghmc_frozen_step(state, g, 0.01, float(N_DATA), 0.05, seed=1, step=step)
+    fast(st, grad, 0)                                                                   # warm
     t0 = time.perf_counter()
     steps = 0
-    while steps < 50 and (time.perf_counter() - t0) < budget_s:
-        O.c_sghmc_step(st, grad, 0.01, float(N_DATA), 0.05, False, None, seed=1, step=steps + 1)
+    while steps < 400 and (time.perf_counter() - t0) < budget_s / 4:
+        fast(st, grad, steps + 1)
         steps += 1
     dt = time.perf_counter() - t0
     # the same on ONE core (B(1) next to B(all))
     lib.oracle_set_num_threads(1)
     t1c = time.perf_counter()
     osteps = 0
-    while osteps < 5 and (time.perf_counter() - t1c) < budget_s / 4:
-        O.c_sghmc_step(st, grad, 0.01, float(N_DATA), 0.05, False, None, seed=1, step=100 + osteps)
+    while osteps < 20 and (time.perf_counter() - t1c) < budget_s / 6:
+        fast(st, grad, 1000 + osteps)
         osteps += 1
     odt = time.perf_counter() - t1c
     lib.oracle_set_num_threads(cores)
+    # the parity oracle's update with its checked noise stream (double-precision libm per element): NOT a baseline
+    t1p = time.perf_counter()
+    psteps = 0
+    while psteps < 10 and (time.perf_counter() - t1p) < budget_s / 6:
+        O.c_sghmc_step(st, grad, 0.01, float(N_DATA), 0.05, False, None, seed=1, step=2000 + psteps)
+        psteps += 1
+    pdt = time.perf_counter() - t1p
     # baseline A: op-by-op numpy mirror of the reference's unfused TF graph (injected noise drawn
     # by numpy, temporaries materialised, + the per-step copy-out of all parameters)
     ns = O.OpByOpState(st.theta, np.float32)
     frozen = st.minv.reshape(-1, 1)
     t1 = time.perf_counter()
     asteps = 0
-    while asteps < 10 and (time.perf_counter() - t1) < budget_s / 2:
+    while asteps < 10 and (time.perf_counter() - t1) < budget_s / 4:
         xi = rng.standard_normal(n, dtype=np.float32)
         O.opbyop_sghmc_step(ns, grad, 0.01, float(N_DATA), 0.05, xi, frozen_minv=frozen)
         _ = ns.theta.copy()
@@ -276,7 +315,7 @@ def cpu_baseline(n, budget_s):
     xi = rng.standard_normal(n, dtype=np.float32)
     t2 = time.perf_counter()
     isteps = 0
-    while isteps < 200 and (time.perf_counter() - t2) < budget_s / 4:
+    while isteps < 200 and (time.perf_counter() - t2) < budget_s / 6:
         O.c_sghmc_step(st, grad, 0.01, float(N_DATA), 0.05, False, xi)
         isteps += 1
     idt = time.perf_counter() - t2
@@ -300,30 +339,32 @@ def cpu_baseline(n, budget_s):
     except Exception:
         blas_limit = None
     fsteps, t3 = 0, time.perf_counter()
-    while fsteps < 22 and (time.perf_counter() - t3) < budget_s / 2:
+    while fsteps < 62 and (time.perf_counter() - t3) < budget_s / 2:
         if fsteps == 2:
             t3 = time.perf_counter()        # two untimed warm-up steps
         views = [fst.theta[offs[k]:offs[k + 1]].reshape(params[k].shape) for k in range(len(params))]
         _, grads = O.bnn_cost_and_grad(views, Xb, Yb, BATCH, N_DATA)
         gflat = np.concatenate([g.ravel() for g in grads])
-        O.c_sghmc_step(fst, gflat, 0.01, float(N_DATA), 0.05, False, None, seed=1, step=fsteps)
+        fast(fst, gflat, fsteps)
         fsteps += 1
     fsteps = max(fsteps - 2, 0)
     fdt = time.perf_counter() - t3
     if blas_limit is not None:
         blas_limit.restore_original_limits()
-    # `value` is the like-for-like figure: the COMPLETE step (gradient + update), samples/s. The update-only
-    # figures are sub-fields; the C port spends ~94 % of its update time in double-precision libm Box-Muller
-    # (compare update_only_steps_per_s with update_only_injected_noise_steps_per_s) -- a stated baseline, not a target.
     return {"value": round(fsteps / fdt, 3) if fsteps else None, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": "%d complete steps of the same workload (numpy/BLAS BNN forward + analytic backward at batch %d on "
-                      "%d threads, then the fused C oracle update of %d fp32 params with OpenMP on %d threads, Philox "
-                      "noise generated in the loop like the GPU kernel), %.1f s; TensorFlow is not installable here, so "
-                      "this port stands in for the reference's TF-CPU sampler" % (fsteps, BATCH, cores, n, cores, fdt),
+                      "%d threads, then the fused C update of %d fp32 params with OpenMP on %d threads: one Philox call per "
+                      "quad, single-precision Box-Muller, generated in the loop like the GPU kernel), %.1f s; TensorFlow is "
+                      "not installable here, so this port stands in for the reference's TF-CPU sampler" % (
+                          fsteps, BATCH, cores, n, cores, fdt),
             "update_only_steps_per_s": round(steps / dt, 3),
             "update_only_sample": "%d frozen SGHMC update steps (no BNN gradient), %.1f s" % (steps, dt),
             "update_only_one_core_steps_per_s": round(osteps / odt, 3) if osteps else None,
             "update_only_injected_noise_steps_per_s": round(isteps / idt, 3) if isteps else None,
+            "parity_oracle_update_steps_per_s": round(psteps / pdt, 3) if psteps else None,
+            "parity_oracle_note": "the parity oracle's update (f32 noise through double-precision libm, Philox recomputed per "
+                                  "element so that it reproduces the device stream): a checker, not a baseline -- rounds 1-2 "
+                                  "reported this figure as update_only_steps_per_s",
             "opbyop_numpy_update_steps_per_s": round(asteps / adt, 3) if asteps else None,
             "opbyop_note": "op-by-op numpy mirror of the reference's unfused TF graph (temporaries materialised, "
                            "+ the per-step copy-out of all parameters): the closest proxy of TF-CPU's update"}
@@ -426,26 +467,146 @@ def run_svgd(args, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+def self_launch(args):
+    """``bench.py --gpus N`` (N > 1) started WITHOUT a launcher: this process -- which has not touched the GPU and never
+    will -- starts N fresh ranks of this same script (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, rendezvous on 127.0.0.1), lets rank 0 write the ONE JSON line to the inherited stdout, and returns the
+    first non-zero exit code (the other ranks are then stopped). A wall-clock limit (--launch-timeout) stops ranks that
+    hang in a collective. The ``python -m torch.distributed.run ... bench.py --gpus N`` form keeps working: it sets
+    WORLD_SIZE, so this function is not entered."""
+    n = args.gpus
+    probe = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    probe.bind(("127.0.0.1", 0))
+    port = probe.getsockname()[1]
+    probe.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    ranks = []
+    for r in range(n):
+        ranks.append(subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0"),
+                                      stdout=None if r == 0 else sys.stderr, start_new_session=True))
+    deadline = time.monotonic() + args.launch_timeout
+    rc, why = 0, None
+    try:
+        while rc == 0 and any(p.poll() is None for p in ranks):
+            for r, p in enumerate(ranks):
+                code = p.poll()
+                if code not in (None, 0):
+                    rc, why = code, "rank %d exited with code %d" % (r, code)
+                    break
+            if rc == 0 and time.monotonic() > deadline:
+                rc, why = 124, "ranks still running after --launch-timeout %.0f s" % args.launch_timeout
+            time.sleep(0.05)
+        if rc == 0:
+            rc = next((p.returncode for p in ranks if p.returncode), 0)
+    finally:
+        for p in ranks:                                        # only the process groups started above, by their exact ids
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, 9)
+                except ProcessLookupError:
+                    pass
+        for p in ranks:
+            p.wait()
+    if why:
+        print("bench: %s; stopped the other ranks" % why, file=sys.stderr)
+    return rc if rc >= 0 else 128 - rc
+
+
+@torch.no_grad()
+def gemm_only_us(sampler, iters=60):
+    """The eight fp32 GEMMs of one step (three forward, five backward; same operands, shapes and output buffers as the
+    cost pipeline) replayed back to back from their own hipGraph: microseconds per step and their FLOP count."""
+    cost, params, gv = sampler.cost_fun, sampler.params, sampler.arena.grad_views
+    X = cost.x_placeholder.value
+    ws = cost._buffers(params, X.shape[0])
+    hs, ds = ws["h"], ws["d"]
+    L = (len(params) - 1) // 2 - 1                              # index of the single-output layer
+
+    def gemms():
+        h, flops = X, 0
+        for l in range(L):
+            torch.addmm(params[2 * l + 1], h, params[2 * l], out=hs[l])
+            flops += 2 * h.shape[0] * h.shape[1] * params[2 * l].shape[1]
+            h = hs[l]
+        for l in range(L - 1, -1, -1):
+            h_in = X if l == 0 else hs[l - 1]
+            if l > 0:
+                torch.mm(ds[l], params[2 * l].t(), out=ds[l - 1])
+                flops += 2 * ds[l].shape[0] * ds[l].shape[1] * params[2 * l].shape[0]
+            torch.mm(h_in.t(), ds[l], out=gv[2 * l])
+            flops += 2 * h_in.shape[1] * h_in.shape[0] * ds[l].shape[1]
+        return flops
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        flops = gemms()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        gemms()
+    for _ in range(5):
+        graph.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3, flops
+
+
+def cost_pipeline_us(sampler, iters=60):
+    """The captured cost/gradient pipeline alone (every graph segment, no update launch): microseconds per step."""
+    segments = sampler._graphs[("cost",)][0]
+    for _ in range(5):
+        for g, _sl in segments:
+            g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        for g, _sl in segments:
+            g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def launch_table(timer, n, bytes_per_param, moments_every):
+    """Per-launch records of a timed region: (step, lo, hi, microseconds, algorithmic bytes). A launch of a moments
+    step also carries the fused Welford update (+16 B per f32 parameter)."""
+    rows = []
+    for kev, tag in zip(timer.kevents, timer.tags):
+        step, lo, hi = tag if tag is not None else (None, 0, n)
+        with_mom = step is not None and moments_every and (step + 1) % moments_every == 0
+        rows.append((step, lo, hi, kev.elapsed_us(), (bytes_per_param + (16 if with_mom else 0)) * (hi - lo), bool(with_mom)))
+    return rows
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: spawn the ranks from here, BEFORE anything in this process touches the GPU
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists for the update path)")
     dev = torch.device("cuda", 0 if args.all_ranks_on_gpu0 else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))     # RCCL over xGMI
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
 
     if WORKLOADS[args.workload]["sampler"] == "svgd":
         return run_svgd(args, dev, rank, world, dist)
@@ -464,10 +625,12 @@ def main():
     kind = WORKLOADS[args.workload]["sampler"]
     sampler.sample_format = "view"                             # no D2H copy of 40 MB per sample
     sampler.use_hip_graph = not args.eager
+    sampler.overlap_update = args.overlap == "on" and not args.eager
+    sampler.collect_stats = "theta_sq"                         # the BNN loss head is the only consumer of the fused statistics
     n = sampler.arena.n
     from pysgmcmc_amd.profiling import UpdateKernelTimer
     # per-launch kernel timestamps of the update kernel; BENCH_BRACKET=1 also records a hipEventRecord pair around each call
-    timer = UpdateKernelTimer(bracket=os.environ.get("BENCH_BRACKET", "0") == "1")
+    timer = UpdateKernelTimer(bracket=os.environ.get("BENCH_BRACKET", "0") == "1", device=dev)
     sampler.kernel_timer = timer
     from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange
     moments = ChainMoments(n, dev)
@@ -488,9 +651,10 @@ def main():
 
     def one_step(i, every=None):
         every = args.moments_every if every is None else every
+        # K4 rides in the update launch of every `every`-th step (sgmcmc_step_opts_t.moments_*): no separate pass over theta
+        sampler.attach_moments(moments if every else None, every or 1)
         _, cost = next(sampler)
-        if (i + 1) % every == 0:
-            moments.update(sampler.arena.row("theta"))                 # K4 Welford, every chain
+        if every and sampler.n_iterations % every == 0:                # this step's update folded theta' into the moments
             trace[kept[0], 0:1].copy_(cost.reshape(1))
             torch.index_select(sampler.arena.row("theta"), 0, coords, out=trace[kept[0], 1:4])
             kept[0] += 1
@@ -532,12 +696,12 @@ def main():
         gc.freeze()
     # ---- phase 1: PRIME (untimed, independent of --warmup): burn-in, then every other code path once
     for i in range(PRIME_BURN_IN):
-        one_step(i, every=1 << 30)
+        one_step(i, every=0)
     assert not getattr(sampler, "_adapting", False), "prime phase must leave the chain in the frozen phase"
     for i in range(PRIME_FROZEN):
-        one_step(i, every=1)                                           # frozen step + K4 + trace append
+        one_step(i, every=1)                                           # frozen step with the fused K4 + trace append
     for i in range(PRIME_STEADY):
-        one_step(i, every=1 << 30)                                     # plain frozen steps until the device runs steadily
+        one_step(i, every=0)                                           # plain frozen steps until the device runs steadily
     if exchange is not None:
         try:
             rhat_start()
@@ -562,19 +726,22 @@ def main():
     frozen_phase = not getattr(sampler, "_adapting", False)
     kept[0] = 0
     # ---- phase 3: the timed region
-    timer.reserve(args.steps)
+    launches_per_step = len(sampler._graphs[("cost",)][0]) if sampler.use_hip_graph else 1
+    timer.reserve(args.steps * launches_per_step)
     timer.enabled = True
     periodic_exchange[0] = True
     fence()
     t0 = time.perf_counter()
     host_stamps = [t0]
     depth = args.max_queue_depth
+    step_end = []                                                      # the last update launch of every timed step
     for i in range(args.steps):
         one_step(i)
+        step_end.append(timer.kevents[-1])
         if depth and i >= depth:
             # host-side flow control: never run more than `depth` steps ahead of the device (the HIP runtime lets the
             # host queue ~750 steps and then stalls host AND device for milliseconds while it recycles its pools)
-            timer.kevents[i - depth].synchronize()
+            step_end[i - depth].synchronize()
         host_stamps.append(time.perf_counter())                        # host-side enqueue time of each step (no sync)
     if exchange is not None and exchange.pending:                      # inside the timed region
         rhat_finish()
@@ -593,20 +760,36 @@ def main():
         from pysgmcmc_amd.diagnostics.sampler_diagnostics import ess_across_ranks
         ess = ess_across_ranks(trace[:kept[0]].contiguous())          # all-gather of kept x 4 floats (untimed)
 
+    line = None
     if rank == 0:
         mode = "rsghmc" if kind == "rsghmc" else "%s_%s" % (kind, "frozen" if frozen_phase else "adapt")
         op_name = {"sghmc": "SghmcOp", "sgld": "SgldOp", "rsghmc": "RsghmcOp"}[kind]
         br = timer.bracket_us()                     # hipEventRecord bracket around the call (BENCH_BRACKET=1), else empty
         b_us = float(br.mean()) if br.size else None
         ev_us = timer.empty_bracket_us()
-        kern = timer.kernel_us()                    # the kernel's own start/stop timestamps, one pair per launch
-        k_us = float(kern.mean())
+        rows = launch_table(timer, n, BYTES_PER_PARAM[mode], args.moments_every)
+        plain = [r for r in rows if not r[5]] or rows                  # launches without the fused Welford update
+        k_us_sum = float(sum(r[3] for r in plain))
+        alg_plain = float(sum(r[4] for r in plain))
+        achieved = alg_plain / (k_us_sum * 1e-6) / 1e9
+        steps_plain = len({r[0] for r in plain}) if plain[0][0] is not None else len(plain)
+        k_us = k_us_sum / max(steps_plain, 1)                          # update time per step (sum of its launches)
         alg_bytes = BYTES_PER_PARAM[mode] * n
-        achieved = alg_bytes / (k_us * 1e-6) / 1e9
         big = alg_bytes > (640 << 20)
         traffic, traffic_src = pmc_traffic(mode, n, stats_variant=True)   # the pipeline launches the STATS variant
-        # per-step device time: from the end of one step's update kernel to the end of the next one's
-        step_ms = timer.step_us() * 1e-3 if len(timer.kevents) > 1 else None
+        # per-step device time: from the end of one step's last update launch to the end of the next one's
+        step_ms = np.array([step_end[j].us_until(step_end[j + 1]) for j in range(len(step_end) - 1)]) * 1e-3 \
+            if len(step_end) > 1 else None
+        slices = None
+        if launches_per_step > 1:
+            slices = []
+            for lo, hi in sorted({(r[1], r[2]) for r in plain}, reverse=True):
+                sel = [r for r in plain if (r[1], r[2]) == (lo, hi)]
+                us = float(np.mean([r[3] for r in sel]))
+                slices.append({"elements": [lo, hi], "params": hi - lo, "us_per_launch_mean": round(us, 2),
+                               "GBps": round(BYTES_PER_PARAM[mode] * (hi - lo) / us / 1e3, 1),
+                               "stream": "main" if lo == 0 else "side (under the backward GEMMs)"})
+        with_mom = [r for r in rows if r[5]]
         line = {
             "metric": "MCMC samples/sec + fused-update HBM GB/s (% roofline), BNN 10M params",
             "value": round(world * args.steps / elapsed, 2),
@@ -628,35 +811,42 @@ def main():
                                        n, BATCH),
                        "params": n, "batch": BATCH, "chains": world,
                        "rhat_every": rhat_every if world > 1 else None,
-                       "moments_every": args.moments_every, "hip_graph": bool(sampler.use_hip_graph),
+                       "moments_every": args.moments_every, "moments": "fused into the update launch (K4 in K1)",
+                       "hip_graph": bool(sampler.use_hip_graph),
+                       "update_overlap": "layer slices on a side stream under the backward GEMMs (%d launches per step)" %
+                                         launches_per_step if launches_per_step > 1 else "off: one launch after the backward pass",
                        "gemm_tuning": not args.no_gemm_tuning,
                        "prime_steps": {"burn_in": PRIME_BURN_IN, "frozen": PRIME_FROZEN + PRIME_STEADY},
                        "max_queue_depth": args.max_queue_depth,
-                       "launch": kernels.get_launch_config()},
-            # template args: <Op<float, ADAPT, INJECT>, quads per lane, NT, STATS, LOOP>
-            "roofline": {"bound": "hbm", "kernel": "stream_quads_vec<%s<float,%s,false>,1,%s,true,false>" % (
+                       "launch": kernels.get_launch_config(), "kernel_source_hash": kernel_source_hash()},
+            # template args: <Op<float, ADAPT, INJECT>, quads per lane, NT, STATS (2 = sum theta^2 only), LOOP, MOMENTS>
+            "roofline": {"bound": "hbm", "kernel": "stream_quads_vec<%s<float,%s,false>,1,%s,2,false,false>" % (
                              op_name, "false" if frozen_phase else "true", "true" if big else "false"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "us_per_launch_mean": round(k_us, 2), "us_per_launch_median": round(float(np.median(kern)), 2),
-                         "us_per_launch_max": round(float(kern.max()), 2),
-                         "launches_timed": len(timer.kevents),
+                         "algorithmic_bytes_per_launch": alg_bytes if launches_per_step == 1 else None,
+                         "algorithmic_bytes_per_step": alg_bytes,
+                         "us_per_step_mean": round(k_us, 2),
+                         "launches_timed": len(plain), "launches_per_step": launches_per_step,
+                         "slices": slices,
+                         "with_fused_moments": None if not with_mom else {
+                             "launches": len(with_mom), "bytes_per_param": BYTES_PER_PARAM[mode] + 16,
+                             "us_per_step_mean": round(sum(r[3] for r in with_mom) / len({r[0] for r in with_mom}), 2),
+                             "GBps": round(sum(r[4] for r in with_mom) / sum(r[3] for r in with_mom) / 1e3, 1)},
                          # the conservative figure of round 1: hipEventRecord pair AROUND the call
                          "bracket": None if b_us is None else {
                              "us_per_launch_mean": round(b_us, 2), "us_per_launch_median": round(float(np.median(br)), 2),
-                             "us_empty_event_pair": round(ev_us, 2),
-                             "achieved": round(alg_bytes / (b_us * 1e-6) / 1e9, 1),
-                             "frac": round(alg_bytes / (b_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
-                         "cache_note": ("%.0f MB per launch: HBM-resident (larger than the 256 MiB Infinity Cache)" if big else
-                                        "%.0f MB per launch fits the 256 MiB Infinity Cache: part of this rate is cache-"
-                                        "assisted (it exceeds the 6.29 TB/s HBM copy ceiling of MI355X_MICROARCH.md); the "
-                                        "HBM-resident figure is `roofline_hbm_resident`") % (alg_bytes / 1e6),
-                         "timing": "every launch of the timed region carries a HIP event pair that receives the kernel's own "
-                                   "start/stop timestamps (hipExtLaunchKernel; the duration rocprofv3 reports, cf. "
-                                   "profiles/r02_bench10m_kernel_stats.csv), in-pipeline (after the GEMMs evicted part "
-                                   "of the state from the Infinity Cache); `bracket` = hipEventRecord pair around the call"},
+                             "us_empty_event_pair": round(ev_us, 2)},
+                         "cache_note": ("%.0f MB per step: HBM-resident (larger than the 256 MiB Infinity Cache)" if big else
+                                        "%.0f MB per step fits the 256 MiB Infinity Cache: part of this rate is cache-"
+                                        "assisted; the HBM-resident figure is `roofline_hbm_resident`") % (alg_bytes / 1e6),
+                         "timing": "every update launch of the timed region carries a HIP event pair that receives the kernel's "
+                                   "own start/stop timestamps (hipExtLaunchKernel; the duration rocprofv3 reports); achieved = "
+                                   "algorithmic bytes of the timed launches / the sum of their durations" + (
+                                       " -- the slices run CONCURRENTLY with the backward GEMMs, so this is the contended "
+                                       "rate; `roofline_unoverlapped` is the same kernel alone in the pipeline"
+                                       if launches_per_step > 1 else "")},
         }
         if exchange is not None:
             timed = ex_events[prime_rhat_events:]
@@ -676,7 +866,7 @@ def main():
         if ess is not None:
             line["ess"] = {"kept_per_chain": kept[0], "cost": ess[0], "theta_coords": ess[1:]}
     if exchange is not None:
-        # the collective alone: blocking all-reduce of the same 3P-float payload, after the timed region (all ranks)
+        # the collective alone: blocking collective of the same payload, after the timed region (all ranks)
         torch.cuda.synchronize()
         dist.barrier()
         ts = []
@@ -693,19 +883,62 @@ def main():
             ts.append(e0.elapsed_time(e1))
         if rank == 0:
             line["rccl"]["collective_alone_ms"] = round(float(np.median(ts[1:])), 3)
-    if rank == 0:
-        if not args.no_update_only and kind == "sghmc":
-            # identical code path at every N (SCALE N = 1 equals BENCH): runs on rank 0 after the timed region
-            line["update_only"] = update_only(sampler)
-            del moments, trace
-            line["roofline_hbm_resident"] = hbm_resident_roofline(dev)
-        if world == 1 and not args.no_cpu_baseline and kind == "sghmc":
-            line["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
-        print(json.dumps(line))
-        sys.stdout.flush()
     if dist is not None:
+        # the job ends HERE for every rank: rank 0's extra legs below run with no process group alive, so no rank sits
+        # in a collective (or its watchdog) while they take their seconds
+        torch.cuda.synchronize()
         dist.barrier()
         dist.destroy_process_group()
+    if rank != 0:
+        return
+    if kind == "sghmc" and sampler.use_hip_graph:
+        # ---- un-overlapped figures + where the step time goes (identical code path at every N: SCALE N = 1 equals BENCH)
+        legs = max(min(args.steps, 60), 20)
+        sampler.attach_moments(None)
+        if launches_per_step > 1:
+            sampler.overlap_update = False
+            sampler._graphs.clear()
+            for _ in range(6):
+                next(sampler)
+        t2 = UpdateKernelTimer(reserve=legs, device=dev)
+        sampler.kernel_timer = t2
+        t2.enabled = True
+        for _ in range(legs):
+            next(sampler)
+        torch.cuda.synchronize()
+        t2.enabled = False
+        sampler.kernel_timer = None
+        u_us = t2.kernel_us()
+        serial_step_us = float(np.median(t2.step_us()))
+        un = BYTES_PER_PARAM[mode] * n / (float(u_us.mean()) * 1e-6) / 1e9
+        line["roofline_unoverlapped"] = {
+            "bound": "hbm", "achieved": round(un, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(un / HBM_PEAK_GBS, 4),
+            "us_per_launch_mean": round(float(u_us.mean()), 2), "us_per_launch_median": round(float(np.median(u_us)), 2),
+            "launches_timed": int(u_us.size), "step_ms_median": round(serial_step_us * 1e-3, 4),
+            "note": "the same chain stepped with ONE update launch after the backward pass (no overlap), %d steps after the "
+                    "timed region: the kernel alone in the pipeline, as rounds 1-2 reported `roofline`" % legs}
+        g_us, g_flops = gemm_only_us(sampler)
+        c_us = cost_pipeline_us(sampler)
+        meas_us = float(np.median(step_ms)) * 1e3 if step_ms is not None else None
+        line["step_breakdown_us"] = {
+            "gemm": round(g_us, 1), "small_launches": round(c_us - g_us, 1), "update": round(float(u_us.mean()), 1),
+            "serial_sum": round(c_us + float(u_us.mean()), 1), "serial_step_measured": round(serial_step_us, 1),
+            "timed_region_step_median": None if meas_us is None else round(meas_us, 1),
+            "hidden_by_overlap": None if meas_us is None else round(serial_step_us - meas_us, 1),
+            "gemm_tflops": round(g_flops / (g_us * 1e-6) / 1e12, 1),
+            "gemm_frac_of_fp32_mfma_peak": round(g_flops / (g_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3),
+            "gemm_flop_per_step": int(g_flops),
+            "note": "gemm = the step's eight fp32 library GEMMs replayed alone from a hipGraph; small_launches = the captured "
+                    "cost pipeline alone minus gemm (tanh, tanh-backward + bias gradient, loss head, window gather ...); "
+                    "update = the fused update launched once after the backward pass"}
+    if not args.no_update_only and kind == "sghmc":
+        line["update_only"] = update_only(sampler)
+        del moments, trace
+        line["roofline_hbm_resident"] = hbm_resident_roofline(dev)
+    if world == 1 and not args.no_cpu_baseline and kind == "sghmc":
+        line["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
+    print(json.dumps(line))
+    sys.stdout.flush()
 
 
 if __name__ == "__main__":

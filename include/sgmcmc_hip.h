@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SGMCMC_ABI_VERSION 2
+#define SGMCMC_ABI_VERSION 3
 
 #define SGMCMC_EINVAL   (-1)   /* null/invalid argument */
 #define SGMCMC_ENODEV   (-2)   /* no HIP device / not gfx950 code object */
@@ -83,6 +83,49 @@ int sgmcmc_event_destroy(void *event);
 int sgmcmc_event_elapsed_ms(void *start_event, void *stop_event, float *ms_out);
 int sgmcmc_event_synchronize(void *event);      /* host waits until the event has completed */
 
+/* Optional extras of ONE step call (K1-K3); NULL = none of them. Unlike sgmcmc_launch_t these change WHAT the launch
+ * does (never the update arithmetic of an element).
+ *   first_element:  index of theta[0] within the chain's whole parameter vector (a multiple of 4). The Philox counter of
+ *                element i is (first_element + i) / 4, so a step issued as several launches over consecutive SLICES of
+ *                the arena -- each as soon as its part of the gradient exists, e.g. layer by layer on a second stream
+ *                under the remaining backward GEMMs -- gives exactly the chain the single launch gives.
+ *   stats_record_base / stats_record_total: with a stats workspace, block b of this launch writes statistics record
+ *                stats_record_base + b and the workspace header is set to stats_record_total records (0 = this launch's
+ *                grid): the slices of one step share one workspace. sgmcmc_step_launch_blocks() gives a launch's grid.
+ *   stats_select:   0 = every statistic the operator produces; SGMCMC_STATS_THETA_SQ = only sum theta'^2 (the one the
+ *                BNN loss head consumes; the other three are written as 0 and cost no reduction work).
+ *   flags:       SGMCMC_STEP_HBM_RESIDENT: the launch is part of a working set larger than the Infinity Cache even if
+ *                this slice alone is not (the auto geometry then picks what it picks for the whole arena).
+ *                SGMCMC_STEP_SKIP_MINV_STORE (adapt = 1 only): do not write minv this step (44 instead of 48 B/param
+ *                for K1). minv is only CONSUMED by frozen steps, which read what the LAST burn-in step wrote, so a
+ *                caller may set this on every burn-in step but the last; minv then holds stale values in between.
+ *   moments_mean / moments_m2 / moments_count: K4 fused into the step -- theta' is folded into the chain's Welford
+ *                moments (arrays of n elements aligned with theta, count includes this sample) in the same pass:
+ *                +16 B/param on that launch instead of a separate 20 B/param pass. Same arithmetic as
+ *                sgmcmc_moments_update_* bit for bit (paths without a fused form run that kernel after the step).
+ *   scalars_dev: NULL, or a DEVICE block of 5 elements of the dtype filled by sgmcmc_{sghmc,sgld,rsghmc}_scalars_*;
+ *                the kernel then takes its derived scalars (stepsize etc.) from there instead of the by-value
+ *                arguments. A hipGraph replays identical arguments: a captured step follows a stepsize SCHEDULE
+ *                through this block (one graph per phase instead of one per stepsize).                           */
+#define SGMCMC_STATS_THETA_SQ        1
+#define SGMCMC_STEP_HBM_RESIDENT     1u
+#define SGMCMC_STEP_SKIP_MINV_STORE  2u
+typedef struct sgmcmc_step_opts {
+    uint64_t first_element;
+    uint32_t stats_record_base;
+    uint32_t stats_record_total;
+    int stats_select;
+    unsigned flags;
+    void *moments_mean;
+    void *moments_m2;
+    uint64_t moments_count;
+    const void *scalars_dev;
+} sgmcmc_step_opts_t;
+
+/* Grid (number of blocks = statistics records) a vector-path step launch of n elements uses under `launch`
+ * (block_threads must be explicit there: 64..256), or 0 on invalid arguments.                                   */
+size_t sgmcmc_step_launch_blocks(size_t n, const sgmcmc_launch_t *launch);
+
 /* K1 -- fused SGHMC step. Replaces the op chain pysgmcmc/samplers/sghmc.py:165-251
  * (+ constants :111-117) and the burn-in switch pysgmcmc/samplers/base_classes.py:432-456.
  *   adapt = 1  burn-in step (is_burning_in): reads theta,V,grad,tau,g,v_hat; writes
@@ -99,7 +142,7 @@ int sgmcmc_event_synchronize(void *event);      /* host waits until the event ha
  *   step: the sampler's n_iterations at the time of the call.
  *   stats_ws:  NULL, or a device workspace of sgmcmc_step_stats_workspace_bytes(n) bytes: the
  *              kernel also reduces, from the values it already holds in registers (wave shuffles
- *              -> LDS -> ONE 32-byte partial per block in stats_ws), the sums {theta'^2, V'^2
+ *              -> LDS -> ONE 32-byte record per block in stats_ws, block-major), the sums {theta'^2, V'^2
  *              (p'^2; 0 for SGLD), minv, minv^2}. sgmcmc_step_stats_finish() then adds the
  *              partials in a fixed order into 4 doubles. Bit-reproducible for a given launch
  *              geometry; costs no extra pass over HBM.
@@ -110,13 +153,26 @@ int sgmcmc_sghmc_step_f32(float *theta, float *V, const float *grad,
                           float *tau, float *g, float *v_hat, float *minv, float *r,
                           size_t n, float eps, float scale_grad, float mdecay, float grad_decay, int adapt,
                           const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
+                          void *stats_ws, const sgmcmc_step_opts_t *opts, const sgmcmc_launch_t *launch,
+                          sgmcmc_stream_t stream);
 int sgmcmc_sghmc_step_f64(double *theta, double *V, const double *grad,
                           double *tau, double *g, double *v_hat, double *minv, double *r,
                           size_t n, double eps, double scale_grad, double mdecay, double grad_decay, int adapt,
                           const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
+                          void *stats_ws, const sgmcmc_step_opts_t *opts, const sgmcmc_launch_t *launch,
+                          sgmcmc_stream_t stream);
 
+/* Host-derived scalars of a step as a DEVICE block (sgmcmc_step_opts_t.scalars_dev): derived exactly as the step call
+ * derives them from its by-value arguments, stored by a 1-thread kernel on `stream`.                              */
+int sgmcmc_sghmc_scalars_f32(float eps, float scale_grad, float mdecay, void *scalars_dev, sgmcmc_stream_t stream);
+int sgmcmc_sghmc_scalars_f64(double eps, double scale_grad, double mdecay, void *scalars_dev, sgmcmc_stream_t stream);
+int sgmcmc_sgld_scalars_f32(float eps, float A, float scale_grad, void *scalars_dev, sgmcmc_stream_t stream);
+int sgmcmc_sgld_scalars_f64(double eps, double A, double scale_grad, void *scalars_dev, sgmcmc_stream_t stream);
+int sgmcmc_rsghmc_scalars_f32(float eps, float mass, float c, float D, float b_hat, void *scalars_dev, sgmcmc_stream_t stream);
+int sgmcmc_rsghmc_scalars_f64(double eps, double mass, double c, double D, double b_hat, void *scalars_dev,
+                              sgmcmc_stream_t stream);
+
+/* Workspace: 32-byte header {uint64 record count} + one 32-byte record {4 doubles} per block.                  */
 size_t sgmcmc_step_stats_workspace_bytes(size_t n);
 /* K7 -- stats_out[0..3] (device doubles) = fixed-order sum of the per-block partials a step kernel left
  * in stats_ws. One 1024-lane block.                                                               */
@@ -129,12 +185,14 @@ int sgmcmc_sgld_step_f32(float *theta, const float *grad,
                          float *tau, float *g, float *v_hat, float *minv, float *r,
                          size_t n, float eps, float A, float scale_grad, float grad_decay, int adapt,
                          const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
+                          void *stats_ws, const sgmcmc_step_opts_t *opts, const sgmcmc_launch_t *launch,
+                          sgmcmc_stream_t stream);
 int sgmcmc_sgld_step_f64(double *theta, const double *grad,
                          double *tau, double *g, double *v_hat, double *minv, double *r,
                          size_t n, double eps, double A, double scale_grad, double grad_decay, int adapt,
                          const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
+                          void *stats_ws, const sgmcmc_step_opts_t *opts, const sgmcmc_launch_t *launch,
+                          sgmcmc_stream_t stream);
 
 /* K3 -- fused relativistic SGHMC step, per element. Replaces
  * pysgmcmc/samplers/relativistic_sghmc.py:120-140. grad_cost = d cost / d theta
@@ -143,11 +201,13 @@ int sgmcmc_sgld_step_f64(double *theta, const double *grad,
 int sgmcmc_rsghmc_step_f32(float *theta, float *p, const float *grad_cost, size_t n,
                            float eps, float mass, float c, float D, float b_hat, float grad_decay,
                            const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
+                          void *stats_ws, const sgmcmc_step_opts_t *opts, const sgmcmc_launch_t *launch,
+                          sgmcmc_stream_t stream);
 int sgmcmc_rsghmc_step_f64(double *theta, double *p, const double *grad_cost, size_t n,
                            double eps, double mass, double c, double D, double b_hat, double grad_decay,
                            const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream);
+                          void *stats_ws, const sgmcmc_step_opts_t *opts, const sgmcmc_launch_t *launch,
+                          sgmcmc_stream_t stream);
 
 /* K5 -- write the N(0,1) stream itself: out[i] = xi(seed, step, i). Replaces
  * tf.random_normal in pysgmcmc/samplers/base_classes.py:218-220 for callers that

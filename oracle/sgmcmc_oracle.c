@@ -163,6 +163,51 @@ static inline double philox_normal_at_f64(uint64_t seed, uint64_t step, uint64_t
 #undef RSQRT
 #undef RPOW
 
+/* ------------------------------------------------- CPU baseline (not the parity oracle) */
+
+/* bench.py's `cpu_baseline` leg ONLY -- never used as a checker. The parity functions above evaluate the f32 noise
+ * stream element by element through double-precision libm (they must reproduce the device stream to 4e-6); as a
+ * TIMED baseline that spends ~94 % of the update in log/sin/cos and recomputes Philox four times per quad. This is
+ * the update a CPU port would actually run: frozen SGHMC step (sghmc.py:211-251 with fed minv), one Philox call per
+ * quad, single-precision Box-Muller (logf, sinf/cosf), same update arithmetic per element. Its noise differs from the
+ * parity stream in the last bits, so it is not compared with anything.                                            */
+int oracle_baseline_sghmc_frozen_step_f32(float *theta, float *V, const float *grad, const float *minv, size_t n,
+                                          float eps, float scale_grad, float mdecay, float grad_decay,
+                                          uint64_t seed, uint64_t step)
+{
+    sghmc_consts_t_f32 k = sghmc_consts_f32(eps, scale_grad, mdecay);
+    long long q, nq = (long long)((n + 3) / 4);
+    const float two_pi = 6.283185307179586f;
+#pragma omp parallel for schedule(static)
+    for (q = 0; q < nq; ++q) {
+        uint32_t x[4];
+        float z[4];
+        int pr, j;
+        philox_quad(seed, step, (uint64_t)q, x);
+        for (pr = 0; pr < 2; ++pr) {
+            float u = fmaf((float)x[2 * pr], 0x1p-32f, 0x1p-33f);
+            float rev = fmaf((float)x[2 * pr + 1], 0x1p-32f, 0x1p-33f);
+            float s = sqrtf(-2.0f * logf(u));
+            float ang = two_pi * rev;
+            z[2 * pr] = s * sinf(ang);
+            z[2 * pr + 1] = s * cosf(ang);
+        }
+        for (j = 0; j < 4; ++j) {
+            size_t i = 4 * (size_t)q + (size_t)j;
+            if (i >= n) break;
+            float gr = (grad_decay != 0.0f) ? grad[i] + grad_decay * theta[i] : grad[i];
+            float mi = minv[i];
+            float noise_scale = (k.c1 * mi - (k.c3 * (mi * mi)) * 0.0f) - k.e4;
+            float sigma = sqrtf((noise_scale > 1e-16f) ? noise_scale : 1e-16f);
+            float v0 = V[i];
+            float v1 = v0 + (((((-k.e2) * mi) * gr) - k.mdecay * v0) + sigma * z[j]);
+            V[i] = v1;
+            theta[i] = theta[i] + v1;
+        }
+    }
+    return 0;
+}
+
 /* ----------------------------------------------------------------- helpers */
 
 void oracle_set_num_threads(int n)

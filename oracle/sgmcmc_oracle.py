@@ -155,6 +155,20 @@ def c_sghmc_step(st, grad, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step
     assert rc == 0
 
 
+def baseline_sghmc_frozen_step(st, grad, eps, scale_grad, mdecay, seed=0, step=0, grad_decay=0.0):
+    """bench.py's CPU-baseline update (f32 only): frozen SGHMC step with ONE Philox call per quad and single-precision
+    Box-Muller -- what a CPU port would run. NOT a parity function (its noise differs from the checked stream in the last
+    bits); see ``oracle_baseline_sghmc_frozen_step_f32`` in sgmcmc_oracle.c."""
+    lib = load_c()
+    assert st.dtype == np.float32
+    grad = np.ascontiguousarray(grad, dtype=np.float32).ravel()
+    f = lib.oracle_baseline_sghmc_frozen_step_f32
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t] + [ctypes.c_float] * 4 + [ctypes.c_uint64] * 2
+    rc = f(_p(st.theta), _p(st.V), _p(grad), _p(st.minv), st.n, eps, scale_grad, mdecay, grad_decay, seed, step)
+    assert rc == 0
+
+
 def c_sgld_step(st, grad, eps, A, scale_grad, adapt, xi=None, seed=0, step=0, grad_decay=0.0):
     lib = load_c()
     grad = np.ascontiguousarray(grad, dtype=st.dtype).ravel()

@@ -26,7 +26,7 @@ def lib_path():
 def build(force=False):
     """Compile ``csrc/libsgmcmc_hip.so`` for gfx950 with hipcc (no GPU needed)."""
     import subprocess
-    deps = [os.path.join(_CSRC, f) for f in ("sgmcmc_kernels.hip", "sgmcmc_bnn_fused.hip", "sgmcmc_svgd.hip", "sgmcmc_device.hpp",
+    deps = [os.path.join(_CSRC, f) for f in ("sgmcmc_kernels.hip", "sgmcmc_sghmc.hip", "sgmcmc_sgld.hip", "sgmcmc_rsghmc.hip", "sgmcmc_stream.hpp", "sgmcmc_bnn_fused.hip", "sgmcmc_svgd.hip", "sgmcmc_device.hpp",
                                              "sgmcmc_host.hpp")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "sgmcmc_hip.h"))
     stale = (not os.path.exists(_LIB_PATH)
@@ -37,7 +37,7 @@ def build(force=False):
 
 
 _lib = None
-ABI_VERSION = 2               # SGMCMC_ABI_VERSION of include/sgmcmc_hip.h
+ABI_VERSION = 3               # SGMCMC_ABI_VERSION of include/sgmcmc_hip.h
 
 _u64 = ctypes.c_uint64
 _sz = ctypes.c_size_t
@@ -54,6 +54,20 @@ class LaunchStruct(ctypes.Structure):
 _lp = ctypes.POINTER(LaunchStruct)
 
 
+class StepOptsStruct(ctypes.Structure):
+    """``sgmcmc_step_opts_t``: optional extras of one step call (slices, statistics selection, fused moments, ...)."""
+    _fields_ = [("first_element", ctypes.c_uint64), ("stats_record_base", ctypes.c_uint32),
+                ("stats_record_total", ctypes.c_uint32), ("stats_select", ctypes.c_int), ("flags", ctypes.c_uint),
+                ("moments_mean", ctypes.c_void_p), ("moments_m2", ctypes.c_void_p), ("moments_count", ctypes.c_uint64),
+                ("scalars_dev", ctypes.c_void_p)]
+
+
+_op = ctypes.POINTER(StepOptsStruct)
+STATS_THETA_SQ = 1
+STEP_HBM_RESIDENT = 1
+STEP_SKIP_MINV_STORE = 2
+
+
 def _declare(lib):
     lib.sgmcmc_abi_version.restype = _ci
     lib.sgmcmc_last_error.restype = ctypes.c_char_p
@@ -68,13 +82,22 @@ def _declare(lib):
     lib.sgmcmc_event_synchronize.restype = _ci
     for sfx, real in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
         f = getattr(lib, "sgmcmc_sghmc_step_" + sfx)
-        f.argtypes = [_vp] * 8 + [_sz, real, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp, _lp, _vp]
+        f.argtypes = [_vp] * 8 + [_sz, real, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp, _op, _lp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_sgld_step_" + sfx)
-        f.argtypes = [_vp] * 7 + [_sz, real, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp, _lp, _vp]
+        f.argtypes = [_vp] * 7 + [_sz, real, real, real, real, _ci, _vp, _u64, _u64, _vp, _vp, _op, _lp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_rsghmc_step_" + sfx)
-        f.argtypes = [_vp] * 3 + [_sz, real, real, real, real, real, real, _vp, _u64, _u64, _vp, _vp, _lp, _vp]
+        f.argtypes = [_vp] * 3 + [_sz, real, real, real, real, real, real, _vp, _u64, _u64, _vp, _vp, _op, _lp, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_sghmc_scalars_" + sfx)
+        f.argtypes = [real, real, real, _vp, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_sgld_scalars_" + sfx)
+        f.argtypes = [real, real, real, _vp, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_rsghmc_scalars_" + sfx)
+        f.argtypes = [real, real, real, real, real, _vp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_philox_normal_" + sfx)
         f.argtypes = [_vp, _sz, _u64, _u64, _vp, _lp, _vp]
@@ -136,6 +159,8 @@ def _declare(lib):
     lib.sgmcmc_svgd_max_particles.restype = _ci
     lib.sgmcmc_step_stats_workspace_bytes.argtypes = [_sz]
     lib.sgmcmc_step_stats_workspace_bytes.restype = _sz
+    lib.sgmcmc_step_launch_blocks.argtypes = [_sz, _lp]
+    lib.sgmcmc_step_launch_blocks.restype = _sz
     lib.sgmcmc_step_stats_finish.argtypes = [_vp, _vp, _vp]
     lib.sgmcmc_step_stats_finish.restype = _ci
 

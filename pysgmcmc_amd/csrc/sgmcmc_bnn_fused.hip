@@ -96,14 +96,14 @@ __device__ __forceinline__ double run_update(Op &op, size_t n_params)
         op.template load_vec<false>(q, R);
         op.compute(q, R);
         op.template store_vec<false>(q, R);
-        op.accumulate(R, 4, acc);
+        op.template accumulate<true>(R, 4, acc);
     }
     if (tail && threadIdx.x == blockDim.x - 1) {
         typename Op::Regs R;
         op.load_part_(nq_full, tail, R);
         op.compute(nq_full, R);
         op.store_part_(nq_full, tail, R);
-        op.accumulate(R, tail, acc);
+        op.template accumulate<true>(R, tail, acc);
     }
     return acc[0];                                        // this lane's share of sum(theta'^2)
 }

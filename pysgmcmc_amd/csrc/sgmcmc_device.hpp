@@ -82,6 +82,9 @@ __device__ __forceinline__ void store_part(T *__restrict__ p, size_t q, int cnt,
 struct NoiseKey {
     uint32_t k0, k1, s0, s1;
     const uint64_t *step_dev;
+    // quad index of the launch's first element within the chain's parameter vector: a launch over a SLICE
+    // [first, first + n) of the arena draws the quads the single launch over the whole arena would draw
+    uint64_t q0 = 0;
     __device__ __forceinline__ void resolve()
     {
         if (step_dev) {
@@ -110,7 +113,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 __device__ __forceinline__ void philox_quad(const NoiseKey &nk, size_t q, uint32_t (&x)[4])
 {
-    philox4x32_10(nk.s0, nk.s1, (uint32_t)q, (uint32_t)((uint64_t)q >> 32), nk.k0, nk.k1, x);
+    const uint64_t gq = (uint64_t)q + nk.q0;
+    philox4x32_10(nk.s0, nk.s1, (uint32_t)gq, (uint32_t)(gq >> 32), nk.k0, nk.k1, x);
 }
 
 // 4 standard normals for quad q. f32: hardware transcendentals
@@ -194,9 +198,18 @@ struct SghmcOp {
     T grad_decay;                  // gradient term grad_decay * theta added in registers (0 = off)
     NoiseKey nk;
     double *stats_part;            // nullable: per-block partials of {sum theta'^2, sum V'^2, sum minv, sum minv^2}
+    bool skip_minv = false;        // ADAPT: do not write minv this step (44 instead of 48 B/param; see sgmcmc_step_opts_t)
+    // nullable: DEVICE copy of {e2, c1, c3, e4, mdecay} that overrides the by-value scalars (a hipGraph-captured
+    // launch replays its arguments; a scheduled stepsize reaches it through this block, sgmcmc_sghmc_scalars_*)
+    const T *scalars_dev = nullptr;
     static constexpr unsigned stats_mask = 0xfu;     // which of the 4 statistics this operator produces
-    __device__ __forceinline__ void prepare() { nk.resolve(); }
-    template <typename RegsT>
+    __device__ __forceinline__ void prepare()
+    {
+        nk.resolve();
+        if (scalars_dev) { e2 = scalars_dev[0]; c1 = scalars_dev[1]; c3 = scalars_dev[2]; e4 = scalars_dev[3]; mdecay = scalars_dev[4]; }
+    }
+    // TSQ_ONLY: only sum theta'^2 (the one statistic the BNN loss head consumes)
+    template <bool TSQ_ONLY, typename RegsT>
     __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
     {
         // the quad's 4 terms are summed in T (4 adds), the running totals in double
@@ -204,9 +217,11 @@ struct SghmcOp {
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (j < cnt) {
             T th = R.th[j], v = R.v[j], mi = R.mi[j];
-            s0 += th * th; s1 += v * v; s2 += mi; s3 += mi * mi;
+            s0 += th * th;
+            if constexpr (!TSQ_ONLY) { s1 += v * v; s2 += mi; s3 += mi * mi; }
         }
-        acc[0] += (double)s0; acc[1] += (double)s1; acc[2] += (double)s2; acc[3] += (double)s3;
+        acc[0] += (double)s0;
+        if constexpr (!TSQ_ONLY) { acc[1] += (double)s1; acc[2] += (double)s2; acc[3] += (double)s3; }
     }
     struct Regs { T th[4], v[4], gr[4], mi[4], tau[4], g[4], vh[4], rr[4], z[4]; };
 
@@ -247,7 +262,7 @@ struct SghmcOp {
         store_quad<NT>(theta, q, R.th); store_quad<NT>(V, q, R.v);
         if (ADAPT) {
             store_quad<NT>(tau, q, R.tau); store_quad<NT>(g, q, R.g); store_quad<NT>(vh, q, R.vh);
-            store_quad<NT>(minv, q, R.mi);
+            if (!skip_minv) store_quad<NT>(minv, q, R.mi);
             if (r) store_quad<NT>(r, q, R.rr);
         }
     }
@@ -256,7 +271,7 @@ struct SghmcOp {
         store_part(theta, q, cnt, R.th); store_part(V, q, cnt, R.v);
         if (ADAPT) {
             store_part(tau, q, cnt, R.tau); store_part(g, q, cnt, R.g); store_part(vh, q, cnt, R.vh);
-            store_part(minv, q, cnt, R.mi);
+            if (!skip_minv) store_part(minv, q, cnt, R.mi);
             if (r) store_part(r, q, cnt, R.rr);
         }
     }
@@ -270,18 +285,26 @@ struct SgldOp {
     T grad_decay;
     NoiseKey nk;
     double *stats_part;
+    bool skip_minv = false;
+    const T *scalars_dev = nullptr;       // nullable device copy of {eps, A, a_eff, two_eps, sg_den} (see SghmcOp)
     static constexpr unsigned stats_mask = 0xdu;     // no momentum: {theta'^2, -, minv, minv^2}
-    __device__ __forceinline__ void prepare() { nk.resolve(); }
-    template <typename RegsT>
+    __device__ __forceinline__ void prepare()
+    {
+        nk.resolve();
+        if (scalars_dev) { eps = scalars_dev[0]; A = scalars_dev[1]; a_eff = scalars_dev[2]; two_eps = scalars_dev[3]; sg_den = scalars_dev[4]; }
+    }
+    template <bool TSQ_ONLY, typename RegsT>
     __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
     {
         T s0 = T(0), s2 = T(0), s3 = T(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (j < cnt) {
             T th = R.th[j], mi = R.mi[j];
-            s0 += th * th; s2 += mi; s3 += mi * mi;
+            s0 += th * th;
+            if constexpr (!TSQ_ONLY) { s2 += mi; s3 += mi * mi; }
         }
-        acc[0] += (double)s0; acc[2] += (double)s2; acc[3] += (double)s3;
+        acc[0] += (double)s0;
+        if constexpr (!TSQ_ONLY) { acc[2] += (double)s2; acc[3] += (double)s3; }
     }
     struct Regs { T th[4], gr[4], mi[4], tau[4], g[4], vh[4], rr[4], z[4]; };
 
@@ -318,7 +341,7 @@ struct SgldOp {
         store_quad<NT>(theta, q, R.th);
         if (ADAPT) {
             store_quad<NT>(tau, q, R.tau); store_quad<NT>(g, q, R.g); store_quad<NT>(vh, q, R.vh);
-            store_quad<NT>(minv, q, R.mi);
+            if (!skip_minv) store_quad<NT>(minv, q, R.mi);
             if (r) store_quad<NT>(r, q, R.rr);
         }
     }
@@ -327,7 +350,7 @@ struct SgldOp {
         store_part(theta, q, cnt, R.th);
         if (ADAPT) {
             store_part(tau, q, cnt, R.tau); store_part(g, q, cnt, R.g); store_part(vh, q, cnt, R.vh);
-            store_part(minv, q, cnt, R.mi);
+            if (!skip_minv) store_part(minv, q, cnt, R.mi);
             if (r) store_part(r, q, cnt, R.rr);
         }
     }
@@ -341,18 +364,25 @@ struct RsghmcOp {
     T grad_decay;
     NoiseKey nk;
     double *stats_part;
+    const T *scalars_dev = nullptr;       // nullable device copy of {eps, mass, D, m2c2, nscale} (see SghmcOp)
     static constexpr unsigned stats_mask = 0x3u;     // {theta'^2, p'^2}
-    __device__ __forceinline__ void prepare() { nk.resolve(); }
-    template <typename RegsT>
+    __device__ __forceinline__ void prepare()
+    {
+        nk.resolve();
+        if (scalars_dev) { eps = scalars_dev[0]; mass = scalars_dev[1]; D = scalars_dev[2]; m2c2 = scalars_dev[3]; nscale = scalars_dev[4]; }
+    }
+    template <bool TSQ_ONLY, typename RegsT>
     __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
     {
         T s0 = T(0), s1 = T(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (j < cnt) {
             T th = R.th[j], pp = R.p[j];
-            s0 += th * th; s1 += pp * pp;
+            s0 += th * th;
+            if constexpr (!TSQ_ONLY) s1 += pp * pp;
         }
-        acc[0] += (double)s0; acc[1] += (double)s1;
+        acc[0] += (double)s0;
+        if constexpr (!TSQ_ONLY) acc[1] += (double)s1;
     }
     struct Regs { T th[4], p[4], gr[4], z[4]; };
 
@@ -399,7 +429,7 @@ struct NormalFillOp {
     static constexpr unsigned stats_mask = 0u;
     __device__ __forceinline__ void prepare() { nk.resolve(); }
     struct Regs { T z[4]; };
-    __device__ __forceinline__ void accumulate(const Regs &, int, double (&)[4]) const {}
+    template <bool TSQ_ONLY> __device__ __forceinline__ void accumulate(const Regs &, int, double (&)[4]) const {}
     template <bool NT> __device__ __forceinline__ void load_vec(size_t, Regs &) const {}
     __device__ __forceinline__ void load_part_(size_t, int, Regs &) const {}
     __device__ __forceinline__ void compute(size_t q, Regs &R) const { normal_quad(nk, q, R.z); }
@@ -415,7 +445,7 @@ struct MomentsOp {
     static constexpr unsigned stats_mask = 0u;
     __device__ __forceinline__ void prepare() {}
     struct Regs { T x[4], mu[4], m2[4]; };
-    __device__ __forceinline__ void accumulate(const Regs &, int, double (&)[4]) const {}
+    template <bool TSQ_ONLY> __device__ __forceinline__ void accumulate(const Regs &, int, double (&)[4]) const {}
     template <bool NT> __device__ __forceinline__ void load_vec(size_t q, Regs &R) const
     { load_quad<NT>(theta, q, R.x); load_quad<NT>(mean, q, R.mu); load_quad<NT>(m2, q, R.m2); }
     __device__ __forceinline__ void load_part_(size_t q, int cnt, Regs &R) const

@@ -34,156 +34,42 @@
 #include <cstdint>
 #include <cstdio>
 
-#include "sgmcmc_hip.h"
-
-#pragma clang fp contract(off)
-
-#include "sgmcmc_device.hpp"
-#include "sgmcmc_host.hpp"
+#include "sgmcmc_stream.hpp"
 
 namespace {
 
-// --------------------------------------------------------------------------
-// the one streaming kernel shape all operators share
-// --------------------------------------------------------------------------
 
-// Fused step statistics ("LDS-staged reduction, wavefront shuffles for the partial
-// sums"): every lane keeps 4 running sums in registers, a wave reduces them with
-// DPP lane moves (row shifts + row broadcasts, 64 lanes), the 4 waves of a block meet in LDS, and ONE
-// 32-byte partial per block. A second, tiny kernel adds the partials in block order,
-// so the result is bit-reproducible for a given launch geometry. Costs no extra HBM
-// pass: the values are already in registers.
-// T = the kernel's dtype: f32 kernels reduce across the wave in f32 (6 DPP adds per statistic), f64 kernels in f64;
-// MASK = the statistics the operator produces (the others are written as 0 without any reduction work).
-template <typename T, unsigned MASK>
-__device__ __forceinline__ void stats_block_write(double (&acc)[4], double *__restrict__ part)
-{
-    __shared__ T lds[4][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if constexpr (((MASK >> 0) & 0xfu) != 0u) {
-            if ((MASK >> k) & 1u) {
-                T v = wave_sum_dpp_lane63((T)acc[k]);
-                if (lane == 63) lds[wave][k] = v;
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        const int nw = blockDim.x >> 6;
-        double v = 0.0;
-        if ((MASK >> threadIdx.x) & 1u)
-            for (int w = 0; w < nw; ++w) v += (double)lds[w][threadIdx.x];
-        // workspace = 32-byte header {number of partials} + statistic-major partials [4][gridDim.x]
-        part[4 + (size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(part)[0] = gridDim.x;
-}
-
-// Final pass: ONE block of 1024 lanes = 4 statistics x 256 lanes. Lane t of statistic k adds
-// partials t, t+256, ... (coalesced 8-B reads, 8 loads in flight), then a fixed shuffle/LDS
-// tree combines the 256 lanes. Fixed association => deterministic.
+// Final pass: ONE block of 1024 lanes = 256 records x 4 statistics per trip. Lane t handles statistic t & 3 of records
+// t >> 2, (t >> 2) + 256, ... (the 32-byte records are read as fully coalesced 8-byte elements, 8 loads in flight),
+// then a fixed shuffle/LDS tree combines the 256 lanes of each statistic. Fixed association => deterministic.
 __global__ void __launch_bounds__(1024) stats_final_kernel(const double *__restrict__ part, double *__restrict__ out4)
 {
-    __shared__ double lds[4][4];
+    __shared__ double lds[16][4];
     const unsigned nparts = (unsigned)reinterpret_cast<const unsigned long long *>(part)[0];
-    const int k = threadIdx.x >> 8, t = threadIdx.x & 255;
-    const int lane = threadIdx.x & 63, wave_in_k = (threadIdx.x >> 6) & 3;
-    const double *__restrict__ p = part + 4 + (size_t)k * nparts;
+    const int k = threadIdx.x & 3, t = threadIdx.x >> 2;
+    const int wave = threadIdx.x >> 6;
+    const double *__restrict__ p = part + 4 + k;
     double v = 0.0;
     unsigned i = t;
     for (; i + 7u * 256u < nparts; i += 8u * 256u) {
         double x[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = p[i + (unsigned)u * 256u];
+        for (int u = 0; u < 8; ++u) x[u] = p[4 * (size_t)(i + (unsigned)u * 256u)];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v += x[u];
     }
-    for (; i < nparts; i += 256u) v += p[i];
+    for (; i < nparts; i += 256u) v += p[4 * (size_t)i];
+    // lanes with equal (lane & 3) hold the same statistic: xor-shuffles over the other 4 lane bits
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0) lds[k][wave_in_k] = v;
+    for (int off = 32; off >= 4; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) < 4) lds[wave][k] = v;
     __syncthreads();
-    if (threadIdx.x < 4) out4[threadIdx.x] = ((lds[threadIdx.x][0] + lds[threadIdx.x][1]) + lds[threadIdx.x][2]) + lds[threadIdx.x][3];
-}
-
-// VEC: arrays are 16-B aligned; quads [0, nq_full) go through dwordx4 accesses,
-//      QPT quads in flight per lane; the ragged tail (n % 4 elements) is done
-//      element-wise by one lane.
-template <typename Op, int QPT, bool NT, bool STATS, bool LOOP>
-__global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t nq_full, int tail_cnt)
-{
-    Op op = op_in;
-    op.prepare();
-    const size_t G = (size_t)gridDim.x * blockDim.x;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    constexpr bool stats = STATS;                         // compile-time: the plain variant carries no reduction code
-    if constexpr (!LOOP) {
-        // the grid covers every quad (the default geometry): straight-line code, no loop-carried
-        // scalar state -> fewer SGPRs/VGPRs -> one more resident block per CU
-        static_assert(QPT == 1, "single-pass variant is one quad per lane");
-        if (gid < nq_full) {
-            typename Op::Regs R;
-            op.template load_vec<NT>(gid, R);
-            op.compute(gid, R);
-            op.template store_vec<NT>(gid, R);
-            if constexpr (stats) op.accumulate(R, 4, acc);
-        }
-    } else {
-        for (size_t base = gid; base < nq_full; base += G * QPT) {
-            typename Op::Regs R[QPT];
+    if (threadIdx.x < 4) {
+        double tot = 0.0;
 #pragma unroll
-            for (int u = 0; u < QPT; ++u) {
-                size_t q = base + (size_t)u * G;
-                if (q < nq_full) op.template load_vec<NT>(q, R[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < QPT; ++u) {
-                size_t q = base + (size_t)u * G;
-                if (q < nq_full) op.compute(q, R[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < QPT; ++u) {
-                size_t q = base + (size_t)u * G;
-                if (q < nq_full) {
-                    op.template store_vec<NT>(q, R[u]);
-                    if constexpr (stats) op.accumulate(R[u], 4, acc);
-                }
-            }
-        }
+        for (int w = 0; w < 16; ++w) tot += lds[w][threadIdx.x];
+        out4[threadIdx.x] = tot;
     }
-    if (tail_cnt && gid == G - 1) {
-        typename Op::Regs R;
-        op.load_part_(nq_full, tail_cnt, R);
-        op.compute(nq_full, R);
-        op.store_part_(nq_full, tail_cnt, R);
-        if constexpr (stats) op.accumulate(R, tail_cnt, acc);
-    }
-    if constexpr (stats) stats_block_write<typename Op::real, Op::stats_mask>(acc, op.stats_part);
-}
-
-// element-wise path for misaligned arrays: same quads, same results
-template <typename Op, bool STATS>
-__global__ void __launch_bounds__(256) stream_quads_scalar(const Op op_in, size_t n)
-{
-    Op op = op_in;
-    op.prepare();
-    const size_t G = (size_t)gridDim.x * blockDim.x;
-    const size_t nq = (n + 3) / 4;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    constexpr bool stats = STATS;
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += G) {
-        size_t left = n - 4 * q;
-        int cnt = left >= 4 ? 4 : (int)left;
-        typename Op::Regs R;
-        op.load_part_(q, cnt, R);
-        op.compute(q, R);
-        op.store_part_(q, cnt, R);
-        if constexpr (stats) op.accumulate(R, cnt, acc);
-    }
-    if constexpr (stats) stats_block_write<typename Op::real, Op::stats_mask>(acc, op.stats_part);
 }
 
 // --------------------------------------------------------------------------
@@ -345,7 +231,7 @@ __global__ void __launch_bounds__(1024) bnn_head_kernel(const T *__restrict__ me
         delta[i] = (T)(r * dscale);                              // d cost / d mean_i
     }
     // sum(theta^2): given directly, or as the per-block partials the previous step kernel left in its
-    // statistics workspace (statistic 0 of [4][nparts] after the 32-byte header), summed here in a
+    // statistics workspace (statistic 0 of the block-major records [nparts][4] after the 32-byte header), summed here in a
     // fixed order -- saves the separate K7 launch on the step's critical path
     double tsq = 0.0;
     if (stats_ws != nullptr) {
@@ -353,11 +239,12 @@ __global__ void __launch_bounds__(1024) bnn_head_kernel(const T *__restrict__ me
         const double *__restrict__ p = stats_ws + 4;
         unsigned i = threadIdx.x;
         const unsigned bd = blockDim.x;
+        // block-major 32-byte records: statistic 0 of record i is p[4 i]
         for (; i + 3u * bd < nparts; i += 4u * bd) {           // 4 loads in flight, fixed add order
-            double x0 = p[i], x1 = p[i + bd], x2 = p[i + 2u * bd], x3 = p[i + 3u * bd];
+            double x0 = p[4 * (size_t)i], x1 = p[4 * (size_t)(i + bd)], x2 = p[4 * (size_t)(i + 2u * bd)], x3 = p[4 * (size_t)(i + 3u * bd)];
             tsq += x0; tsq += x1; tsq += x2; tsq += x3;
         }
-        for (; i < nparts; i += bd) tsq += p[i];
+        for (; i < nparts; i += bd) tsq += p[4 * (size_t)i];
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -478,7 +365,7 @@ __global__ void __launch_bounds__(256) tanh_rowdot_kernel(T *__restrict__ a, con
         const double *__restrict__ p = stats_ws + 4;
         const unsigned len = (nparts + n_slices - 1) / n_slices;
         const unsigned lo = blockIdx.x * len, hi = (lo + len < nparts) ? lo + len : nparts;
-        for (unsigned i = lo + threadIdx.x; i < hi; i += 256) tsq += p[i];
+        for (unsigned i = lo + threadIdx.x; i < hi; i += 256) tsq += p[4 * (size_t)i];      // statistic 0 of record i
     }
     T *row = a + (size_t)blockIdx.x * cols;
     T acc = T(0);
@@ -704,68 +591,6 @@ using namespace sgmcmc_host;
 
 namespace {
 
-// Launch geometry of ONE call (sgmcmc_launch_t in the header; NULL = these defaults). The library keeps
-// no mutable state: two host threads may step two chains with different geometries concurrently.
-struct LaunchCfg {
-    int block_threads = -1;       // -1 = auto: 128 lanes when a launch streams > NT_AUTO_BYTES, else 256
-    int qpt = 1;
-    int max_blocks = 1 << 20;
-    int nt = 2;                   // 0 = plain, 1 = nt, 2 = auto by working-set size
-    int bt = 256;                 // resolved block size of this launch (set by launch_inner)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // kernel start / stop timestamps (hipExtLaunchKernel), both or none
-};
-// hipLaunchKernelGGL, or the timestamping launch when the caller passed events
-#define SGMCMC_LAUNCH(KERNEL, GRID, BLOCK, STREAM, CFG, ...)                                                         \
-    do {                                                                                                             \
-        if ((CFG).ev0 != nullptr || (CFG).ev1 != nullptr)                                                            \
-            hipExtLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, STREAM, (CFG).ev0, (CFG).ev1, 0, __VA_ARGS__); \
-        else                                                                                                         \
-            hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, STREAM, __VA_ARGS__);                             \
-    } while (0)
-// validates *in (0 / -1 fields keep the default); returns 0 or SGMCMC_EINVAL
-inline int resolve_launch(const sgmcmc_launch_t *in, LaunchCfg &c)
-{
-    if (!in) return 0;
-    if (in->block_threads != 0) {
-        if (in->block_threads != -1 && (in->block_threads < 64 || in->block_threads > 256 || (in->block_threads % 64) != 0))
-            return fail(SGMCMC_EINVAL, "launch.block_threads must be 64, 128, 192, 256, 0 (default) or -1 (auto)");
-        c.block_threads = in->block_threads;
-    }
-    if (in->quads_per_thread != 0) {
-        if (in->quads_per_thread != 1 && in->quads_per_thread != 2 && in->quads_per_thread != 4)
-            return fail(SGMCMC_EINVAL, "launch.quads_per_thread must be 0 (default), 1, 2 or 4");
-        c.qpt = in->quads_per_thread;
-    }
-    if (in->max_blocks != 0) {
-        if (in->max_blocks < 1) return fail(SGMCMC_EINVAL, "launch.max_blocks must be 0 (default) or >= 1");
-        c.max_blocks = in->max_blocks;
-    }
-    if (in->nontemporal != -1) {
-        if (in->nontemporal < 0 || in->nontemporal > 2)
-            return fail(SGMCMC_EINVAL, "launch.nontemporal must be -1 (default), 0 (off), 1 (on) or 2 (auto)");
-        c.nt = in->nontemporal;
-    }
-    c.ev0 = static_cast<hipEvent_t>(in->start_event);
-    c.ev1 = static_cast<hipEvent_t>(in->stop_event);
-    return 0;
-}
-// Above this many bytes touched per launch the arrays cannot stay in the 256 MiB
-// Infinity Cache between steps and nt accesses win (+6..7 % at 1.2 GB); below it
-// plain accesses win (the cache holds part of the working set across steps:
-// -5..-12 % with nt at 240 MB and 480 MB; +8 % at 800 MB). Measured on MI355X, profiles/r01_tune_*.txt.
-constexpr size_t NT_AUTO_BYTES = (size_t)640 << 20;
-
-inline bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-inline NoiseKey make_key(uint64_t seed, uint64_t step, const uint64_t *step_dev)
-{
-    NoiseKey nk;
-    nk.k0 = (uint32_t)seed; nk.k1 = (uint32_t)(seed >> 32);
-    nk.s0 = (uint32_t)step; nk.s1 = (uint32_t)(step >> 32);
-    nk.step_dev = step_dev;
-    return nk;
-}
-
 __global__ void counter_add_kernel(uint64_t *ctr, uint64_t inc) { *ctr += inc; }
 
 // minibatch window [start, start + B) of the resident dataset into the static feed buffers
@@ -785,162 +610,6 @@ __global__ void window_gather_kernel(const T *__restrict__ X, const T *__restric
     for (size_t q = gid; q < nq; q += G) reinterpret_cast<Q *>(xb)[q] = reinterpret_cast<const Q *>(src)[q];
     for (size_t i = nq * V + gid; i < nx; i += G) xb[i] = src[i];
     for (size_t i = gid; i < B; i += G) yb[i] = y[start + i];
-}
-
-// Upper bound of the grid any launch of n elements can use (sizes the stats workspace).
-inline size_t max_grid_for(size_t n)
-{
-    size_t nq = (n + 3) / 4;
-    size_t want = (nq + 63) / 64;                      // smallest block (64 threads), 1 quad per lane
-    size_t cap = (size_t)1 << 20;
-    return want < cap ? (want ? want : 1) : cap;
-}
-
-template <typename Op, int QPT, bool NT>
-int launch_vec(const Op &op, size_t n, const LaunchCfg &cfg, hipStream_t st)
-{
-    const int bt = cfg.bt;
-    const size_t nq_full = n / 4;
-    const int tail = (int)(n % 4);
-    size_t per_block = (size_t)bt * QPT;
-    size_t want = (nq_full + per_block - 1) / per_block;
-    if (want == 0) want = 1;
-    size_t cap = (size_t)cfg.max_blocks;
-    unsigned grid = (unsigned)(want < cap ? want : cap);
-    const bool with_stats = op.stats_part != nullptr;
-    if constexpr (QPT == 1) {
-        if (want <= cap) {                                 // one quad per lane, whole array in one pass
-            if (with_stats)
-                SGMCMC_LAUNCH((stream_quads_vec<Op, 1, NT, true, false>), grid, bt, st, cfg, op, nq_full, tail);
-            else
-                SGMCMC_LAUNCH((stream_quads_vec<Op, 1, NT, false, false>), grid, bt, st, cfg, op, nq_full, tail);
-            hipError_t e1 = hipGetLastError();
-            return e1 == hipSuccess ? 0 : hip_fail(e1, "launch stream_quads_vec");
-        }
-    }
-    if (with_stats)
-        SGMCMC_LAUNCH((stream_quads_vec<Op, QPT, NT, true, true>), grid, bt, st, cfg, op, nq_full, tail);
-    else
-        SGMCMC_LAUNCH((stream_quads_vec<Op, QPT, NT, false, true>), grid, bt, st, cfg, op, nq_full, tail);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : hip_fail(e, "launch stream_quads_vec");
-}
-template <typename Op>
-int launch_scalar(const Op &op, size_t n, const LaunchCfg &cfg, hipStream_t st)
-{
-    const int bt = cfg.bt;
-    size_t nq = (n + 3) / 4;
-    size_t want = (nq + bt - 1) / bt;
-    if (want == 0) want = 1;
-    size_t cap = (size_t)cfg.max_blocks;
-    unsigned grid = (unsigned)(want < cap ? want : cap);
-    if (op.stats_part != nullptr)
-        SGMCMC_LAUNCH((stream_quads_scalar<Op, true>), grid, bt, st, cfg, op, n);
-    else
-        SGMCMC_LAUNCH((stream_quads_scalar<Op, false>), grid, bt, st, cfg, op, n);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : hip_fail(e, "launch stream_quads_scalar");
-}
-
-// f32 ops honour the (quads_per_thread, nontemporal) knobs; f64 ops (a quad is
-// already 32 B per lane per array) use one quad per lane.
-template <typename Op>
-int launch(const Op &op, size_t n, bool vec_ok, size_t bytes_per_elem, const sgmcmc_launch_t *launch_in, hipStream_t st)
-{
-    if (n == 0) return 0;
-    LaunchCfg cfg;
-    if (int rc = resolve_launch(launch_in, cfg)) return rc;
-    const bool big = n * bytes_per_elem > NT_AUTO_BYTES;     // cannot stay in the Infinity Cache between steps
-    // measured (profiles/r01_block_sweep.txt): 128-lane blocks +7 % at 50 M params (HBM-resident), 256 +2 % at 10 M
-    cfg.bt = cfg.block_threads > 0 ? cfg.block_threads : (big ? 128 : 256);
-    if (!vec_ok) return launch_scalar<Op>(op, n, cfg, st);
-    const bool nt = cfg.nt == 2 ? big : (cfg.nt != 0);
-    if (sizeof(typename Op::real) == 8) {
-        return nt ? launch_vec<Op, 1, true>(op, n, cfg, st) : launch_vec<Op, 1, false>(op, n, cfg, st);
-    }
-    const int qpt = cfg.qpt;
-    if (nt) {
-        if (qpt >= 4) return launch_vec<Op, 4, true>(op, n, cfg, st);
-        if (qpt == 2) return launch_vec<Op, 2, true>(op, n, cfg, st);
-        return launch_vec<Op, 1, true>(op, n, cfg, st);
-    }
-    if (qpt >= 4) return launch_vec<Op, 4, false>(op, n, cfg, st);
-    if (qpt == 2) return launch_vec<Op, 2, false>(op, n, cfg, st);
-    return launch_vec<Op, 1, false>(op, n, cfg, st);
-}
-
-template <typename T>
-int sghmc_step(T *theta, T *V, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, size_t n,
-               T eps, T scale_grad, T mdecay, T grad_decay, int adapt, const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-               void *stats_ws, const sgmcmc_launch_t *lc, hipStream_t st)
-{
-    if (n == 0) return 0;
-    if (!theta || !V || !grad || !minv) return fail(SGMCMC_EINVAL, "sghmc_step: theta, V, grad and minv must be non-NULL");
-    if (adapt && (!tau || !g || !v_hat)) return fail(SGMCMC_EINVAL, "sghmc_step: adapt=1 needs tau, g and v_hat");
-    // scalars of the reference graph, in the dtype, same op order (sghmc.py:111-117,211-217,235)
-    T eps_s = eps / std::sqrt(scale_grad);
-    T e2 = std::pow(eps, T(2));
-    T c1 = (T(2) * std::pow(eps_s, T(2))) * mdecay;
-    T c3 = T(2) * std::pow(eps_s, T(3));
-    T e4 = std::pow(eps_s, T(4));
-    NoiseKey nk = make_key(seed, step, step_dev);
-    double *sp = static_cast<double *>(stats_ws);
-    bool vec_ok = aligned16(theta) && aligned16(V) && aligned16(grad) && aligned16(minv) && aligned16(xi) &&
-                  (!adapt || (aligned16(tau) && aligned16(g) && aligned16(v_hat) && aligned16(r)));
-#define SGHMC_GO(AD, INJ)                                                                              \
-    {                                                                                                  \
-        SghmcOp<T, AD, INJ> op{theta, V, grad, tau, g, v_hat, minv, r, xi, e2, c1, c3, e4, mdecay, grad_decay, nk, sp}; \
-        return launch(op, n, vec_ok, sizeof(T) * ((AD ? 12 : 6) + (INJ ? 1 : 0)), lc, st);                 \
-    }
-    if (adapt) { if (xi) SGHMC_GO(true, true) else SGHMC_GO(true, false) }
-    else { if (xi) SGHMC_GO(false, true) else SGHMC_GO(false, false) }
-#undef SGHMC_GO
-}
-
-template <typename T>
-int sgld_step(T *theta, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, size_t n,
-              T eps, T A, T scale_grad, T grad_decay, int adapt, const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-               void *stats_ws, const sgmcmc_launch_t *lc, hipStream_t st)
-{
-    if (n == 0) return 0;
-    if (!theta || !grad || !minv) return fail(SGMCMC_EINVAL, "sgld_step: theta, grad and minv must be non-NULL");
-    if (adapt && (!tau || !g || !v_hat)) return fail(SGMCMC_EINVAL, "sgld_step: adapt=1 needs tau, g and v_hat");
-    T sgn = (scale_grad > T(0)) ? T(1) : ((scale_grad < T(0)) ? T(-1) : T(0));
-    T sg_den = scale_grad + ((T(2) * sgn) * T(1e-16) + T(1e-16));
-    T two_eps = T(2) * eps;
-    T a_eff = A - T(0);
-    NoiseKey nk = make_key(seed, step, step_dev);
-    double *sp = static_cast<double *>(stats_ws);
-    bool vec_ok = aligned16(theta) && aligned16(grad) && aligned16(minv) && aligned16(xi) &&
-                  (!adapt || (aligned16(tau) && aligned16(g) && aligned16(v_hat) && aligned16(r)));
-#define SGLD_GO(AD, INJ)                                                                            \
-    {                                                                                               \
-        SgldOp<T, AD, INJ> op{theta, grad, tau, g, v_hat, minv, r, xi, eps, A, a_eff, two_eps, sg_den, grad_decay, nk, sp}; \
-        return launch(op, n, vec_ok, sizeof(T) * ((AD ? 10 : 4) + (INJ ? 1 : 0)), lc, st);              \
-    }
-    if (adapt) { if (xi) SGLD_GO(true, true) else SGLD_GO(true, false) }
-    else { if (xi) SGLD_GO(false, true) else SGLD_GO(false, false) }
-#undef SGLD_GO
-}
-
-template <typename T>
-int rsghmc_step(T *theta, T *p, const T *grad, size_t n, T eps, T mass, T c, T D, T b_hat, T grad_decay,
-                const T *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                void *stats_ws, const sgmcmc_launch_t *lc, hipStream_t st)
-{
-    if (n == 0) return 0;
-    if (!theta || !p || !grad) return fail(SGMCMC_EINVAL, "rsghmc_step: theta, p and grad_cost must be non-NULL");
-    T m2c2 = (mass * mass) * (c * c);
-    T nscale = std::sqrt(eps * ((T(2) * D) - (eps * b_hat)));
-    NoiseKey nk = make_key(seed, step, step_dev);
-    double *sp = static_cast<double *>(stats_ws);
-    bool vec_ok = aligned16(theta) && aligned16(p) && aligned16(grad) && aligned16(xi);
-    if (xi) {
-        RsghmcOp<T, false, true> op{theta, p, grad, xi, eps, mass, D, m2c2, nscale, grad_decay, nk, sp};
-        return launch(op, n, vec_ok, sizeof(T) * 6, lc, st);
-    }
-    RsghmcOp<T, false, false> op{theta, p, grad, xi, eps, mass, D, m2c2, nscale, grad_decay, nk, sp};
-    return launch(op, n, vec_ok, sizeof(T) * 5, lc, st);
 }
 
 template <typename T>
@@ -1087,57 +756,15 @@ int sgmcmc_device_count(void)
     return n;
 }
 
-int sgmcmc_sghmc_step_f32(float *theta, float *V, const float *grad, float *tau, float *g, float *v_hat,
-                          float *minv, float *r, size_t n, float eps, float scale_grad, float mdecay, float grad_decay, int adapt,
-                          const float *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream)
-{
-    return sghmc_step<float>(theta, V, grad, tau, g, v_hat, minv, r, n, eps, scale_grad, mdecay, grad_decay, adapt, xi, seed, step,
-                             step_dev, stats_ws, launch, static_cast<hipStream_t>(stream));
-}
-int sgmcmc_sghmc_step_f64(double *theta, double *V, const double *grad, double *tau, double *g, double *v_hat,
-                          double *minv, double *r, size_t n, double eps, double scale_grad, double mdecay, double grad_decay,
-                          int adapt,
-                          const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
-                          void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream)
-{
-    return sghmc_step<double>(theta, V, grad, tau, g, v_hat, minv, r, n, eps, scale_grad, mdecay, grad_decay, adapt, xi, seed, step,
-                              step_dev, stats_ws, launch, static_cast<hipStream_t>(stream));
-}
-int sgmcmc_sgld_step_f32(float *theta, const float *grad, float *tau, float *g, float *v_hat, float *minv, float *r,
-                         size_t n, float eps, float A, float scale_grad, float grad_decay, int adapt, const float *xi,
-                         uint64_t seed,
-                         uint64_t step, const uint64_t *step_dev, void *stats_ws, const sgmcmc_launch_t *launch,
-                         sgmcmc_stream_t stream)
-{
-    return sgld_step<float>(theta, grad, tau, g, v_hat, minv, r, n, eps, A, scale_grad, grad_decay, adapt, xi, seed, step, step_dev,
-                            stats_ws, launch, static_cast<hipStream_t>(stream));
-}
-int sgmcmc_sgld_step_f64(double *theta, const double *grad, double *tau, double *g, double *v_hat, double *minv,
-                         double *r, size_t n, double eps, double A, double scale_grad, double grad_decay, int adapt,
-                         const double *xi,
-                         uint64_t seed, uint64_t step, const uint64_t *step_dev, void *stats_ws, const sgmcmc_launch_t *launch,
-                         sgmcmc_stream_t stream)
-{
-    return sgld_step<double>(theta, grad, tau, g, v_hat, minv, r, n, eps, A, scale_grad, grad_decay, adapt, xi, seed, step, step_dev,
-                             stats_ws, launch, static_cast<hipStream_t>(stream));
-}
-int sgmcmc_rsghmc_step_f32(float *theta, float *p, const float *grad_cost, size_t n, float eps, float mass, float c,
-                           float D, float b_hat, float grad_decay, const float *xi, uint64_t seed, uint64_t step,
-                           const uint64_t *step_dev, void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream)
-{
-    return rsghmc_step<float>(theta, p, grad_cost, n, eps, mass, c, D, b_hat, grad_decay, xi, seed, step, step_dev,
-                              stats_ws, launch, static_cast<hipStream_t>(stream));
-}
-int sgmcmc_rsghmc_step_f64(double *theta, double *p, const double *grad_cost, size_t n, double eps, double mass,
-                           double c, double D, double b_hat, double grad_decay, const double *xi, uint64_t seed,
-                           uint64_t step,
-                           const uint64_t *step_dev, void *stats_ws, const sgmcmc_launch_t *launch, sgmcmc_stream_t stream)
-{
-    return rsghmc_step<double>(theta, p, grad_cost, n, eps, mass, c, D, b_hat, grad_decay, xi, seed, step, step_dev,
-                               stats_ws, launch, static_cast<hipStream_t>(stream));
-}
 size_t sgmcmc_step_stats_workspace_bytes(size_t n) { return (max_grid_for(n) + 1) * 4 * sizeof(double); }
+size_t sgmcmc_step_launch_blocks(size_t n, const sgmcmc_launch_t *launch_in)
+{
+    LaunchCfg cfg;
+    if (!launch_in || resolve_launch(launch_in, cfg) != 0) return 0;
+    if (cfg.block_threads <= 0) { fail(SGMCMC_EINVAL, "step_launch_blocks: launch.block_threads must be explicit"); return 0; }
+    const size_t want = want_blocks(n, cfg.block_threads, cfg.qpt);
+    return want < (size_t)cfg.max_blocks ? want : (size_t)cfg.max_blocks;
+}
 int sgmcmc_step_stats_finish(const void *stats_ws, double *stats_out, sgmcmc_stream_t stream)
 {
     if (!stats_ws || !stats_out) return fail(SGMCMC_EINVAL, "step_stats_finish: NULL argument");

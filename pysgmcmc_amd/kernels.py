@@ -15,7 +15,7 @@ from pysgmcmc_amd._lib import SgmcmcLibraryError, check, lib
 __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
-    "LaunchConfig", "KernelEvents", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
+    "LaunchConfig", "KernelEvents", "StepOpts", "step_launch_blocks", "step_scalars", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
     "bnn_fused_sgld_steps", "window_gather", "tanh_rowdot", "bnn_head_last_layer_backward", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
 ]
 
@@ -118,15 +118,18 @@ class LaunchConfig(object):
                 "max_blocks": c.max_blocks, "nontemporal": c.nontemporal}
 
 
+
 class KernelEvents(object):
     """A pair of HIP events that a launch fills with the KERNEL's own start and stop timestamps (the duration
     rocprofv3 reports for the kernel), via ``LaunchConfig(events=...)``. ``elapsed_us()`` after a synchronise."""
 
-    def __init__(self):
+    def __init__(self, device=None):
+        """``device``: the device whose launches the events will time (default: the current device)."""
         import ctypes
         a, b = ctypes.c_void_p(), ctypes.c_void_p()
-        check(lib().sgmcmc_event_create(ctypes.byref(a)), "sgmcmc_event_create")
-        check(lib().sgmcmc_event_create(ctypes.byref(b)), "sgmcmc_event_create")
+        with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+            check(lib().sgmcmc_event_create(ctypes.byref(a)), "sgmcmc_event_create")
+            check(lib().sgmcmc_event_create(ctypes.byref(b)), "sgmcmc_event_create")
         self.start, self.stop = a.value, b.value
 
     def elapsed_us(self):
@@ -181,38 +184,102 @@ def _launch(launch):
     return None if cfg is None else ctypes.byref(cfg._c)
 
 
+class StepOpts(object):
+    """Optional extras of one step call (``sgmcmc_step_opts_t``; see ``include/sgmcmc_hip.h``):
+
+    ``first_element``  this launch covers the slice of the chain's parameter vector that starts there (multiple of 4);
+    ``stats_base`` / ``stats_total``  statistics record slot of block 0 / record count of the whole step;
+    ``theta_sq_only``  reduce only sum theta'^2;  ``hbm_resident``  geometry hint for slices of a large arena;
+    ``skip_minv_store``  burn-in step that does not write minv;
+    ``moments`` = (mean, m2, count)  fold theta' into the Welford moments in the same pass (K4 fused);
+    ``scalars_dev``  device block from :func:`step_scalars` that overrides the by-value scalars."""
+
+    __slots__ = ("_c", "_keep")
+
+    def __init__(self, first_element=0, stats_base=0, stats_total=0, theta_sq_only=False, hbm_resident=False,
+                 skip_minv_store=False, moments=None, scalars_dev=None, like=None):
+        from pysgmcmc_amd import _lib
+        flags = (_lib.STEP_HBM_RESIDENT if hbm_resident else 0) | (_lib.STEP_SKIP_MINV_STORE if skip_minv_store else 0)
+        mean = m2 = None
+        count = 0
+        if moments is not None:
+            mean, m2, count = moments
+            if like is not None:
+                for t in (mean, m2):
+                    if t.dtype != like.dtype or t.numel() != like.numel() or t.device != like.device:
+                        raise TypeError("pysgmcmc_amd: fused moments must match theta in dtype, length and device")
+        if scalars_dev is not None and like is not None and (scalars_dev.dtype != like.dtype or scalars_dev.numel() < 5):
+            raise TypeError("pysgmcmc_amd: scalars_dev must hold 5 elements of the step's dtype")
+        self._keep = (mean, m2, scalars_dev)
+        self._c = _lib.StepOptsStruct(int(first_element), int(stats_base), int(stats_total),
+                                      _lib.STATS_THETA_SQ if theta_sq_only else 0, flags, _ptr(mean), _ptr(m2), int(count),
+                                      _ptr(scalars_dev))
+
+
+def _opts(opts, like):
+    import ctypes
+    if opts is None:
+        return None
+    if not isinstance(opts, StepOpts):
+        opts = StepOpts(like=like, **opts)
+    return ctypes.byref(opts._c)
+
+
+def step_launch_blocks(n, launch):
+    """Number of blocks (= statistics records) a vector-path step launch of ``n`` elements uses under ``launch``
+    (a :class:`LaunchConfig` with an explicit ``block_threads``)."""
+    import ctypes
+    blocks = int(lib().sgmcmc_step_launch_blocks(int(n), ctypes.byref(launch._c)))
+    if blocks == 0:
+        check(-1, "sgmcmc_step_launch_blocks")
+    return blocks
+
+
+def step_scalars(kind, out, *scalars):
+    """Fill the device block ``out`` (>= 5 elements of the step's dtype) with the derived scalars of a step, for
+    ``StepOpts(scalars_dev=out)``: kind "sghmc" (eps, scale_grad, mdecay), "sgld" (eps, A, scale_grad) or "rsghmc"
+    (eps, mass, c, D, b_hat)."""
+    f = getattr(lib(), "sgmcmc_%s_scalars_%s" % (kind, _sfx(out)))
+    if out.numel() < 5:
+        raise ValueError("pysgmcmc_amd: the scalars block needs 5 elements")
+    with _on(out):
+        rc = f(*[float(v) for v in scalars], _ptr(out), _stream(out))
+    check(rc, "sgmcmc_%s_scalars" % kind)
+    return out
+
+
 def sghmc_step(theta, V, grad, tau, g, v_hat, minv, r, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step=0, step_dev=None,
-               stats=None, grad_decay=0.0, launch=None):
+               stats=None, grad_decay=0.0, launch=None, opts=None):
     """K1, one fused SGHMC step in place (pysgmcmc/samplers/sghmc.py:165-251)."""
     f = getattr(lib(), "sgmcmc_sghmc_step_" + _sfx(theta))
     with _on(theta):
         rc = f(_ptr(theta), _ptr(V, theta), _ptr(grad, theta), _ptr(tau, theta), _ptr(g, theta),
                _ptr(v_hat, theta), _ptr(minv, theta), _ptr(r, theta), theta.numel(),
                float(eps), float(scale_grad), float(mdecay), float(grad_decay), int(bool(adapt)), _ptr(xi, theta),
-               int(seed), int(step), _ctr(step_dev), *_stats(stats), _launch(launch), _stream(theta))
+               int(seed), int(step), _ctr(step_dev), *_stats(stats), _opts(opts, theta), _launch(launch), _stream(theta))
     check(rc, "sgmcmc_sghmc_step")
 
 
 def sgld_step(theta, grad, tau, g, v_hat, minv, r, eps, A, scale_grad, adapt, xi=None, seed=0, step=0, step_dev=None,
-              stats=None, grad_decay=0.0, launch=None):
+              stats=None, grad_decay=0.0, launch=None, opts=None):
     """K2, one fused SGLD step in place (pysgmcmc/samplers/sgld.py:149-211)."""
     f = getattr(lib(), "sgmcmc_sgld_step_" + _sfx(theta))
     with _on(theta):
         rc = f(_ptr(theta), _ptr(grad, theta), _ptr(tau, theta), _ptr(g, theta), _ptr(v_hat, theta),
                _ptr(minv, theta), _ptr(r, theta), theta.numel(), float(eps), float(A), float(scale_grad),
-               float(grad_decay), int(bool(adapt)), _ptr(xi, theta), int(seed), int(step), _ctr(step_dev), *_stats(stats), _launch(launch),
-               _stream(theta))
+               float(grad_decay), int(bool(adapt)), _ptr(xi, theta), int(seed), int(step), _ctr(step_dev), *_stats(stats),
+               _opts(opts, theta), _launch(launch), _stream(theta))
     check(rc, "sgmcmc_sgld_step")
 
 
 def rsghmc_step(theta, p, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, step=0, step_dev=None,
-                stats=None, grad_decay=0.0, launch=None):
+                stats=None, grad_decay=0.0, launch=None, opts=None):
     """K3, one fused relativistic SGHMC step (pysgmcmc/samplers/relativistic_sghmc.py:120-140)."""
     f = getattr(lib(), "sgmcmc_rsghmc_step_" + _sfx(theta))
     with _on(theta):
         rc = f(_ptr(theta), _ptr(p, theta), _ptr(grad_cost, theta), theta.numel(), float(eps), float(mass),
                float(c), float(D), float(b_hat), float(grad_decay), _ptr(xi, theta), int(seed), int(step), _ctr(step_dev), *_stats(stats),
-               _launch(launch), _stream(theta))
+               _opts(opts, theta), _launch(launch), _stream(theta))
     check(rc, "sgmcmc_rsghmc_step")
 
 
@@ -250,6 +317,11 @@ def rhat_pack(mean, m2, count, out3, n_shards=1, shard_len=None):
     shard_len = n if shard_len is None else int(shard_len)
     if out3.numel() != 3 * int(n_shards) * shard_len:
         raise ValueError("out3 must hold 3 * n_shards * shard_len elements")
+    if out3.dtype != mean.dtype or m2.dtype != mean.dtype:
+        # the kernel is picked from mean.dtype: an f64 pack into an f32 buffer of equal length would write past its end
+        raise TypeError("rhat_pack: mean, m2 and out3 must share a dtype (got %s, %s, %s)" % (mean.dtype, m2.dtype, out3.dtype))
+    if out3.device != mean.device:
+        raise ValueError("rhat_pack: out3 lives on %s, the moments on %s" % (out3.device, mean.device))
     f = getattr(lib(), "sgmcmc_rhat_pack_" + _sfx(mean))
     with _on(mean):
         rc = f(_ptr(mean), _ptr(m2, mean), n, int(count), int(n_shards), shard_len, _ptr(out3), _stream(mean))

@@ -251,7 +251,35 @@ class BNNCost(object):
                 torch.tanh_(hs[l])
             h = hs[l]
 
+    # layers with at least this many weights announce their finished gradient (grad_ready_points): the sampler may
+    # then update that slice of the arena on a side stream under the rest of the backward pass
+    OVERLAP_MIN_WEIGHTS = 1 << 18
+
+    def grad_ready_points(self, params):
+        """Parameter indices p, in the order the backward pass reaches them, at which the gradients of ``params[p:]``
+        are complete and their values are no longer read: after the weight-gradient GEMM of hidden layer l (p = 2 l),
+        for every layer but the first (its gradient is the last thing the pipeline computes)."""
+        n_layers = (len(params) - 1) // 2
+        L = n_layers - 1
+        single_out = params[2 * L].shape[1] == 1 and n_layers >= 2
+        top = L - 1 if single_out else L
+        return [2 * l for l in range(top, 0, -1) if params[2 * l].numel() >= self.OVERLAP_MIN_WEIGHTS]
+
+    def cost_and_grad_iter(self, params, grad_views, theta_sumsq=None, theta_sumsq_partials=None):
+        """``cost_and_grad`` as a generator: yields p at every point of ``grad_ready_points`` (in that order) and
+        returns the cost (``StopIteration.value``). HIP path only; advance it under ``torch.no_grad()`` (a generator
+        cannot hold a grad-mode context across its yields)."""
+        return self._hip_pipeline(params, grad_views, theta_sumsq, theta_sumsq_partials)
+
     def _cost_and_grad_hip(self, params, grad_views, theta_sumsq, theta_sumsq_partials=None):
+        gen = self._hip_pipeline(params, grad_views, theta_sumsq, theta_sumsq_partials)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as stop:
+                return stop.value
+
+    def _hip_pipeline(self, params, grad_views, theta_sumsq, theta_sumsq_partials=None):
         from pysgmcmc_amd import kernels
         X, Y = self.x_placeholder.value, self.y_placeholder.value
         B = X.shape[0]
@@ -260,10 +288,11 @@ class BNNCost(object):
         hs, ds = ws["h"], ws["d"]
         L = n_layers - 1
         single_out = params[2 * L].shape[1] == 1 and n_layers >= 2
+        ready = set(self.grad_ready_points(params))
         # forward; a single-output last layer is a plain GEMV whose bias the loss head adds
         h = X
         fuse_top = single_out and self.fuse_tanh_rowdot
-        # loss head folded into the last layer's backward (one launch less): needs the sum(theta^2) partials of the
+        # loss head folded into the last layer's backward (one launch less): needs the sum(theta^2) records of the
         # previous step kernel, which the rowdot launch reduces to 16 slices on the side
         fuse_head = fuse_top and self.fuse_head and theta_sumsq_partials is not None
         for l in range(n_layers):
@@ -317,6 +346,10 @@ class BNNCost(object):
                                                 grad_views[2 * (l - 1) + 1], grad_views[2 * l].view(-1),
                                                 bias_prev=params[2 * (l - 1) + 1], beta=beta)
                 continue
+            # delta_{l-1} = delta_l W_l^T FIRST: it is the last reader of W_l, so once gW_l exists (next GEMM) the layer's
+            # slice of the arena may be updated while the rest of the backward pass runs
+            if l > 0:
+                torch.mm(ds[l], W.t(), out=ds[l - 1])
             # gW_l = h_{l-1}^T delta_l written directly into the gradient arena. The weight-prior term
             # coef * theta is added by the update kernel (fold_prior) or rides in the GEMM epilogue (beta).
             if self.fold_prior:
@@ -329,8 +362,9 @@ class BNNCost(object):
                     torch.mv(ds[l].t(), ws["ones"], out=grad_views[2 * l + 1])
                 else:
                     torch.addmv(b, ds[l].t(), ws["ones"], beta=prior_coef, alpha=1.0, out=grad_views[2 * l + 1])
+            if 2 * l in ready:
+                yield 2 * l                                   # gradients of params[2 l:] complete, values no longer read
             if l > 0:
-                torch.mm(ds[l], W.t(), out=ds[l - 1])
                 # delta_{l-1} *= 1 - h_{l-1}^2, and gb_{l-1} = column sums of the result (+ beta * b_{l-1})
                 kernels.tanh_backward_colsum(ds[l - 1], hs[l - 1], grad_views[2 * (l - 1) + 1],
                                              bias=params[2 * (l - 1) + 1], beta=beta)

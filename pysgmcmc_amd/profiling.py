@@ -24,10 +24,13 @@ __all__ = ["UpdateKernelTimer"]
 
 
 class UpdateKernelTimer(object):
-    def __init__(self, reserve=0, bracket=False):
+    def __init__(self, reserve=0, bracket=False, device=None):
+        """``device``: the device of the sampler being timed (events belong to a device; default: the current one)."""
+        self.device = device
         self.enabled = False
         self.bracket = bool(bracket)
         self.kevents = []          # one KernelEvents per timed launch, in launch order
+        self.tags = []             # per timed launch: None, or (step, lo, hi) for one slice of an overlapped update
         self.pairs = []            # (torch event, torch event) brackets, when bracket=True
         self._pool = []
         self._current = None
@@ -36,37 +39,70 @@ class UpdateKernelTimer(object):
 
     def reserve(self, n):
         """Create the events of ``n`` timed launches up front (no event creation inside a timed loop)."""
-        self._pool = [(kernels.KernelEvents(), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                      for _ in range(int(n))]
+        self._pool = [self._new_events() for _ in range(int(n))]
+
+    def _new_events(self):
+        with torch.cuda.device(self.device if self.device is not None else torch.cuda.current_device()):
+            return (kernels.KernelEvents(self.device), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
     # -- called by the sampler around its update launch --
-    def begin(self):
-        self._current = self._pool.pop() if self._pool else (
-            kernels.KernelEvents(), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    def begin(self, tag=None):
+        self._tag = tag
+        self._current = self._pool.pop() if self._pool else self._new_events()
         if self.bracket:
             self._current[1].record()
 
     def launch_config(self, base):
         """The launch geometry ``base`` (or the defaults) plus this launch's timestamp events."""
+        base = base if base is not None else kernels._default_launch      # the sweep tools' Python-side default
         geom = base.as_dict() if base is not None else {}
         return kernels.LaunchConfig(events=self._current[0], **geom)
 
-    def end(self):
+    def end(self, launched=True):
+        """``launched=False``: the launch raised -- its never-recorded events are dropped, not kept as a sample."""
         kev, e0, e1 = self._current
+        self._current = None
+        if not launched:
+            return
         if self.bracket:
             e1.record()
             self.pairs.append((e0, e1))
         self.kevents.append(kev)
-        self._current = None
+        self.tags.append(getattr(self, "_tag", None))
 
     # -- results (after the stream has been synchronised) --
     def kernel_us(self):
         return np.array([k.elapsed_us() for k in self.kevents])
 
     def step_us(self):
-        """Time from the end of each timed update kernel to the end of the next: the device time of a whole step."""
-        kv = self.kevents
+        """Time from the end of each step's LAST update launch to the end of the next step's: the device time of a
+        whole step (an overlapped update is several launches per step, tagged (step, lo, hi))."""
+        kv = self.last_launch_of_each_step()
         return np.array([kv[j].us_until(kv[j + 1]) for j in range(len(kv) - 1)])
+
+    def last_launch_of_each_step(self):
+        out, prev = [], object()
+        for kev, tag in zip(self.kevents, self.tags):
+            step = tag[0] if tag is not None else None
+            if tag is not None and step == prev:
+                out[-1] = kev
+            else:
+                out.append(kev)
+            prev = step if tag is not None else object()
+        return out
+
+    def per_step_kernel_us(self):
+        """(sum of the update launches' durations per step, bytes-weighted slices included)."""
+        sums, prev = [], object()
+        for kev, tag in zip(self.kevents, self.tags):
+            us = kev.elapsed_us()
+            step = tag[0] if tag is not None else None
+            if tag is not None and step == prev:
+                sums[-1] += us
+            else:
+                sums.append(us)
+            prev = step if tag is not None else object()
+        return np.array(sums)
 
     def bracket_us(self):
         return np.array([a.elapsed_time(b) * 1e3 for a, b in self.pairs])

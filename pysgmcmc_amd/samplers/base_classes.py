@@ -25,6 +25,8 @@ What differs, by design:
   * ``collect_stats`` (attribute, default True): the step kernel also reduces
     {sum theta^2, sum V^2, sum minv, sum minv^2} from registers (``sampler.stats``); a cost
     function that sets ``accepts_theta_sumsq`` gets sum theta^2 for free (BNN weight prior).
+    ``"theta_sq"`` reduces only sum theta^2 (all a BNN pipeline consumes); ``False`` nothing.
+  * ``overlap_update`` (attribute) / ``attach_moments``: see ``_step_graph`` and ``attach_moments``.
   * ``sample_format`` (attribute, not a constructor keyword so that the
     ``get_sampler`` keyword reflection stays identical to the reference):
     ``"numpy"`` (default, reference behaviour: one D2H copy of theta per step),
@@ -80,6 +82,9 @@ class MCMCSampler(object):
 
     # state rows (besides theta and grad) the subclass's kernel needs
     _STATE_ROWS = ()
+    # "sghmc" / "sgld" / "rsghmc": the kernel can read its stepsize-derived scalars from a device block
+    # (kernels.step_scalars); None: by value only
+    _SCALARS_KIND = None
     # every parameter starts at a multiple of this many elements in the arena rows (1 = dense)
     _PARAM_ALIGN = 1
 
@@ -136,9 +141,21 @@ class MCMCSampler(object):
         self._stats = None
         self._stats_valid = False
         self._stats_out_valid = False
+        # Welford moments folded into the update launch (attach_moments)
+        self._moments, self._moments_every = None, 1
         # hipGraph mode
         self.use_hip_graph = False
-        self.max_full_graphs = 4              # "full" mode: graphs kept per (stepsize, phase) before falling back
+        # True: update the arena slice by slice on a side stream as soon as each layer's gradient is complete (needs
+        # use_hip_graph = True and a cost function with cost_and_grad_iter, e.g. BNNCost). Bit-identical chain, but
+        # MEASURED SLOWER on MI355X (profiles/r03_overlap_probe.txt: 239-246 vs 199 us per step at 10 M parameters --
+        # cross-queue synchronisation costs ~40 us per step whatever the update's grid): off by default, kept for
+        # the measurement.
+        self.overlap_update = False
+        self._slice_plan = None
+        self._slice_launch = None
+        self._side_stream = None
+        self._scalars_dev = None
+        self._scalars_value = None
         self._graphs = {}
         self._static_feeds = {}
         self._step_ctr = None
@@ -154,6 +171,7 @@ class MCMCSampler(object):
         self.theta_t = self.arena.views("theta")
         self._graphs.clear()
         self._static_feeds.clear()
+        self._slice_plan = None
         self._stats_valid = False
         self._view_cache = None
 
@@ -220,12 +238,7 @@ class MCMCSampler(object):
         """Evaluate cost at the current theta and leave d cost/d theta in the arena's grad row."""
         fused = getattr(self.cost_fun, "cost_and_grad", None)
         if fused is not None:
-            kw = {}
-            if getattr(self.cost_fun, "accepts_theta_sumsq", False):
-                st = self._ensure_stats()
-                if st is not None:
-                    kw["theta_sumsq_partials"] = st.workspace
-            cost = fused(self.params, self.arena.grad_views, **kw)
+            cost = fused(self.params, self.arena.grad_views, **self._cost_kwargs())
             # a cost function may leave a term coef * theta of its gradient to the update kernel
             self._grad_decay = float(getattr(self.cost_fun, "grad_theta_coef", 0.0))
             return cost.detach() if isinstance(cost, torch.Tensor) else torch.as_tensor(cost)
@@ -308,26 +321,90 @@ class MCMCSampler(object):
         return cost
 
     # ------------------------------------------------------------------ step
-    def _kernel_step(self, eps, xi):
+    def _kernel_step(self, eps, xi, sl=None, opts=None):
+        """Launch the update of the elements ``sl`` (a slice of the arena rows; None = all) with the step extras
+        ``opts`` (a dict of ``kernels.StepOpts`` keywords or None)."""
         raise NotImplementedError
 
+    def _bytes_per_element(self):
+        """Bytes one update launch touches per parameter (mirrors the library's auto-geometry rule)."""
+        return 6 * self.arena.row("theta").element_size()
+
+    def _sliced_rows(self, names, sl):
+        rows = [self.arena.row(k) for k in names]
+        return rows if sl is None else [r[sl] for r in rows]
+
+    def _stats_written(self):
+        if self._stats is not None:
+            self._stats_valid = True          # the workspace now holds this step's per-block records
+            self._stats_out_valid = False     # K7 runs lazily (sampler.stats); the BNN head reads the records
+
     def _launch(self):
-        """Launch configuration of the update kernel for THIS launch: the chain's geometry, plus the timestamp events
-        of an attached, enabled kernel timer (never inside a graph capture)."""
+        """Launch configuration of the update kernel for THIS launch: the chain's geometry (or the geometry this
+        step's slices were planned with), plus the timestamp events of an attached, enabled kernel timer (never inside
+        a graph capture)."""
+        base = self._slice_launch if self._slice_launch is not None else self.launch
         t = self.kernel_timer
         if t is not None and t._current is not None:
-            return t.launch_config(self.launch)
-        return self.launch
+            return t.launch_config(base)
+        return base
 
-    def _timed_kernel_step(self, eps, xi):
+    def _timed_kernel_step(self, eps, xi, sl=None, opts=None, tag=None):
         t = self.kernel_timer
+        kw = {} if (sl is None and opts is None) else dict(sl=sl, opts=opts)
         if t is None or not t.enabled or self._capturing:
-            return self._kernel_step(eps, xi)
-        t.begin()
+            return self._kernel_step(eps, xi, **kw)
+        if t.device is None:
+            t.device = self.device
+        t.begin(tag)
+        ok = False
         try:
-            self._kernel_step(eps, xi)
+            self._kernel_step(eps, xi, **kw)
+            ok = True
         finally:
-            t.end()
+            t.end(launched=ok)
+
+    # -- what one update launch carries besides the update --
+    def attach_moments(self, moments, every=1):
+        """Fold theta' into ``moments`` (a ``ChainMoments`` of this chain's dtype) on every ``every``-th step INSIDE the
+        update launch (K4 fused into K1-K3: +16 B/param on those launches instead of a separate 20 B/param pass);
+        ``moments.count`` advances with it. ``attach_moments(None)`` detaches."""
+        if moments is not None:
+            assert moments.n == self.arena.n and moments.mean.dtype == self._torch_dtype, \
+                "moments must match the chain in length and dtype"
+        self._moments, self._moments_every = moments, max(int(every), 1)
+
+    def _moments_due(self):
+        return self._moments is not None and (self.n_iterations + 1) % self._moments_every == 0
+
+    def _update_opts(self, lo, hi, rec_base=0, rec_total=0, moments=None, sliced=False):
+        o = {}
+        if lo:
+            o["first_element"] = int(lo)
+        if rec_base or rec_total:
+            o["stats_base"], o["stats_total"] = int(rec_base), int(rec_total)
+        if self.collect_stats == "theta_sq":
+            o["theta_sq_only"] = True
+        if sliced and self._arena_is_hbm_resident():
+            o["hbm_resident"] = True
+        if moments is not None:
+            o["moments"] = (moments.mean[lo:hi], moments.m2[lo:hi], moments.count)
+        if self._capturing and self._scalars_dev is not None:
+            o["scalars_dev"] = self._scalars_dev
+        return o or None
+
+    def _arena_is_hbm_resident(self):
+        return self.arena.n * self._bytes_per_element() > (640 << 20)
+
+    def _update(self, eps, xi):
+        """The whole update of this step as ONE launch (eager stepping, the plain graph modes)."""
+        moments = None
+        if self._moments_due() and not self._capturing:
+            moments = self._moments
+            moments.count += 1
+        # (a captured launch replays its arguments and cannot carry the by-value Welford count: see _step_graph_full)
+        self._timed_kernel_step(eps, xi, opts=self._update_opts(0, self.arena.n, moments=moments),
+                                tag=(self.n_iterations, 0, self.arena.n))
 
     def _step(self, feed_dict):
         assert (feed_dict is None or hasattr(feed_dict, "update"))
@@ -341,7 +418,10 @@ class MCMCSampler(object):
         cost = self._cost_and_grad()          # U(theta_{t-1}) and its gradient
         self.cost = cost
         with torch.no_grad():
-            self._timed_kernel_step(eps, self._draw_noise())
+            self._update(eps, self._draw_noise())
+        return self._finish_step(cost)
+
+    def _finish_step(self, cost):
         sample = self._format_sample()        # theta_t
         cost_out = self._format_cost(cost)
         self.stepsize_schedule.update(sample, cost_out)
@@ -349,21 +429,11 @@ class MCMCSampler(object):
         return sample, cost_out
 
     # ------------------------------------------------------------------ hipGraph mode
-    def _graph_key(self, eps):
-        return (float(eps),)
+    def _graph_key(self):
+        return ("full",)
 
-    def _step_graph(self, feed_dict):
-        """One step with the launch-bound part replayed from a hipGraph.
-
-        ``use_hip_graph = True``: the graph holds cost + gradient into the arena; the fused update is
-        then launched directly (stepsize / phase / Philox step by value, HIP events can bracket it).
-        ``use_hip_graph = "full"``: the graph also holds the fused update (Philox step read from a
-        device counter) and ``counter += 1``; a new (eps, phase) pair captures a new graph, so
-        constant-stepsize sampling replays one graph for burn-in and one for the frozen phase. With a
-        scheduled stepsize the cache is bounded by ``max_full_graphs``; beyond it the sampler drops to
-        ``use_hip_graph = True`` for good (eps is then a by-value argument of a direct launch).
-        Feeds are copied into static buffers first. Requirements: static feed shapes; a cost
-        function without host synchronisation."""
+    def _feed_static(self, feed_dict):
+        """Next minibatch into the STATIC feed buffers a captured cost pipeline reads."""
         gen = self.batch_generator
         if (not feed_dict and hasattr(gen, "next_starts") and gen.x_dev.is_cuda
                 and gen.x_placeholder in self._static_feeds and gen.y_placeholder in self._static_feeds
@@ -375,7 +445,6 @@ class MCMCSampler(object):
             gen.x_placeholder.value, gen.y_placeholder.value = bx, by
         else:
             feed_dict.update(self._next_batch())
-        eps = self._next_stepsize()
         for placeholder, value in feed_dict.items():
             if not hasattr(placeholder, "feed"):
                 continue
@@ -388,64 +457,187 @@ class MCMCSampler(object):
             else:
                 buf.copy_(value)                  # (one torch._foreach_copy_ for all feeds measured slower: 246 vs 236 us/step)
             placeholder.value = buf
+
+    def _step_graph(self, feed_dict):
+        """One step with the launch-bound part replayed from hipGraphs.
+
+        ``use_hip_graph = True``: the graph holds cost + gradient into the arena; the fused update is launched
+        directly (stepsize / phase / Philox step by value, HIP events can time it). With ``overlap_update`` and a
+        cost function that reports when a layer's gradient is complete (``cost_and_grad_iter``), the pipeline is
+        captured as consecutive graph SEGMENTS and the update of the finished slice of the arena is launched on a side
+        stream between them, so the HBM-bound update runs under the remaining (matrix-core-bound) backward GEMMs; the
+        slices draw the Philox quads the single launch would draw -- the chain is bit-identical.
+        ``use_hip_graph = "full"``: ONE graph per phase (burn-in / frozen) also holds the update: the Philox step comes
+        from a device counter and the stepsize-derived scalars from a device block refreshed by a tiny direct launch
+        whenever the schedule moves (``StepOpts.scalars_dev``), so a SCHEDULED stepsize replays the same graph.
+        Feeds are copied into static buffers first. Requirements: static feed shapes; a cost function without host
+        synchronisation."""
+        self._feed_static(feed_dict)
+        eps = self._next_stepsize()
         self._ensure_stats()
-        full = self.use_hip_graph == "full"
+        if self.use_hip_graph == "full":
+            return self._step_graph_full(eps)
+        entry = self._graphs.get(("cost",))
+        if entry is None:
+            entry = self._graphs[("cost",)] = self._capture_cost()
+        segments, cost = entry
+        with torch.no_grad():
+            if len(segments) == 1:
+                segments[0][0].replay()
+                self._update(eps, None)
+            else:
+                self._replay_overlapped(segments, eps)
+        self.cost = cost
+        return self._finish_step(cost)
+
+    def _step_graph_full(self, eps):
         if self._step_ctr is None:
             self._step_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
-        if full and self._ctr_value != self.n_iterations:
-            # only the fully captured step reads the device counter (the direct launch gets the step by value)
+            self._scalars_dev = torch.zeros(8, dtype=self._torch_dtype, device=self.device)
+        if self._ctr_value != self.n_iterations:
             self._step_ctr.fill_(self.n_iterations)
             self._ctr_value = self.n_iterations
-        key = self._graph_key(eps) if full else ("cost",)
+        key = self._graph_key()
+        if self._SCALARS_KIND is None:
+            # a sampler whose kernel takes its stepsize by value only (SVGD): one graph per stepsize
+            self._scalars_dev = None
+            key = key + (float(eps),)
+        else:
+            scal = self._step_scalars(eps)
+            if scal != self._scalars_value:       # the schedule moved: refresh the device block (1-thread launch)
+                kernels.step_scalars(self._SCALARS_KIND, self._scalars_dev, *scal)
+                self._scalars_value = scal
         entry = self._graphs.get(key)
-        if entry is None and full and len(self._graphs) >= self.max_full_graphs:
-            # "full" bakes the stepsize into the captured update launch, one graph per (eps, phase). A stepsize
-            # SCHEDULE (e.g. BurnInRampStepsizeSchedule) would capture and keep a new graph every step: stop
-            # capturing, drop the cache and continue in cost-graph mode (update launched directly, eps by value).
-            import logging
-            logging.getLogger(__name__).warning(
-                "use_hip_graph='full': more than %d distinct (stepsize, phase) pairs -- the stepsize is scheduled; "
-                "switching this sampler to use_hip_graph=True (cost graph + direct update launch)", self.max_full_graphs)
-            self._graphs.clear()
-            self.use_hip_graph = True
-            full = False
-            key = ("cost",)
-            entry = None
         if entry is None:
-            entry = self._capture(eps, full)
-            self._graphs[key] = entry
+            entry = self._graphs[key] = self._capture_full(eps)
         graph, cost = entry
         graph.replay()
-        if full:
-            self._ctr_value += 1
-        else:
-            with torch.no_grad():
-                self._timed_kernel_step(eps, None)
+        self._ctr_value += 1
+        if self._moments_due():
+            # a captured launch replays its arguments, the Welford count cannot ride in it: separate K4 launch
+            self._moments.update(self.arena.row("theta"))
         self.cost = cost
-        sample = self._format_sample()
-        cost_out = self._format_cost(cost)
-        self.stepsize_schedule.update(sample, cost_out)
-        self.n_iterations += 1
-        return sample, cost_out
+        return self._finish_step(cost)
 
-    def _capture(self, eps, full):
+    def _warm_cost(self):
         cur = torch.cuda.current_stream(self.device)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):                 # warm-up: cost only, no state change
             self._cost_and_grad()
         cur.wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        self._capturing = full
-        try:
+
+    def _cost_kwargs(self):
+        kw = {}
+        if getattr(self.cost_fun, "accepts_theta_sumsq", False):
+            st = self._ensure_stats()
+            if st is not None:
+                kw["theta_sumsq_partials"] = st.workspace
+        return kw
+
+    def _plan_slices(self, ready_points):
+        """Arena slices of an overlapped step. ``ready_points`` = parameter indices p (descending): when the cost
+        pipeline reaches that point, the gradients of params[p:] are complete and their values no longer read.
+        Returns [(lo, hi, record_base)] in launch order plus the record total, or None when a boundary is not
+        quad-aligned (slices must start on a Philox quad)."""
+        a = self.arena
+        bt = self._slice_block_threads()
+        cfg = kernels.LaunchConfig(block_threads=bt,
+                                   **{k: v for k, v in (self.launch.as_dict() if self.launch is not None else {}).items()
+                                      if k != "block_threads"})
+        bounds = [a.n] + [int(a.offsets[p]) for p in ready_points] + [0]
+        if any(b % 4 for b in bounds[1:]) or sorted(set(bounds), reverse=True) != bounds:
+            return None
+        spans = [(bounds[i + 1], bounds[i]) for i in range(len(bounds) - 1)]      # launch order: high addresses first
+        blocks = [kernels.step_launch_blocks(hi - lo, cfg) for lo, hi in spans]
+        total = sum(blocks)
+        plan, base = [], total
+        for (lo, hi), nb in zip(spans, blocks):
+            base -= nb                                                           # records in memory order
+            plan.append((lo, hi, base))
+        return plan, total, cfg
+
+    def _slice_block_threads(self):
+        if self.launch is not None and self.launch.as_dict()["block_threads"] > 0:
+            return self.launch.as_dict()["block_threads"]
+        return 128 if self._arena_is_hbm_resident() else 256
+
+    def _capture_cost(self):
+        """Capture the cost/gradient pipeline: one graph, or -- overlapped update -- one graph per segment between
+        the points where a slice of the gradient is complete. Returns ([(graph, slice or None)], cost)."""
+        self._warm_cost()
+        iter_fn = getattr(self.cost_fun, "cost_and_grad_iter", None) if self.overlap_update else None
+        plan = None
+        if iter_fn is not None:
+            points = list(self.cost_fun.grad_ready_points(self.params))
+            plan = self._plan_slices(points) if points else None
+        if plan is None:
+            graph = torch.cuda.CUDAGraph()
             # thread_local: other threads (e.g. the RCCL watchdog of a multi-chain job) may keep calling
             # HIP while this thread captures
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 cost = self._cost_and_grad()
-                if full:
-                    with torch.no_grad():
-                        self._kernel_step(eps, None)
-                    kernels.counter_add(self._step_ctr, 1)
+            return [(graph, None)], cost
+        spans, total, cfg = plan
+        self._slice_plan = (spans, total, cfg)
+        gen = iter_fn(self.params, self.arena.grad_views, **self._cost_kwargs())
+        segments, cost, pool = [], None, None
+        for k in range(len(spans)):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"), torch.no_grad():
+                try:
+                    next(gen)
+                except StopIteration as stop:
+                    cost = stop.value
+            pool = graph.pool()
+            segments.append((graph, spans[k]))
+        assert cost is not None, "cost_and_grad_iter must yield exactly once per grad_ready_points() entry"
+        self._grad_decay = float(getattr(self.cost_fun, "grad_theta_coef", 0.0))
+        cost = cost.detach() if isinstance(cost, torch.Tensor) else torch.as_tensor(cost)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+            self._fork_events = [torch.cuda.Event() for _ in range(len(spans))]
+            self._join_event = torch.cuda.Event()
+        return segments, cost
+
+    def _replay_overlapped(self, segments, eps):
+        """graph segment -> update of the slice whose gradient it completed, on the side stream -> next segment ...;
+        the last slice (nothing left to hide under) runs on the main stream, which then waits for the side stream."""
+        spans, total, cfg = self._slice_plan
+        moments = None
+        if self._moments_due():
+            moments = self._moments
+            moments.count += 1
+        main = torch.cuda.current_stream(self.device)
+        side = self._side_stream
+        self._slice_launch = cfg
+        try:
+            last = len(segments) - 1
+            for k, (graph, (lo, hi, base)) in enumerate(segments):
+                graph.replay()
+                opts = self._update_opts(lo, hi, base, total, moments=moments, sliced=True)
+                if k < last:
+                    self._fork_events[k].record(main)
+                    side.wait_event(self._fork_events[k])
+                    with torch.cuda.stream(side):
+                        self._timed_kernel_step(eps, None, sl=slice(lo, hi), opts=opts, tag=(self.n_iterations, lo, hi))
+                else:
+                    self._timed_kernel_step(eps, None, sl=slice(lo, hi), opts=opts, tag=(self.n_iterations, lo, hi))
+            self._join_event.record(side)
+            main.wait_event(self._join_event)
+        finally:
+            self._slice_launch = None
+
+    def _capture_full(self, eps):
+        self._warm_cost()
+        graph = torch.cuda.CUDAGraph()
+        self._capturing = True
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                cost = self._cost_and_grad()
+                with torch.no_grad():
+                    self._update(eps, None)
+                kernels.counter_add(self._step_ctr, 1)
         finally:
             self._capturing = False
         return graph, cost
@@ -519,8 +711,8 @@ class BurnInMCMCSampler(MCMCSampler):
     def _adapting(self):
         return self.is_burning_in or self.burn_in_steps <= 0
 
-    def _graph_key(self, eps):
-        return (float(eps), bool(self._adapting))
+    def _graph_key(self):
+        return ("full", bool(self._adapting))
 
     @property
     def minv(self):

@@ -132,12 +132,17 @@ class RelativisticSGHMCSampler(MCMCSampler):
     def momentum(self):
         return self.arena.views("p")
 
-    def _kernel_step(self, eps, xi):
-        a = self.arena
+    def _bytes_per_element(self):
+        return 5 * self.arena.row("theta").element_size()                                  # K3: 20 B per f32 parameter
+
+    _SCALARS_KIND = "rsghmc"
+
+    def _step_scalars(self, eps):
+        return (eps, self.mass, self.speed_of_light, self.D, self.Bhat)
+
+    def _kernel_step(self, eps, xi, sl=None, opts=None):
+        rows = self._sliced_rows(("theta", "p", "grad"), sl)
         kernels.rsghmc_step(
-            a.row("theta"), a.row("p"), a.row("grad"),
-            eps, self.mass, self.speed_of_light, self.D, self.Bhat,
-            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, launch=self._launch(), **self._noise_args())
-        if self._stats is not None:
-            self._stats_valid = True          # the workspace now holds this step's per-block partials
-            self._stats_out_valid = False     # K7 runs lazily (sampler.stats); the BNN head reads the partials
+            *rows, eps, self.mass, self.speed_of_light, self.D, self.Bhat,
+            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, launch=self._launch(), opts=opts, **self._noise_args())
+        self._stats_written()

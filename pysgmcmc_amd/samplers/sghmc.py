@@ -36,16 +36,22 @@ class SGHMCSampler(FusedBNNStepsMixin, BurnInMCMCSampler):
         self.scale_grad = float(scale_grad)
         # momentum starts at zero (sghmc.py:152-155); tau = g = v_hat = minv = 1 set by the base
 
-    def _kernel_step(self, eps, xi):
-        a = self.arena
+    def _bytes_per_element(self):
+        return (12 if self._adapting else 6) * self.arena.row("theta").element_size()     # K1: 48 / 24 B per f32 parameter
+
+    _SCALARS_KIND = "sghmc"
+
+    def _step_scalars(self, eps):
+        return (eps, self.scale_grad, self.mdecay)
+
+    def _kernel_step(self, eps, xi, sl=None, opts=None):
+        rows = self._sliced_rows(("theta", "V", "grad", "tau", "g", "v_hat", "minv"), sl)
+        r = self._r_row()
         kernels.sghmc_step(
-            a.row("theta"), a.row("V"), a.row("grad"),
-            a.row("tau"), a.row("g"), a.row("v_hat"), a.row("minv"), self._r_row(),
+            *rows, r if (r is None or sl is None) else r[sl],
             eps, self.scale_grad, self.mdecay, self._adapting,
-            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, launch=self._launch(), **self._noise_args())
-        if self._stats is not None:
-            self._stats_valid = True          # the workspace now holds this step's per-block partials
-            self._stats_out_valid = False     # K7 runs lazily (sampler.stats); the BNN head reads the partials
+            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, launch=self._launch(), opts=opts, **self._noise_args())
+        self._stats_written()
 
     # ------------------------------------------------------------------ fused small-model path (see _fused_bnn.py)
     def _fused_bnn_launch(self, starts, costs, eps, n_steps, n_chains=1, chain_stride=None, bases=None):

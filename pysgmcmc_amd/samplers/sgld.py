@@ -52,16 +52,22 @@ class SGLDSampler(FusedBNNStepsMixin, BurnInMCMCSampler):
         self.stepsize_schedule = self._reference_schedule if self._strict else self._caller_schedule
         self.epsilon = self.stepsize_schedule.initial_value
 
-    def _kernel_step(self, eps, xi):
-        a = self.arena
+    def _bytes_per_element(self):
+        return (10 if self._adapting else 4) * self.arena.row("theta").element_size()     # K2: 40 / 16 B per f32 parameter
+
+    _SCALARS_KIND = "sgld"
+
+    def _step_scalars(self, eps):
+        return (eps, self.A, self.scale_grad)
+
+    def _kernel_step(self, eps, xi, sl=None, opts=None):
+        rows = self._sliced_rows(("theta", "grad", "tau", "g", "v_hat", "minv"), sl)
+        r = self._r_row()
         kernels.sgld_step(
-            a.row("theta"), a.row("grad"),
-            a.row("tau"), a.row("g"), a.row("v_hat"), a.row("minv"), self._r_row(),
+            *rows, r if (r is None or sl is None) else r[sl],
             eps, self.A, self.scale_grad, self._adapting,
-            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, launch=self._launch(), **self._noise_args())
-        if self._stats is not None:
-            self._stats_valid = True          # the workspace now holds this step's per-block partials
-            self._stats_out_valid = False     # K7 runs lazily (sampler.stats); the BNN head reads the partials
+            xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, launch=self._launch(), opts=opts, **self._noise_args())
+        self._stats_written()
 
     # ------------------------------------------------------------------ fused small-model path (see _fused_bnn.py)
     def _fused_bnn_launch(self, starts, costs, eps, n_steps, n_chains=1, chain_stride=None, bases=None):

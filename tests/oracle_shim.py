@@ -15,7 +15,7 @@ def _sfx(t):
 
 
 def sghmc_step(theta, V, grad, tau, g, v_hat, minv, r, eps, scale_grad, mdecay, adapt, xi=None, seed=0, step=0,
-               step_dev=None, stats=None, grad_decay=0.0, launch=None):
+               step_dev=None, stats=None, grad_decay=0.0, launch=None, opts=None):
     lib = O.load_c()
     f = getattr(lib, "oracle_sghmc_step_" + _sfx(theta))
     p = lambda t: None if t is None else t.data_ptr()
@@ -23,10 +23,11 @@ def sghmc_step(theta, V, grad, tau, g, v_hat, minv, r, eps, scale_grad, mdecay, 
            float(eps), float(scale_grad), float(mdecay), float(grad_decay), int(bool(adapt)), p(xi), int(seed), int(step))
     assert rc == 0
     calls.append(("sghmc", bool(adapt), float(eps), int(step)))
+    _fused_moments(theta, opts)
 
 
 def sgld_step(theta, grad, tau, g, v_hat, minv, r, eps, A, scale_grad, adapt, xi=None, seed=0, step=0,
-              step_dev=None, stats=None, grad_decay=0.0, launch=None):
+              step_dev=None, stats=None, grad_decay=0.0, launch=None, opts=None):
     lib = O.load_c()
     f = getattr(lib, "oracle_sgld_step_" + _sfx(theta))
     p = lambda t: None if t is None else t.data_ptr()
@@ -34,10 +35,11 @@ def sgld_step(theta, grad, tau, g, v_hat, minv, r, eps, A, scale_grad, adapt, xi
            float(eps), float(A), float(scale_grad), float(grad_decay), int(bool(adapt)), p(xi), int(seed), int(step))
     assert rc == 0
     calls.append(("sgld", bool(adapt), float(eps), int(step)))
+    _fused_moments(theta, opts)
 
 
 def rsghmc_step(theta, p_, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, step=0, step_dev=None, stats=None,
-                grad_decay=0.0, launch=None):
+                grad_decay=0.0, launch=None, opts=None):
     lib = O.load_c()
     f = getattr(lib, "oracle_rsghmc_step_" + _sfx(theta))
     p = lambda t: None if t is None else t.data_ptr()
@@ -45,6 +47,17 @@ def rsghmc_step(theta, p_, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, s
            float(b_hat), float(grad_decay), p(xi), int(seed), int(step))
     assert rc == 0
     calls.append(("rsghmc", False, float(eps), int(step)))
+    _fused_moments(theta, opts)
+
+
+def _fused_moments(theta, opts):
+    """``opts`` (a dict of StepOpts keywords): the shim honours ``moments`` (K4 folded into the step) and refuses slices."""
+    if not opts:
+        return
+    assert not opts.get("first_element"), "the CPU shim steps whole arenas only"
+    if opts.get("moments") is not None:
+        mean, m2, count = opts["moments"]
+        moments_update(theta, mean, m2, count)
 
 
 def svgd_workspace(n_particles, like):

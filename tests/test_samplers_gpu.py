@@ -252,11 +252,12 @@ def test_hip_graph_mode_equals_eager(gpu):
     assert np.isclose(st["momentum_sq"], (graph.arena.row("V").double() ** 2).sum().item(), rtol=5e-7)
 
 
-def test_full_graph_mode_with_a_stepsize_schedule_is_bounded(gpu):
-    """``use_hip_graph = "full"`` bakes the stepsize into the captured update; with a SCHEDULED stepsize
-    (BurnInRampStepsizeSchedule, configs[4]) every step would capture and keep a new graph. The cache is bounded by
-    ``max_full_graphs``; beyond it the sampler drops to the cost-graph mode for good. Either way the chain equals the
-    eager chain bit for bit, and the stepsizes fed to the kernel are the schedule's."""
+def test_full_graph_mode_follows_a_stepsize_schedule_through_the_device_scalars(gpu):
+    """``use_hip_graph = "full"`` captures the update too. A captured launch replays its arguments, so the
+    stepsize-derived scalars live in a device block (``StepOpts.scalars_dev``) that a 1-thread launch refreshes when the
+    schedule moves: a SCHEDULED stepsize (BurnInRampStepsizeSchedule, configs[4]) replays ONE graph per phase, the
+    user's ``use_hip_graph`` attribute is never touched, the chain equals the eager chain bit for bit and the stepsizes
+    are the schedule's."""
     from pysgmcmc_amd.data_batches import Placeholder, generate_batches
     from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
     from pysgmcmc_amd.stepsize_schedules import BurnInRampStepsizeSchedule
@@ -276,23 +277,16 @@ def test_full_graph_mode_with_a_stepsize_schedule_is_bounded(gpu):
         for _ in range(16):
             next(s)
             eps.append(float(s.epsilon))
-            assert len(s._graphs) <= s.max_full_graphs                    # never an unbounded graph cache
         return s, eps
-    for ctor, kw, rows in ((SGLDSampler, dict(burn_in_steps=10, scale_grad=200.0), ("theta", "minv")),
-                           (RelativisticSGHMCSampler, {}, ("theta", "p"))):
+    for ctor, kw, rows, n_graphs in ((SGLDSampler, dict(burn_in_steps=10, scale_grad=200.0), ("theta", "minv"), 2),
+                                     (SGHMCSampler, dict(burn_in_steps=10, scale_grad=200.0), ("theta", "V", "minv"), 2),
+                                     (RelativisticSGHMCSampler, {}, ("theta", "p"), 1)):
         eager, e0 = chain(ctor, False, **kw)
         full, e1 = chain(ctor, "full", **kw)
         assert e0 == e1 and len(set(e0[:11])) == 11 and e0[10] == e0[-1] == 1e-2      # ramp, then constant
-        assert full.use_hip_graph is True and len(full._graphs) == 1                  # fell back to the cost graph
+        assert full.use_hip_graph == "full" and len(full._graphs) == n_graphs         # one graph per phase, attribute untouched
         for row in rows:
             assert torch.equal(eager.arena.row(row), full.arena.row(row)), (ctor.__name__, row)
-    # a constant schedule keeps the fully captured mode (2 graphs: burn-in and frozen)
-    s = SGLDSampler(params=[torch.zeros(8, device=gpu)], cost_fun=lambda p: (p[0] ** 2).sum(), burn_in_steps=3,
-                    session=gpu, dtype=torch.float32, seed=1)
-    s.use_hip_graph = "full"
-    for _ in range(8):
-        next(s)
-    assert s.use_hip_graph == "full" and len(s._graphs) == 2
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])
