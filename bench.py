@@ -597,6 +597,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists for the update path)")
+    if os.environ.get("BENCH_TEST_FAIL_RANK") == str(rank) and world > 1:
+        sys.exit(7)                                            # tests/: a rank that dies must take the job down
     dev = torch.device("cuda", 0 if args.all_ranks_on_gpu0 else local_rank)
     torch.cuda.set_device(dev)
     dist = None
@@ -828,7 +830,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes if launches_per_step == 1 else None,
                          "algorithmic_bytes_per_step": alg_bytes,
                          "us_per_step_mean": round(k_us, 2),
-                         "launches_timed": len(plain), "launches_per_step": launches_per_step,
+                         "launches_timed": len(rows), "launches_in_the_rate": len(plain), "launches_per_step": launches_per_step,
                          "slices": slices,
                          "with_fused_moments": None if not with_mom else {
                              "launches": len(with_mom), "bytes_per_param": BYTES_PER_PARAM[mode] + 16,

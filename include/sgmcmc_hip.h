@@ -91,7 +91,7 @@ int sgmcmc_event_synchronize(void *event);      /* host waits until the event ha
  *                under the remaining backward GEMMs -- gives exactly the chain the single launch gives.
  *   stats_record_base / stats_record_total: with a stats workspace, block b of this launch writes statistics record
  *                stats_record_base + b and the workspace header is set to stats_record_total records (0 = this launch's
- *                grid): the slices of one step share one workspace. sgmcmc_step_launch_blocks() gives a launch's grid.
+ *                own): the slices of one step share one workspace. sgmcmc_step_stats_records() gives a launch's count.
  *   stats_select:   0 = every statistic the operator produces; SGMCMC_STATS_THETA_SQ = only sum theta'^2 (the one the
  *                BNN loss head consumes; the other three are written as 0 and cost no reduction work).
  *   flags:       SGMCMC_STEP_HBM_RESIDENT: the launch is part of a working set larger than the Infinity Cache even if
@@ -122,9 +122,9 @@ typedef struct sgmcmc_step_opts {
     const void *scalars_dev;
 } sgmcmc_step_opts_t;
 
-/* Grid (number of blocks = statistics records) a vector-path step launch of n elements uses under `launch`
- * (block_threads must be explicit there: 64..256), or 0 on invalid arguments.                                   */
-size_t sgmcmc_step_launch_blocks(size_t n, const sgmcmc_launch_t *launch);
+/* Number of statistics records (one per block = the grid) a vector-path step launch of n elements writes under
+ * `launch` (block_threads must be explicit there: 64..256), or 0 on invalid arguments.                          */
+size_t sgmcmc_step_stats_records(size_t n, const sgmcmc_launch_t *launch);
 
 /* K1 -- fused SGHMC step. Replaces the op chain pysgmcmc/samplers/sghmc.py:165-251
  * (+ constants :111-117) and the burn-in switch pysgmcmc/samplers/base_classes.py:432-456.
@@ -174,7 +174,7 @@ int sgmcmc_rsghmc_scalars_f64(double eps, double mass, double c, double D, doubl
 
 /* Workspace: 32-byte header {uint64 record count} + one 32-byte record {4 doubles} per block.                  */
 size_t sgmcmc_step_stats_workspace_bytes(size_t n);
-/* K7 -- stats_out[0..3] (device doubles) = fixed-order sum of the per-block partials a step kernel left
+/* K7 -- stats_out[0..3] (device doubles) = fixed-order sum of the per-block records a step kernel left
  * in stats_ws. One 1024-lane block.                                                               */
 int sgmcmc_step_stats_finish(const void *stats_ws, double *stats_out, sgmcmc_stream_t stream);
 
@@ -208,6 +208,29 @@ int sgmcmc_rsghmc_step_f64(double *theta, double *p, const double *grad_cost, si
                            const double *xi, uint64_t seed, uint64_t step, const uint64_t *step_dev,
                           void *stats_ws, const sgmcmc_step_opts_t *opts, const sgmcmc_launch_t *launch,
                           sgmcmc_stream_t stream);
+
+/* Many steps of many independent chains on the reference's built-in toy targets in ONE launch (one lane per chain; state
+ * in registers; the per-element update operators and the Philox stream of K1-K3, so a chain is the chain next(sampler)
+ * gives on the same gradients). Replaces the per-step session.run loop of the reference's sampler tests and of its ESS
+ * experiment (pysgmcmc/tests/samplers/sampler_testing.py:14-59, docs/source/experiments/compute_ess.py:176-246; targets
+ * pysgmcmc/diagnostics/objective_functions.py:49-98), cost = -log_likelihood with analytic gradients.
+ *   sampler: 0 SGHMC, 1 preconditioned SGLD, 2 relativistic SGHMC
+ *   target:  0 1-D Gaussian mixture, target_params = {mu[k], var[k], w[k]} (dim 1)
+ *            1 banana (dim 2, no parameters)
+ *            2 2-D isotropic unit-variance equal-weight mixture, target_params = {x_0, y_0, ..., x_{k-1}, y_{k-1}} (dim 2)
+ *   theta, mom (V or p; NULL for SGLD), tau, g, v_hat, minv (NULL for relativistic SGHMC): DEVICE arrays [n_chains][dim]
+ *   scalars (host): SGHMC {eps, scale_grad, mdecay}; SGLD {eps, A, scale_grad}; relativistic {eps, mass, c, D, b_hat}
+ *   seeds: DEVICE array [n_chains], the chains' Philox keys; element i of a chain draws normal i of quad 0 at (seed, step)
+ *   steps first_step .. first_step + n_steps - 1; steps < burn_in_steps adapt (burn_in_steps <= 0: always, quirk Q4)
+ *   kept: NULL, or DEVICE array [ceil(n_steps / keep_every)][n_chains][dim]: theta after steps first_step + j keep_every */
+int sgmcmc_toy_chains_f32(int sampler, int target, const double *target_params, int k, float *theta, float *mom, float *tau,
+                          float *g, float *v_hat, float *minv, size_t n_chains, int dim, const double *scalars,
+                          const uint64_t *seeds, uint64_t first_step, uint64_t n_steps, int64_t burn_in_steps,
+                          uint64_t keep_every, float *kept, sgmcmc_stream_t stream);
+int sgmcmc_toy_chains_f64(int sampler, int target, const double *target_params, int k, double *theta, double *mom, double *tau,
+                          double *g, double *v_hat, double *minv, size_t n_chains, int dim, const double *scalars,
+                          const uint64_t *seeds, uint64_t first_step, uint64_t n_steps, int64_t burn_in_steps,
+                          uint64_t keep_every, double *kept, sgmcmc_stream_t stream);
 
 /* K5 -- write the N(0,1) stream itself: out[i] = xi(seed, step, i). Replaces
  * tf.random_normal in pysgmcmc/samplers/base_classes.py:218-220 for callers that
@@ -275,7 +298,7 @@ int sgmcmc_summary_f64(const double *x, size_t n, double *out4, void *workspace,
  *   grad_log_var_out = d NLL / d log_var, mse_out, and (if grad_last_bias_out != NULL) the bias
  *   gradient of a single-output last layer = sum_i delta[i] (+ prior term; `last_bias` = that bias).
  * sum(theta^2) comes from `theta_sumsq` (a device double) or, when `stats_ws` != NULL, from the
- * per-block partials the previous step kernel left in its statistics workspace (summed here in a
+ * per-block records the previous step kernel left in its statistics workspace (summed here in a
  * fixed order; saves the K7 launch on the critical path). All scalar outputs are device pointers.
  * fold_prior_grad is a bit mask: bit 0 leaves the weight-prior gradient term (wdecay / (n_params * n_examples)) * theta
  * out of the gradients because the caller passes it to the update kernel as grad_decay; bit 1 says

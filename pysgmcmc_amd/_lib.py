@@ -26,7 +26,7 @@ def lib_path():
 def build(force=False):
     """Compile ``csrc/libsgmcmc_hip.so`` for gfx950 with hipcc (no GPU needed)."""
     import subprocess
-    deps = [os.path.join(_CSRC, f) for f in ("sgmcmc_kernels.hip", "sgmcmc_sghmc.hip", "sgmcmc_sgld.hip", "sgmcmc_rsghmc.hip", "sgmcmc_stream.hpp", "sgmcmc_bnn_fused.hip", "sgmcmc_svgd.hip", "sgmcmc_device.hpp",
+    deps = [os.path.join(_CSRC, f) for f in ("sgmcmc_kernels.hip", "sgmcmc_sghmc.hip", "sgmcmc_sgld.hip", "sgmcmc_rsghmc.hip", "sgmcmc_toy.hip", "sgmcmc_stream.hpp", "sgmcmc_bnn_fused.hip", "sgmcmc_svgd.hip", "sgmcmc_device.hpp",
                                              "sgmcmc_host.hpp")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "sgmcmc_hip.h"))
     stale = (not os.path.exists(_LIB_PATH)
@@ -99,6 +99,10 @@ def _declare(lib):
         f = getattr(lib, "sgmcmc_rsghmc_scalars_" + sfx)
         f.argtypes = [real, real, real, real, real, _vp, _vp]
         f.restype = _ci
+        f = getattr(lib, "sgmcmc_toy_chains_" + sfx)
+        f.argtypes = [_ci, _ci, ctypes.POINTER(ctypes.c_double), _ci] + [_vp] * 6 + [_sz, _ci, ctypes.POINTER(ctypes.c_double),
+                      _vp, _u64, _u64, ctypes.c_int64, _u64, _vp, _vp]
+        f.restype = _ci
         f = getattr(lib, "sgmcmc_philox_normal_" + sfx)
         f.argtypes = [_vp, _sz, _u64, _u64, _vp, _lp, _vp]
         f.restype = _ci
@@ -159,8 +163,8 @@ def _declare(lib):
     lib.sgmcmc_svgd_max_particles.restype = _ci
     lib.sgmcmc_step_stats_workspace_bytes.argtypes = [_sz]
     lib.sgmcmc_step_stats_workspace_bytes.restype = _sz
-    lib.sgmcmc_step_launch_blocks.argtypes = [_sz, _lp]
-    lib.sgmcmc_step_launch_blocks.restype = _sz
+    lib.sgmcmc_step_stats_records.argtypes = [_sz, _lp]
+    lib.sgmcmc_step_stats_records.restype = _sz
     lib.sgmcmc_step_stats_finish.argtypes = [_vp, _vp, _vp]
     lib.sgmcmc_step_stats_finish.restype = _ci
 

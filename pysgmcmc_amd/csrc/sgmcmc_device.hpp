@@ -209,8 +209,8 @@ struct SghmcOp {
         if (scalars_dev) { e2 = scalars_dev[0]; c1 = scalars_dev[1]; c3 = scalars_dev[2]; e4 = scalars_dev[3]; mdecay = scalars_dev[4]; }
     }
     // TSQ_ONLY: only sum theta'^2 (the one statistic the BNN loss head consumes)
-    template <bool TSQ_ONLY, typename RegsT>
-    __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
+    template <bool TSQ_ONLY, typename RegsT, typename ACC>
+    __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, ACC (&acc)[4]) const
     {
         // the quad's 4 terms are summed in T (4 adds), the running totals in double
         T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
@@ -220,8 +220,8 @@ struct SghmcOp {
             s0 += th * th;
             if constexpr (!TSQ_ONLY) { s1 += v * v; s2 += mi; s3 += mi * mi; }
         }
-        acc[0] += (double)s0;
-        if constexpr (!TSQ_ONLY) { acc[1] += (double)s1; acc[2] += (double)s2; acc[3] += (double)s3; }
+        acc[0] += (ACC)s0;
+        if constexpr (!TSQ_ONLY) { acc[1] += (ACC)s1; acc[2] += (ACC)s2; acc[3] += (ACC)s3; }
     }
     struct Regs { T th[4], v[4], gr[4], mi[4], tau[4], g[4], vh[4], rr[4], z[4]; };
 
@@ -293,8 +293,8 @@ struct SgldOp {
         nk.resolve();
         if (scalars_dev) { eps = scalars_dev[0]; A = scalars_dev[1]; a_eff = scalars_dev[2]; two_eps = scalars_dev[3]; sg_den = scalars_dev[4]; }
     }
-    template <bool TSQ_ONLY, typename RegsT>
-    __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
+    template <bool TSQ_ONLY, typename RegsT, typename ACC>
+    __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, ACC (&acc)[4]) const
     {
         T s0 = T(0), s2 = T(0), s3 = T(0);
 #pragma unroll
@@ -303,8 +303,8 @@ struct SgldOp {
             s0 += th * th;
             if constexpr (!TSQ_ONLY) { s2 += mi; s3 += mi * mi; }
         }
-        acc[0] += (double)s0;
-        if constexpr (!TSQ_ONLY) { acc[2] += (double)s2; acc[3] += (double)s3; }
+        acc[0] += (ACC)s0;
+        if constexpr (!TSQ_ONLY) { acc[2] += (ACC)s2; acc[3] += (ACC)s3; }
     }
     struct Regs { T th[4], gr[4], mi[4], tau[4], g[4], vh[4], rr[4], z[4]; };
 
@@ -371,8 +371,8 @@ struct RsghmcOp {
         nk.resolve();
         if (scalars_dev) { eps = scalars_dev[0]; mass = scalars_dev[1]; D = scalars_dev[2]; m2c2 = scalars_dev[3]; nscale = scalars_dev[4]; }
     }
-    template <bool TSQ_ONLY, typename RegsT>
-    __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, double (&acc)[4]) const
+    template <bool TSQ_ONLY, typename RegsT, typename ACC>
+    __device__ __forceinline__ void accumulate(const RegsT &R, int cnt, ACC (&acc)[4]) const
     {
         T s0 = T(0), s1 = T(0);
 #pragma unroll
@@ -381,8 +381,8 @@ struct RsghmcOp {
             s0 += th * th;
             if constexpr (!TSQ_ONLY) s1 += pp * pp;
         }
-        acc[0] += (double)s0;
-        if constexpr (!TSQ_ONLY) acc[1] += (double)s1;
+        acc[0] += (ACC)s0;
+        if constexpr (!TSQ_ONLY) acc[1] += (ACC)s1;
     }
     struct Regs { T th[4], p[4], gr[4], z[4]; };
 
@@ -429,7 +429,7 @@ struct NormalFillOp {
     static constexpr unsigned stats_mask = 0u;
     __device__ __forceinline__ void prepare() { nk.resolve(); }
     struct Regs { T z[4]; };
-    template <bool TSQ_ONLY> __device__ __forceinline__ void accumulate(const Regs &, int, double (&)[4]) const {}
+    template <bool TSQ_ONLY, typename ACC> __device__ __forceinline__ void accumulate(const Regs &, int, ACC (&)[4]) const {}
     template <bool NT> __device__ __forceinline__ void load_vec(size_t, Regs &) const {}
     __device__ __forceinline__ void load_part_(size_t, int, Regs &) const {}
     __device__ __forceinline__ void compute(size_t q, Regs &R) const { normal_quad(nk, q, R.z); }
@@ -445,7 +445,7 @@ struct MomentsOp {
     static constexpr unsigned stats_mask = 0u;
     __device__ __forceinline__ void prepare() {}
     struct Regs { T x[4], mu[4], m2[4]; };
-    template <bool TSQ_ONLY> __device__ __forceinline__ void accumulate(const Regs &, int, double (&)[4]) const {}
+    template <bool TSQ_ONLY, typename ACC> __device__ __forceinline__ void accumulate(const Regs &, int, ACC (&)[4]) const {}
     template <bool NT> __device__ __forceinline__ void load_vec(size_t q, Regs &R) const
     { load_quad<NT>(theta, q, R.x); load_quad<NT>(mean, q, R.mu); load_quad<NT>(m2, q, R.m2); }
     __device__ __forceinline__ void load_part_(size_t q, int cnt, Regs &R) const

@@ -756,12 +756,13 @@ int sgmcmc_device_count(void)
     return n;
 }
 
+// header + one record per block of the smallest block size (64 lanes)
 size_t sgmcmc_step_stats_workspace_bytes(size_t n) { return (max_grid_for(n) + 1) * 4 * sizeof(double); }
-size_t sgmcmc_step_launch_blocks(size_t n, const sgmcmc_launch_t *launch_in)
+size_t sgmcmc_step_stats_records(size_t n, const sgmcmc_launch_t *launch_in)
 {
     LaunchCfg cfg;
     if (!launch_in || resolve_launch(launch_in, cfg) != 0) return 0;
-    if (cfg.block_threads <= 0) { fail(SGMCMC_EINVAL, "step_launch_blocks: launch.block_threads must be explicit"); return 0; }
+    if (cfg.block_threads <= 0) { fail(SGMCMC_EINVAL, "step_stats_records: launch.block_threads must be explicit"); return 0; }
     const size_t want = want_blocks(n, cfg.block_threads, cfg.qpt);
     return want < (size_t)cfg.max_blocks ? want : (size_t)cfg.max_blocks;
 }

@@ -13,6 +13,7 @@
 #include <hip/hip_ext.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "sgmcmc_hip.h"
 
@@ -41,27 +42,27 @@ struct StreamExtras {
     T mom_inv = T(0);             // 1 / count (count includes this sample)
 };
 
-// "LDS-staged reduction, wavefront shuffles for the partial sums": every lane keeps its running sums in registers, a
-// wave reduces them with DPP lane moves (row shifts + row broadcasts, 64 lanes), the waves of a block meet in LDS, and
-// lanes 0..3 write ONE 32-byte record {sum theta'^2, sum V'^2, sum minv, sum minv^2} per block -- block-major, so the
-// record is a single 32-byte sector write (round 2 wrote statistic-major: four separate 8-byte sector writes per block,
-// +0.25 B/param of write traffic at 128-lane blocks). sgmcmc_step_stats_finish adds the records in block order: the
-// result is bit-reproducible for a given launch geometry. No extra HBM pass: the values are already in registers.
+// Fused step statistics ("LDS-staged reduction, wavefront shuffles for the partial sums"): every lane holds the sums of
+// its quad in registers, a wave combines them with DPP lane moves (row shifts + row broadcasts across the 64 lanes, VALU
+// only), the waves of a block meet in LDS, and lanes 0..3 write ONE 32-byte record {sum theta'^2, sum V'^2, sum minv,
+// sum minv^2} per block -- block-major, i.e. a single 32-byte sector write. sgmcmc_step_stats_finish adds the records in
+// block order: bit-reproducible for a given launch geometry, no extra HBM pass.
+// History (profiles/r03_stats_variant_cost.txt): round 2 wrote statistic-major partials (four 8-byte sector writes per
+// block: +0.25 B/param of write traffic at 128-lane blocks). One record per WAVE without LDS and barrier was tried in
+// round 3 and was no faster (relativistic step at 49.8 M: 169-172 vs 165-168 us) while doubling the record bytes.
 // T = the kernel's dtype: f32 kernels reduce across the wave in f32 (6 DPP adds per statistic), f64 kernels in f64.
 // MASK = the statistics reduced (the others are written as 0 without any reduction work).
-template <typename T, unsigned MASK>
-__device__ __forceinline__ void stats_block_write(double (&acc)[4], double *__restrict__ part, unsigned part_base,
+template <typename T, unsigned MASK, typename ACC>
+__device__ __forceinline__ void stats_block_write(ACC (&acc)[4], double *__restrict__ part, unsigned part_base,
                                                   unsigned part_total)
 {
     __shared__ T lds[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if constexpr (((MASK >> 0) & 0xfu) != 0u) {
-            if ((MASK >> k) & 1u) {
-                T v = wave_sum_dpp_lane63((T)acc[k]);
-                if (lane == 63) lds[wave][k] = v;
-            }
+        if ((MASK >> k) & 1u) {
+            T v = wave_sum_dpp_lane63((T)acc[k]);
+            if (lane == 63) lds[wave][k] = v;
         }
     }
     __syncthreads();
@@ -104,7 +105,10 @@ __global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t n
     op.prepare();
     const size_t G = (size_t)gridDim.x * blockDim.x;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    // running sums of this lane: the single-pass variant adds at most one quad (+ the ragged tail) -> the kernel's own
+    // dtype, no f64 round trip in front of the wave reduction; the looping variants add many quads -> double
+    typedef typename std::conditional<LOOP, double, T>::type acc_t;
+    acc_t acc[4] = {acc_t(0), acc_t(0), acc_t(0), acc_t(0)};
     constexpr bool stats = STATS != 0;
     constexpr bool tsq_only = STATS == 2;
     if constexpr (!LOOP) {
@@ -116,6 +120,10 @@ __global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t n
             T mu[4], m2[4];
             op.template load_vec<NT>(gid, R);
             if constexpr (MOM) { load_quad<NT>(ex.mom_mean, gid, mu); load_quad<NT>(ex.mom_m2, gid, m2); }
+            // every load is ISSUED before any arithmetic: Philox + Box-Muller (which need no loaded value) then run under
+            // the memory latency. Without the fence the scheduler sank the loads below the Philox rounds in some
+            // variants (relativistic step with statistics: 168 instead of 158 us at 49.8 M parameters).
+            __builtin_amdgcn_sched_barrier(0);
             op.compute(gid, R);
             op.template store_vec<NT>(gid, R);
             if constexpr (MOM) {

@@ -15,7 +15,7 @@ from pysgmcmc_amd._lib import SgmcmcLibraryError, check, lib
 __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
-    "LaunchConfig", "KernelEvents", "StepOpts", "step_launch_blocks", "step_scalars", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
+    "LaunchConfig", "KernelEvents", "StepOpts", "step_stats_records", "step_scalars", "toy_chains", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
     "bnn_fused_sgld_steps", "window_gather", "tanh_rowdot", "bnn_head_last_layer_backward", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
 ]
 
@@ -225,13 +225,13 @@ def _opts(opts, like):
     return ctypes.byref(opts._c)
 
 
-def step_launch_blocks(n, launch):
+def step_stats_records(n, launch):
     """Number of blocks (= statistics records) a vector-path step launch of ``n`` elements uses under ``launch``
     (a :class:`LaunchConfig` with an explicit ``block_threads``)."""
     import ctypes
-    blocks = int(lib().sgmcmc_step_launch_blocks(int(n), ctypes.byref(launch._c)))
+    blocks = int(lib().sgmcmc_step_stats_records(int(n), ctypes.byref(launch._c)))
     if blocks == 0:
-        check(-1, "sgmcmc_step_launch_blocks")
+        check(-1, "sgmcmc_step_stats_records")
     return blocks
 
 
@@ -281,6 +281,31 @@ def rsghmc_step(theta, p, grad_cost, eps, mass, c, D, b_hat, xi=None, seed=0, st
                float(c), float(D), float(b_hat), float(grad_decay), _ptr(xi, theta), int(seed), int(step), _ctr(step_dev), *_stats(stats),
                _opts(opts, theta), _launch(launch), _stream(theta))
     check(rc, "sgmcmc_rsghmc_step")
+
+
+def toy_chains(sampler, target, target_params, theta, mom, tau, g, v_hat, minv, scalars, seeds, first_step, n_steps,
+               burn_in_steps, keep_every=1, kept=None):
+    """``n_steps`` steps of ``theta.shape[0]`` independent chains on a built-in toy target in one launch
+    (``sgmcmc_toy_chains_*``, see include/sgmcmc_hip.h). ``theta`` etc.: ``[n_chains, dim]`` device tensors;
+    ``seeds``: int64 device tensor ``[n_chains]``; ``kept``: ``[ceil(n_steps / keep_every), n_chains, dim]`` or None."""
+    import ctypes
+    f = getattr(lib(), "sgmcmc_toy_chains_" + _sfx(theta))
+    n_chains, dim = int(theta.shape[0]), int(theta.shape[1])
+    tp = [float(v) for v in target_params]
+    k = {0: len(tp) // 3, 1: 0, 2: len(tp) // 2}[int(target)]
+    if seeds.dtype != torch.int64 or seeds.numel() != n_chains:
+        raise TypeError("seeds must be an int64 device tensor with one entry per chain")
+    n_kept = (int(n_steps) + int(keep_every) - 1) // int(keep_every)
+    if kept is not None and (kept.numel() != n_kept * n_chains * dim or kept.dtype != theta.dtype):
+        raise ValueError("kept must hold ceil(n_steps / keep_every) x n_chains x dim elements of theta's dtype")
+    arr = (ctypes.c_double * max(len(tp), 1))(*tp)
+    sc = (ctypes.c_double * 5)(*([float(v) for v in scalars] + [0.0] * (5 - len(scalars))))
+    with _on(theta):
+        rc = f(int(sampler), int(target), arr, k, _ptr(theta), _ptr(mom, theta), _ptr(tau, theta), _ptr(g, theta),
+               _ptr(v_hat, theta), _ptr(minv, theta), n_chains, dim, sc, _ptr(seeds), int(first_step), int(n_steps),
+               int(burn_in_steps), int(keep_every), _ptr(kept), _stream(theta))
+    check(rc, "sgmcmc_toy_chains")
+    return kept
 
 
 def philox_normal(out, seed, step, step_dev=None, launch=None):

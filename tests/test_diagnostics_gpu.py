@@ -13,6 +13,7 @@ import json
 import os
 import socket
 import subprocess
+import time
 import sys
 from itertools import islice
 
@@ -241,6 +242,8 @@ def test_bench_n2_path_on_one_gpu(gpu):
     assert rc["mode"] == "reduce_scatter"                               # the default: parameter-sharded exchange
     assert d["rhat"]["max"] >= d["rhat"]["mean"] > 0
     assert d["roofline"]["launches_timed"] == 24 and 0 < d["roofline"]["frac"] < 1.2
+    # every 2nd step's update launch also carries the Welford moments (K4 fused): those launches are timed apart
+    assert d["roofline"]["launches_in_the_rate"] == 12 and d["roofline"]["with_fused_moments"]["launches"] == 12
     assert "cpu_baseline" not in d
 
 
@@ -253,6 +256,47 @@ def test_bench_n2_driver_arguments_contain_one_exchange(gpu):
     assert d["steps"] == 20 and d["warmup"] == 5 and d["config"]["rhat_every"] == 14 and d["config"]["moments_every"] == 10
     assert d["rccl"]["exchanges_timed"] == 1 and d["rccl"]["rhat_exchange_ms"]["start_to_finish"] > 0
     assert d["rhat"] is not None and d["roofline"]["launches_timed"] == 20
+
+
+def _bench_self_launched(n, extra, timeout=800):
+    """``python3 bench.py --gpus N ...`` with NO launcher, as the driver starts the 1-GPU bench: the process spawns its
+    own ranks."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + extra + [
+        "--backend", "gloo", "--all-ranks-on-gpu0", "--no-update-only"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    return res, [l for l in res.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_starts_its_own_ranks_without_a_launcher(gpu, n):
+    """``python3 bench.py --gpus N`` without torch.distributed.run must not exit non-zero -- the parent
+    (which never touches the GPU) spawns N fresh ranks, rank 0 prints the ONE JSON line, exit code 0. All ranks on
+    cuda:0 over gloo here (one GPU on the box); 8 ranks = configs[3]'s shape."""
+    res, lines = _bench_self_launched(n, ["--steps", "6", "--warmup", "2"])
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["rccl"]["ranks"] == n and d["rccl"]["exchanges_timed"] == 1 and d["value"] > 0
+    assert d["config"]["chains"] == n and d["rhat"] is not None
+    assert "roofline_unoverlapped" in d and "step_breakdown_us" in d      # rank 0's extra legs ran after the group was torn down
+
+
+@pytest.mark.timeout(600)
+def test_self_launched_bench_propagates_a_failing_rank_and_stops_the_others(gpu):
+    """A rank that dies takes the job down with its exit code instead of leaving the other ranks in a collective: the
+    workload name is valid for the parent's argument parser but rank 1 is told to fail (BENCH_TEST_FAIL_RANK)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo",
+           "--all-ranks-on-gpu0", "--launch-timeout", "300"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_TEST_FAIL_RANK="1")
+    t0 = time.time()
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=500)
+    assert res.returncode == 7, (res.returncode, res.stderr[-2000:])
+    assert "rank 1 exited with code 7" in res.stderr and not [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert time.time() - t0 < 400
 
 
 RCCL_WORKER = r"""

@@ -56,7 +56,7 @@ def test_slice_launches_equal_the_single_launch(gpu, dt, kind, adapt):
     cfg = kernels.LaunchConfig(block_threads=128)
     cuts = [0, 4 * 1000, 4 * 9001, 4 * 9002, n]
     spans = list(zip(cuts[:-1], cuts[1:]))
-    blocks = [kernels.step_launch_blocks(hi - lo, cfg) for lo, hi in spans]
+    blocks = [kernels.step_stats_records(hi - lo, cfg) for lo, hi in spans]
     bases = np.concatenate([[0], np.cumsum(blocks)[:-1]])
     for i in (2, 0, 3, 1):                                  # any order
         lo, hi = spans[i]
@@ -117,7 +117,7 @@ def test_theta_sq_only_statistics(gpu, kind, adapt):
     assert np.isclose(fa[0], float((a["theta"].double() ** 2).sum()), rtol=5e-7)
     recs = sb.workspace.view(torch.float64)
     nrec = int(sb.workspace.view(torch.int64)[0])
-    assert nrec == (n // 4 + 255) // 256
+    assert nrec == (n // 4 + 255) // 256                          # one record per block
     rec = recs[4:4 + 4 * nrec].view(nrec, 4)
     assert float(rec[:, 0].sum()) == pytest.approx(fb[0], rel=1e-12) and float(rec[:, 1:].abs().sum()) == 0.0
 
@@ -213,3 +213,43 @@ def test_overlapped_update_gives_the_same_chain(gpu):
                 assert torch.equal(base.arena.row(row), other.arena.row(row)), (ctor.__name__, row)
             assert np.allclose(c, cb, rtol=1e-6, atol=0)
             assert m.count == mb.count == 4 and torch.equal(m.mean, mb.mean) and torch.equal(m.m2, mb.m2)
+
+
+def test_burn_in_without_minv_stores_gives_the_same_chain(gpu):
+    """``store_minv_every_step = False``: only the LAST burn-in step writes minv (it is the one value the frozen steps
+    consume, pysgmcmc/samplers/base_classes.py:449-454). Same chain bit for bit through the switch, in every stepping
+    mode; ``.minv`` read during burn-in comes from v_hat."""
+    from pysgmcmc_amd.samplers import SGHMCSampler, SGLDSampler
+    for ctor in (SGHMCSampler, SGLDSampler):
+        for graph in (False, True, "full"):
+            kw = dict(burn_in_steps=6, scale_grad=400.0)
+            a, _, ca = _bnn_chain(gpu, ctor, overlap=False, graph=graph, steps=11, **kw)
+            b = None
+
+            def chain_b():
+                from pysgmcmc_amd.data_batches import Placeholder, generate_batches
+                from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
+                from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+                rng = np.random.RandomState(0)
+                X, y = rng.rand(400, 16), rng.rand(400)
+                xp, yp = Placeholder(dtype=torch.float32, device=gpu), Placeholder(dtype=torch.float32, device=gpu)
+                params = init_mlp_params(16, hidden=(96, 128, 64), seed=5, dtype=torch.float32, device=gpu)
+                s = ctor(params=params, cost_fun=BNNCost(xp, yp, batch_size=32, n_examples=400),
+                         batch_generator=generate_batches(X, y, xp, yp, batch_size=32, seed=2),
+                         stepsize_schedule=ConstantStepsizeSchedule(0.01), session=gpu, dtype=torch.float32, seed=9, **kw)
+                s.sample_format = "view"
+                s.use_hip_graph = graph
+                s.collect_stats = "theta_sq"
+                s.store_minv_every_step = False
+                return s
+            b = chain_b()
+            minv0 = b.arena.row("minv").clone()
+            for i in range(11):
+                next(b)
+                if i == 3:
+                    assert torch.equal(b.arena.row("minv"), minv0)                     # burn-in steps left minv alone ...
+                    want = 1.0 / torch.sqrt(b.arena.row("v_hat"))
+                    got = torch.from_numpy(np.concatenate([m.ravel() for m in b.minv])).to(gpu)
+                    assert torch.allclose(got, want, rtol=1e-6)                          # ... and .minv comes from v_hat
+            for row in ("theta", "minv", "tau", "g", "v_hat"):
+                assert torch.equal(a.arena.row(row), b.arena.row(row)), (ctor.__name__, graph, row)

@@ -33,9 +33,15 @@ for r in range(reps):
     flush(); kernels.sgld_step(theta, grad, None, None, None, minv, None, 0.01, 1.0, 1e5, False, seed=1, step=r)
     flush(); kernels.sgld_step(theta, grad, tau, gg, vh, minv, None, 0.01, 1.0, 1e5, True, seed=1, step=r)
     flush(); kernels.rsghmc_step(theta, V, grad, 0.001, 1.0, 1.0, 1.0, 0.0, seed=1, step=r)
-    # the variants the samplers launch in the pipeline: fused step statistics (STATS = true)
-    flush(); kernels.sghmc_step(theta, V, grad, None, None, None, minv, None, 0.01, 1e5, 0.05, False, seed=1, step=r, stats=st)
-    flush(); kernels.sgld_step(theta, grad, None, None, None, minv, None, 0.01, 1.0, 1e5, False, seed=1, step=r, stats=st)
-    flush(); kernels.rsghmc_step(theta, V, grad, 0.001, 1.0, 1.0, 1.0, 0.0, seed=1, step=r, stats=st)
+    # the variants the samplers launch in the pipeline: fused step statistics (STATS = 1: all of the operator's, 2: sum theta^2
+    # only), the fused Welford moments (MOM), and the burn-in step that skips the minv store
+    tsq = dict(theta_sq_only=True)
+    for o in (None, tsq):
+        flush(); kernels.sghmc_step(theta, V, grad, None, None, None, minv, None, 0.01, 1e5, 0.05, False, seed=1, step=r, stats=st, opts=o)
+        flush(); kernels.sgld_step(theta, grad, None, None, None, minv, None, 0.01, 1.0, 1e5, False, seed=1, step=r, stats=st, opts=o)
+        flush(); kernels.rsghmc_step(theta, V, grad, 0.001, 1.0, 1.0, 1.0, 0.0, seed=1, step=r, stats=st, opts=o)
+    flush(); kernels.sghmc_step(theta, V, grad, None, None, None, minv, None, 0.01, 1e5, 0.05, False, seed=1, step=r, stats=st,
+                                opts=dict(theta_sq_only=True, moments=(mean, m2, r + 2)))
+    flush(); kernels.sghmc_step(theta, V, grad, tau, gg, vh, minv, None, 0.01, 1e5, 0.05, True, seed=1, step=r, stats=st, opts=tsq)
 torch.cuda.synchronize()
 print("probe done n=%d reps=%d" % (n, reps))

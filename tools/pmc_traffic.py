@@ -47,25 +47,35 @@ def _find(d, suffix):
 
 
 def medians(directory, counter):
+    """Median counter value per kernel variant. Key = operator + "|stats" (STATS = 1), "|tsq" (STATS = 2: sum theta^2
+    only), "|mom" (fused Welford moments). Template args: <Op, QPT, NT, STATS, LOOP, MOM>."""
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     full = {}
     for r in csv.DictReader(open(_find(directory, "counter_collection.csv"))):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"stream_quads_vec<(?:\(anonymous namespace\)::)?(\w+Op<[^>]*>), *(\d+), *(\w+), *(\w+), *(\w+)>",
+        m = re.search(r"stream_quads_vec<(?:\(anonymous namespace\)::)?(\w+Op<[^>]*>), *(\d+), *(\w+), *(\d+), *(\w+), *(\w+)>",
                       r["Kernel_Name"])
         if not m or m.group(1) not in MODES:
             continue
-        key = m.group(1) + ("|stats" if m.group(4) == "true" else "")
+        key = m.group(1) + {"0": "", "1": "|stats", "2": "|tsq"}[m.group(4)] + ("|mom" if m.group(6) == "true" else "")
         per[key][r["Dispatch_Id"]] += float(r["Counter_Value"])
-        full[key] = "stream_quads_vec<%s,%s,%s,%s,%s>" % (m.group(1).replace(" ", ""), *m.groups()[1:])
+        full[key] = "stream_quads_vec<%s,%s,%s,%s,%s,%s>" % (m.group(1).replace(" ", ""), *m.groups()[1:])
     return {k: (float(np.median(list(v.values()))), len(v)) for k, v in per.items()}, full
+
+
+def kernel_source_hash():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.kernel_source_hash()
 
 
 def main():
     out = sys.argv[1]
     doc = {"collected": datetime.date.today().isoformat(),
            "build": subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
+           # bench.py reports roofline.traffic from this table only while the kernel sources are the ones it was collected with
+           "kernel_source_hash": os.environ.get("PMC_KERNEL_SOURCE_HASH") or kernel_source_hash(),
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/pmc_probe.py (1 GiB "
                      "cache flush between launches); KiB * 1024; FETCH_SIZE doubled (gfx950: half of a 16 B/lane "
                      "coalesced read stream is reported); medians over the dispatches of each kernel",
@@ -81,6 +91,8 @@ def main():
         entry = {}
         variants = [(op, mode, rd, wr) for op, (mode, rd, wr) in MODES.items()]
         variants += [(op + "|stats", mode + "_stats", rd, wr) for op, (mode, rd, wr) in MODES.items()]
+        variants += [(op + "|tsq", mode + "_tsq", rd, wr) for op, (mode, rd, wr) in MODES.items()]
+        variants += [(op + "|tsq|mom", mode + "_tsq_mom", rd + 8, wr + 8) for op, (mode, rd, wr) in MODES.items()]
         for op, mode, rd, wr in variants:
             if op not in fetch or op not in write:
                 continue

@@ -12,12 +12,13 @@ for n in (10_002_434, 49_826_818):
     minv = torch.rand(n, device=dev, generator=g) * 1.5 + 0.5
     st = kernels.StepStats(n, dev)
     calls = {
-        "sghmc_frozen": lambda i, s: kernels.sghmc_step(theta, V, grad, None, None, None, minv, None, 0.01, 1e5, 0.05, False, seed=1, step=i, stats=s),
-        "sgld_frozen": lambda i, s: kernels.sgld_step(theta, grad, None, None, None, minv, None, 1e-3, 1.0, 1e5, False, seed=1, step=i, stats=s),
-        "rsghmc": lambda i, s: kernels.rsghmc_step(theta, V, grad, 1e-3, 1.0, 1.0, 1.0, 0.0, seed=1, step=i, stats=s),
+        "sghmc_frozen": lambda i, s, o: kernels.sghmc_step(theta, V, grad, None, None, None, minv, None, 0.01, 1e5, 0.05, False, seed=1, step=i, stats=s, opts=o),
+        "sgld_frozen": lambda i, s, o: kernels.sgld_step(theta, grad, None, None, None, minv, None, 1e-3, 1.0, 1e5, False, seed=1, step=i, stats=s, opts=o),
+        "rsghmc": lambda i, s, o: kernels.rsghmc_step(theta, V, grad, 1e-3, 1.0, 1.0, 1.0, 0.0, seed=1, step=i, stats=s, opts=o),
     }
-    for name, call in calls.items():
-        for label, s in (("plain", None), ("stats", st)):
+    for name, call0 in calls.items():
+        for label, s, o in (("plain", None, None), ("stats", st, None), ("tsq", st, dict(theta_sq_only=True))):
+            call = lambda i, s, call0=call0, o=o: call0(i, s, o)
             for i in range(10):
                 call(i, s)
             torch.cuda.synchronize()
