@@ -482,7 +482,7 @@ def self_launch(args):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this pool
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, os.path.abspath(sys.argv[0])] + sys.argv[1:]      # this script (or one that borrows the launcher)
     ranks = []
     for r in range(n):
         ranks.append(subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0"),
@@ -490,17 +490,18 @@ def self_launch(args):
     deadline = time.monotonic() + args.launch_timeout
     rc, why = 0, None
     try:
-        while rc == 0 and any(p.poll() is None for p in ranks):
-            for r, p in enumerate(ranks):
-                code = p.poll()
-                if code not in (None, 0):
-                    rc, why = code, "rank %d exited with code %d" % (r, code)
-                    break
-            if rc == 0 and time.monotonic() > deadline:
+        while True:
+            codes = [p.poll() for p in ranks]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc, why = bad[0][1], "rank %d exited with code %d" % bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
                 rc, why = 124, "ranks still running after --launch-timeout %.0f s" % args.launch_timeout
+                break
             time.sleep(0.05)
-        if rc == 0:
-            rc = next((p.returncode for p in ranks if p.returncode), 0)
     finally:
         for p in ranks:                                        # only the process groups started above, by their exact ids
             if p.poll() is None:
@@ -926,7 +927,7 @@ def main():
             "gemm": round(g_us, 1), "small_launches": round(c_us - g_us, 1), "update": round(float(u_us.mean()), 1),
             "serial_sum": round(c_us + float(u_us.mean()), 1), "serial_step_measured": round(serial_step_us, 1),
             "timed_region_step_median": None if meas_us is None else round(meas_us, 1),
-            "hidden_by_overlap": None if meas_us is None else round(serial_step_us - meas_us, 1),
+            "hidden_by_overlap": round(serial_step_us - meas_us, 1) if (meas_us is not None and launches_per_step > 1) else None,
             "gemm_tflops": round(g_flops / (g_us * 1e-6) / 1e12, 1),
             "gemm_frac_of_fp32_mfma_peak": round(g_flops / (g_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3),
             "gemm_flop_per_step": int(g_flops),

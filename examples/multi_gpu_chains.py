@@ -1,5 +1,6 @@
-"""configs[3] in ~40 lines: one independent SGHMC chain per GPU, cross-chain R-hat over RCCL every 100 steps.
+"""configs[3] in ~50 lines: one independent SGHMC chain per GPU, cross-chain R-hat over RCCL every 100 steps.
 
+    python examples/multi_gpu_chains.py --gpus 8          # starts its own ranks, like `bench.py --gpus 8`
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/multi_gpu_chains.py
 
 (The reference runs its chains one after another in fresh TF graphs, pysgmcmc/diagnostics/sample_chains.py:369-382, and
@@ -7,6 +8,14 @@ hands them to pymc3.diagnostics.gelman_rubin.) Rehearsal on ONE GPU: add `--gloo
 """
 import os
 import sys
+
+if "WORLD_SIZE" not in os.environ and "--gpus" in sys.argv:
+    # no launcher: start the ranks from here, before anything in this process touches the GPU (bench.py's own entry)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import argparse
+    import bench
+    n = int(sys.argv[sys.argv.index("--gpus") + 1])
+    sys.exit(bench.self_launch(argparse.Namespace(gpus=n, launch_timeout=900.0)))
 
 import torch
 import torch.distributed as dist
@@ -19,7 +28,7 @@ from pysgmcmc_amd.samplers import SGHMCSampler  # noqa: E402
 from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule  # noqa: E402
 
 if int(os.environ.get("WORLD_SIZE", "1")) < 2:
-    print("multi_gpu_chains.py needs >= 2 ranks: launch it through torch.distributed.run (see the docstring)")
+    print("multi_gpu_chains.py needs >= 2 ranks: `--gpus N` or torch.distributed.run (see the docstring)")
     sys.exit(0)
 one_gpu = "--gloo-one-gpu" in sys.argv
 rank, local = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
@@ -41,15 +50,17 @@ sampler.sample_format = "view"                                          # sample
 sampler.use_hip_graph = True
 moments = ChainMoments(sampler.arena.n, dev)
 exchange = RhatExchange(sampler.arena.n, dev, mode="reduce_scatter")    # half the xGMI traffic of an all-reduce
-for step in range(1, 1201):
-    next(sampler)
-    if step > 200 and step % 10 == 0:
-        moments.update(sampler.arena.row("theta"))                      # Welford mean / M2 of this chain (kernel K4)
-    if step > 400 and step % 100 == 0:
+N_STEPS = 1200
+for step in range(1, N_STEPS + 1):
+    if step == 201:
+        sampler.attach_moments(moments, every=10)                       # Welford mean / M2 of this chain, folded into the
+    next(sampler)                                                       # update launch of every 10th step (K4 in K1)
+    if step > 400 and step % 100 == 0 and step + 50 <= N_STEPS:         # (an exchange started now is collected at +50)
         exchange.start(moments)                                         # pack + async reduce-scatter on RCCL's stream
     elif exchange.pending and step % 100 == 50:
         exchange.finish()                                               # stream-level wait, R-hat of this rank's shard
         if rank == 0:
             print("step %4d  R-hat over %d chains: %s" % (step, dist.get_world_size(), exchange.summary.as_dict()))
+assert not exchange.pending                                             # nothing in flight when the group is torn down
 dist.barrier()
 dist.destroy_process_group()

@@ -165,6 +165,10 @@ class RhatExchange(object):
         return self._work is not None
 
     def start(self, moments):
+        if moments.mean.dtype != self.pack.dtype:
+            # the pack kernel is chosen from the moments' dtype: an f64 pack into this f32 buffer would overrun it
+            raise TypeError("RhatExchange was built for %s but the chain's moments are %s: pass dtype=%s" % (
+                self.pack.dtype, moments.mean.dtype, moments.mean.dtype))
         dist = _dist()
         if dist is None or dist.get_world_size(self.group) < 2:
             raise RuntimeError("RhatExchange needs an initialised process group with >= 2 chains")

@@ -23,7 +23,6 @@ trainable tensor including biases and ``output_bias`` (``:386``).
     allocated, gathered or copied between the backward pass and the fused update.
 """
 import copy
-import itertools
 import logging
 import math
 from collections import deque
@@ -496,133 +495,116 @@ class BayesianNeuralNetwork(object):
             return torch.device(self.session)
         return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
-    def train(self, X, y, *args, **kwargs):
-        """Sample ``n_nets`` networks from the posterior given data ``X (N, D)``, ``y (N,)``
-        (loop semantics of ``bayesian_neural_network.py:391-533``, including the
-        ``iteration_index <= burn_in_steps`` off-by-one at :514)."""
-        assert X.ndim == 2 and X.shape[0] == y.shape[0]
-        start_time = time()
+    # -- training: an event-driven loop ------------------------------------------------------------------
+    # The reference visits the host once per sample (bayesian_neural_network.py:508-531) although only a few
+    # iterations do anything there: every 512th burn-in iteration logs, every `sample_steps`-th sampling iteration
+    # logs and keeps a network. Here the chain is ADVANCED FROM EVENT TO EVENT -- by the fused whole-step kernel
+    # (many steps per launch, many chains per launch) or by next(sampler) -- and the host only looks at the events.
+
+    BURN_IN_LOG_EVERY = 512                      # bayesian_neural_network.py:505
+
+    def _is_burn_in_iteration(self, i):
+        return i <= self.burn_in_steps           # `<=`: the reference's off-by-one against the sampler's `<` (:514, quirk Q8)
+
+    def _host_events(self):
+        """Ascending iteration indices at which the loop must look at the chain (log and/or collect), ending with the
+        last iteration of the budget."""
+        last = self.n_iters - 1
+        for i in range(self.n_iters):
+            every = self.BURN_IN_LOG_EVERY if self._is_burn_in_iteration(i) else self.sample_steps
+            if i % every == 0 or i == last:
+                yield i
+
+    def _log_full_training_error(self, i, clock):
+        with torch.no_grad():
+            nll, mse = self.cost.negative_log_likelihood(self.network_params, self._X_full, self._Y_full)
+        if self._is_burn_in_iteration(i):        # the reference's two log lines (:492-503)
+            logging.info("Iter {:8d} : NLL = {:.4e} MSE = {:.4e} Samples = {} Time = {:5.2f}".format(
+                i, float(nll), float(mse), len(self.samples), time() - clock))
+        else:
+            logging.info("Iter {:8d} : NLL = {:.4e} MSE = {:.4e} Time = {:5.2f}".format(i, float(nll), float(mse), time() - clock))
+
+    def _visit(self, i, clock):
+        """Host work of event iteration ``i``; True once ``n_nets`` networks are kept."""
+        every = self.BURN_IN_LOG_EVERY if self._is_burn_in_iteration(i) else self.sample_steps
+        if i % every:
+            return False                         # the closing iteration of the budget: nothing to do
+        self._log_full_training_error(i, clock)
+        if self._is_burn_in_iteration(i):
+            return False
+        chains = self.chains.samplers if self.chains is not None else [self.sampler]
+        for chain in chains:                     # one network per chain and collection point
+            self.samples.append([v.clone() for v in chain.arena.views("theta")])
+            if len(self.samples) == self.n_nets:
+                return True
+        return False
+
+    def _adopt_data(self, X, y, device):
         self.X, self.y = X, y
         if self.normalize_input:
             self.X, self.x_mean, self.x_std = zero_mean_unit_var_normalization(self.X)
         if self.normalize_output:
             self.y, self.y_mean, self.y_std = zero_mean_unit_var_normalization(self.y)
-        n_datapoints, n_inputs = X.shape
-        device = self._device()
+        self._X_full = torch.as_tensor(self.X, dtype=self._torch_dtype, device=device)
+        self._Y_full = torch.as_tensor(self.y, dtype=self._torch_dtype, device=device).reshape(-1, 1)
+
+    def _build_sampler(self, n_datapoints, n_inputs, device):
         self.X_Minibatch = Placeholder(dtype=self._torch_dtype, shape=(None, n_inputs), name="X_Minibatch", device=device)
         self.Y_Minibatch = Placeholder(dtype=self._torch_dtype, name="Y_Minibatch", device=device)
-
         self.network_params = init_mlp_params(n_inputs, hidden=self.hidden, seed=self.seed,
                                               dtype=self._torch_dtype, device=device)
-        names = []
-        for l in range(len(self.hidden) + 1):
-            names += ["fc_layer_%d/kernel:0" % (l + 1), "fc_layer_%d/bias:0" % (l + 1)]
-        names.append("output_bias:0")
-        self.network_param_names = names          # torch tensors cannot carry a `.name` like tf.Variables
+        # torch tensors cannot carry a `.name` like tf.Variables: the names TF would give the default net's variables
+        self.network_param_names = [n for l in range(1, len(self.hidden) + 2)
+                                    for n in ("fc_layer_%d/kernel:0" % l, "fc_layer_%d/bias:0" % l)] + ["output_bias:0"]
         self.cost = BNNCost(self.X_Minibatch, self.Y_Minibatch, self.batch_size, n_datapoints)
-        cost_fun = self.cost
-        if not self.fused_cost:
-            cost_fun = lambda params, *_: self.cost(params)   # hides cost_and_grad -> autograd path
-        self.samples.clear()
-
-        self.sampler_kwargs.update({
-            "params": self.network_params,
-            "cost_fun": cost_fun,
-            "batch_generator": self.batch_generator(
-                x=self.X, x_placeholder=self.X_Minibatch,
-                y=self.y, y_placeholder=self.Y_Minibatch,
-                batch_size=self.batch_size,
-                seed=self.seed
-            ),
-            "session": device,
-            "seed": self.seed,
-            "dtype": self.dtype,
-            "stepsize_schedule": self.stepsize_schedule,
-        })
+        # fused_cost = False hides cost_and_grad, so the sampler differentiates the cost with autograd
+        cost_fun = self.cost if self.fused_cost else (lambda params, *_: self.cost(params))
+        kw = self.sampler_kwargs
+        kw.update(params=self.network_params, cost_fun=cost_fun, session=device, seed=self.seed, dtype=self.dtype,
+                  stepsize_schedule=self.stepsize_schedule,
+                  batch_generator=self.batch_generator(x=self.X, x_placeholder=self.X_Minibatch, y=self.y,
+                                                       y_placeholder=self.Y_Minibatch, batch_size=self.batch_size,
+                                                       seed=self.seed))
         if Sampler.is_burn_in_mcmc(self.sampling_method):
-            self.sampler_kwargs.update({
-                "scale_grad": n_datapoints,
-                "burn_in_steps": self.burn_in_steps,
-            })
-        self.sampler = Sampler.get_sampler(self.sampling_method, **self.sampler_kwargs)
-        # samples are kept on the device; no per-step D2H copy of all parameters
-        self.sampler.sample_format = "view"
-        self.sampler.param_names = list(names)
+            kw.update(scale_grad=n_datapoints, burn_in_steps=self.burn_in_steps)        # :451-457
+        self.sampler = Sampler.get_sampler(self.sampling_method, **kw)
+        self.sampler.sample_format = "view"      # samples stay on the device; no per-step D2H copy of all parameters
+        self.sampler.param_names = list(self.network_param_names)
+        self.sampler.collect_stats = "theta_sq"  # the loss head is the only consumer of the fused statistics
         self.sampler.use_hip_graph = bool(self.use_hip_graph and self.fused_cost and device.type == "cuda")
-        X_full = torch.as_tensor(self.X, dtype=self._torch_dtype, device=device)
-        Y_full = torch.as_tensor(self.y, dtype=self._torch_dtype, device=device).reshape(-1, 1)
 
-        logging.info("Starting sampling")
-
-        def log_full_training_error(iteration_index, is_sampling):
-            with torch.no_grad():
-                total_nll, total_mse = self.cost.negative_log_likelihood(self.network_params, X_full, Y_full)
-            seconds_elapsed = time() - start_time
-            if is_sampling:
-                logging.info("Iter {:8d} : NLL = {:.4e} MSE = {:.4e} "
-                             "Time = {:5.2f}".format(iteration_index, float(total_nll), float(total_mse),
-                                                     seconds_elapsed))
-            else:
-                logging.info("Iter {:8d} : NLL = {:.4e} MSE = {:.4e} "
-                             "Samples = {} Time = {:5.2f}".format(iteration_index, float(total_nll),
-                                                                  float(total_mse), len(self.samples),
-                                                                  seconds_elapsed))
-
-        logging_intervals = {"burn-in": 512, "sampling": self.sample_steps}
+    def train(self, X, y, *args, **kwargs):
+        """Sample ``n_nets`` networks from the posterior given data ``X (N, D)``, ``y (N,)``: the sample sequence,
+        logging cadence and collection rule of ``bayesian_neural_network.py:391-533`` (including the
+        ``iteration_index <= burn_in_steps`` off-by-one at :514), driven from event to event."""
+        assert X.ndim == 2 and X.shape[0] == y.shape[0]
+        clock = time()
+        device = self._device()
+        self._adopt_data(X, y, device)
+        self._build_sampler(X.shape[0], X.shape[1], device)
+        self.samples.clear()
         fused = bool(self.use_fused_steps and self.fused_cost and hasattr(self.sampler, "fused_bnn_available")
                      and self.sampler.fused_bnn_available())
         self.used_fused_steps = fused
-
-        def handle(iteration_index, parameter_values):
-            """Bookkeeping of the reference loop for the sample of iteration `iteration_index` (:514-531)."""
-            burning_in = iteration_index <= self.burn_in_steps
-            if burning_in and iteration_index % logging_intervals["burn-in"] == 0:
-                log_full_training_error(iteration_index=iteration_index, is_sampling=False)
-            if not burning_in and iteration_index % logging_intervals["sampling"] == 0:
-                log_full_training_error(iteration_index=iteration_index, is_sampling=True)
-                self.samples.append([v.clone() for v in parameter_values])
-                return len(self.samples) == self.n_nets
-            return False
-
-        group = None
+        self.chains = None
         if self.n_chains > 1:
             if not fused:
                 raise ValueError("BayesianNeuralNetwork(n_chains > 1) needs the fused small-model path (a net whose "
                                  "activations fit the LDS, SGHMC or SGLD, on an AMD GPU); got a configuration without it")
-            group = self._build_chain_group(n_datapoints, n_inputs, device)
-            self.chains = group
-
-            def handle(iteration_index, parameter_values, _single=handle):     # noqa: F811
-                burning_in = iteration_index <= self.burn_in_steps
-                if burning_in or iteration_index % logging_intervals["sampling"] != 0:
-                    return _single(iteration_index, parameter_values) if burning_in else False
-                log_full_training_error(iteration_index=iteration_index, is_sampling=True)
-                for member in group.samplers:                                   # one network per chain
-                    self.samples.append([v.clone() for v in member.arena.views("theta")])
-                    if len(self.samples) == self.n_nets:
-                        return True
-                return False
-
-        if fused:
-            stepper = group.steps if group is not None else self.sampler.fused_bnn_steps
-            # same loop, advanced in chunks: only iterations that log or collect need the host
-            def is_event(i):
-                return (i <= self.burn_in_steps and i % logging_intervals["burn-in"] == 0) or \
-                       (i > self.burn_in_steps and i % logging_intervals["sampling"] == 0)
-            i = 0                                           # index of the next sample to produce
-            while i < self.n_iters:
-                e = i
-                while e < self.n_iters - 1 and not is_event(e):
-                    e += 1
-                stepper(e - i + 1)                          # produces samples i .. e
-                if handle(e, self.sampler.arena.views("theta")):
-                    break
-                i = e + 1
+            self.chains = self._build_chain_group(X.shape[0], X.shape[1], device)
+        if self.chains is not None:
+            advance = self.chains.steps          # every chain, n steps, one launch
+        elif fused:
+            advance = self.sampler.fused_bnn_steps
         else:
-            sample_chain = itertools.islice(self.sampler, self.n_iters)
-            for iteration_index, (parameter_values, _) in enumerate(sample_chain):
-                if handle(iteration_index, parameter_values):
-                    break
+            advance = lambda n: [next(self.sampler) for _ in range(n)]
+        logging.info("Starting sampling")
+        done = 0                                 # iterations produced so far
+        for event in self._host_events():
+            advance(event + 1 - done)            # the chain now stands after iteration `event`
+            done = event + 1
+            if self._visit(event, clock):
+                break
         self.is_trained = True
 
     def _build_chain_group(self, n_datapoints, n_inputs, device):
@@ -659,7 +641,9 @@ class BayesianNeuralNetwork(object):
             return mlp_forward(ps, x).cpu().numpy()
 
     def predict(self, X_test, return_individual_predictions=False, *args, **kwargs):
-        """Predictive mean and variance at ``X_test (N, D)`` (``:560-630``)."""
+        """Predictive mean and variance at ``X_test (N, D)`` (``:560-630``): the kept networks' means and noise
+        variances ``(n_nets, N)`` if ``return_individual_predictions``, else the ensemble mean and the variance of the
+        networks' means."""
         assert X_test.ndim == 2
         if not self.is_trained:
             raise ValueError(
@@ -667,25 +651,17 @@ class BayesianNeuralNetwork(object):
                 "Bayesian Neural Network 'bnn' is not supported! "
                 "Please call `bnn.train()` before calling `bnn.predict()`"
             )
-        if self.normalize_input:
-            X_, _, _ = zero_mean_unit_var_normalization(X_test, self.x_mean, self.x_std)
-        else:
-            X_ = X_test
-        f_out, theta_noise = [], []
-        for sample in self.samples:
-            out = self.compute_network_output(params=sample, input_data=X_)
-            f_out.append(out[:, 0])
-            theta_noise.append(np.exp(out[:, 1]))
-        f_out = np.asarray(f_out)
-        theta_noise = np.asarray(theta_noise)
+        x = zero_mean_unit_var_normalization(X_test, self.x_mean, self.x_std)[0] if self.normalize_input else X_test
+        outputs = np.stack([self.compute_network_output(params=net, input_data=x) for net in self.samples])    # (nets, N, 2)
+        means, noise_var = outputs[:, :, 0], np.exp(outputs[:, :, 1])
         if return_individual_predictions:
             if self.normalize_output:
-                f_out = zero_mean_unit_var_unnormalization(f_out, self.y_mean, self.y_std)
-                theta_noise *= self.y_std ** 2
-            return f_out, theta_noise
-        mean_prediction = np.mean(f_out, axis=0)
-        variance_prediction = np.mean((f_out - mean_prediction) ** 2, axis=0)
+                means = zero_mean_unit_var_unnormalization(means, self.y_mean, self.y_std)
+                noise_var = noise_var * self.y_std ** 2
+            return means, noise_var
+        ensemble_mean = means.mean(axis=0)
+        ensemble_var = ((means - ensemble_mean) ** 2).mean(axis=0)
         if self.normalize_output:
-            mean_prediction = zero_mean_unit_var_unnormalization(mean_prediction, self.y_mean, self.y_std)
-            variance_prediction *= self.y_std ** 2
-        return mean_prediction, variance_prediction
+            ensemble_mean = zero_mean_unit_var_unnormalization(ensemble_mean, self.y_mean, self.y_std)
+            ensemble_var = ensemble_var * self.y_std ** 2
+        return ensemble_mean, ensemble_var

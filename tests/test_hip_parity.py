@@ -528,3 +528,27 @@ def test_randomised_parity_sweep(gpu, oracle):
             for name in names:
                 got = getattr(gst, name).cpu().numpy()
                 assert np.array_equal(got, getattr(cst, name), equal_nan=True), (case, sampler, npdt, n, t, name)
+
+
+def test_rhat_pack_refuses_a_buffer_of_another_dtype(gpu):
+    """the pack kernel is chosen from the moments' dtype; an f64 pack into an f32 buffer of the same element
+    count would write twice the allocation. Both the kernel front end and RhatExchange.start refuse it."""
+    from pysgmcmc_amd import kernels
+    from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange
+    n = 1000
+    mean, m2 = torch.zeros(n, dtype=torch.float64, device=gpu), torch.ones(n, dtype=torch.float64, device=gpu)
+    with pytest.raises(TypeError, match="share a dtype"):
+        kernels.rhat_pack(mean, m2, 5, torch.empty(3 * n, dtype=torch.float32, device=gpu))
+    with pytest.raises(TypeError, match="share a dtype"):
+        kernels.rhat_pack(mean, m2.float(), 5, torch.empty(3 * n, dtype=torch.float64, device=gpu))
+    kernels.rhat_pack(mean, m2, 5, torch.empty(3 * n, dtype=torch.float64, device=gpu))
+    ex = RhatExchange(n, gpu)                                     # default dtype float32, mode all-reduce: no group needed to build
+    mom = ChainMoments(n, gpu, dtype=torch.float64)
+    mom.count = 5
+    try:
+        ex.start(mom)
+        raise AssertionError("RhatExchange.start accepted float64 moments for a float32 exchange")
+    except TypeError as exc:
+        assert "float64" in str(exc)
+    except RuntimeError as exc:                                   # no process group here: the dtype check must come first
+        raise AssertionError("dtype must be checked before the process group: %s" % exc)
