@@ -232,6 +232,13 @@ int sgmcmc_toy_chains_f64(int sampler, int target, const double *target_params, 
                           const uint64_t *seeds, uint64_t first_step, uint64_t n_steps, int64_t burn_in_steps,
                           uint64_t keep_every, double *kept, sgmcmc_stream_t stream);
 
+/* Weight-gradient product of a dense layer on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32):
+ * C[M][N] = A^T B, A = the layer's input activations [K = batch][lda >= M], B = its deltas [K][ldb >= N]
+ * (replaces the tf.gradients matmul behind pysgmcmc/samplers/sghmc.py:121-122 for one kernel matrix).
+ * N % 128 == 0, K % 16 == 0, M % 4 == 0, operands 16-byte aligned.                                              */
+int sgmcmc_gemm_tn_f32(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc,
+                       int variant /* tile shape, 0 = default */, sgmcmc_stream_t stream);
+
 /* K5 -- write the N(0,1) stream itself: out[i] = xi(seed, step, i). Replaces
  * tf.random_normal in pysgmcmc/samplers/base_classes.py:218-220 for callers that
  * want the draws materialised (tests, relativistic momentum initialisation).      */

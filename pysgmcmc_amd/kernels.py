@@ -15,7 +15,7 @@ from pysgmcmc_amd._lib import SgmcmcLibraryError, check, lib
 __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
-    "LaunchConfig", "KernelEvents", "StepOpts", "step_stats_records", "step_scalars", "toy_chains", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
+    "LaunchConfig", "KernelEvents", "StepOpts", "step_stats_records", "step_scalars", "toy_chains", "gemm_tn", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
     "bnn_fused_sgld_steps", "window_gather", "tanh_rowdot", "bnn_head_last_layer_backward", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
 ]
 
@@ -306,6 +306,21 @@ def toy_chains(sampler, target, target_params, theta, mom, tau, g, v_hat, minv, 
                int(burn_in_steps), int(keep_every), _ptr(kept), _stream(theta))
     check(rc, "sgmcmc_toy_chains")
     return kept
+
+
+def gemm_tn(a, b, out, variant=0):
+    """``out[M, N] = a[K, M]^T @ b[K, N]`` (fp32, matrix cores): the weight-gradient product of a dense layer."""
+    K, M = a.shape
+    N = b.shape[1]
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or out.dtype != torch.float32:
+        raise TypeError("gemm_tn is fp32")
+    if b.shape[0] != K or tuple(out.shape) != (M, N) or a.stride(1) != 1 or b.stride(1) != 1 or out.stride(1) != 1:
+        raise ValueError("gemm_tn: shapes / strides do not match")
+    with _on(a):
+        rc = lib().sgmcmc_gemm_tn_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+                                      int(variant), _stream(a))
+    check(rc, "sgmcmc_gemm_tn_f32")
+    return out
 
 
 def philox_normal(out, seed, step, step_dev=None, launch=None):
