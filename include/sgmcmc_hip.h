@@ -239,6 +239,23 @@ int sgmcmc_toy_chains_f64(int sampler, int target, const double *target_params, 
 int sgmcmc_gemm_tn_f32(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc,
                        int variant /* tile shape, 0 = default */, sgmcmc_stream_t stream);
 
+/* The same product with the frozen SGHMC update of the layer as its epilogue (kernel K1's arithmetic and Philox stream,
+ * sghmc.py:211-251 with fed minv): the tile of gW a workgroup accumulated never goes to HBM; the workgroup updates the
+ * same tile of theta / V (the layer's weights W = theta[0 .. M N), row-major [M][N]) and the launch also updates the
+ * n_tail parameters that follow W in the arena (bias, ...) from their already computed gradient grad_tail.
+ * 20 B of HBM traffic per weight instead of 4 (GEMM output) + 24 (K1), hidden under the matrix-core work.
+ *   first_element: index of W[0][0] in the chain's parameter vector (Philox counter of element i = (first_element + i) / 4)
+ *   grad_out:      NULL, or [M][N]: also write gW (tests: K1 on this gradient gives the same theta', V' bit for bit)
+ *   stats_ws / stats_record_*: as sgmcmc_step_opts_t; one {sum theta'^2, 0, 0, 0} record per workgroup,
+ *                  sgmcmc_gemm_tn_sghmc_blocks() = the launch's workgroup count. gemm_blocks: 0 = default (512).
+ *   K % 32 == 0, N % 128 == 0, M % 4 == 0.                                                                        */
+int sgmcmc_gemm_tn_sghmc_f32(const float *A, const float *B, int M, int N, int K, int lda, int ldb, float *theta, float *V,
+                             const float *minv, const float *grad_tail, size_t n_tail, float *grad_out, float eps,
+                             float scale_grad, float mdecay, float grad_decay, uint64_t seed, uint64_t step,
+                             const uint64_t *step_dev, uint64_t first_element, void *stats_ws, uint32_t stats_record_base,
+                             uint32_t stats_record_total, int gemm_blocks, sgmcmc_stream_t stream);
+int sgmcmc_gemm_tn_sghmc_blocks(int M, int N, size_t n_tail, int gemm_blocks);
+
 /* K5 -- write the N(0,1) stream itself: out[i] = xi(seed, step, i). Replaces
  * tf.random_normal in pysgmcmc/samplers/base_classes.py:218-220 for callers that
  * want the draws materialised (tests, relativistic momentum initialisation).      */

@@ -186,6 +186,21 @@ __device__ __forceinline__ T adapt_stats(T grad, T &tau, T &g, T &vh, T &r_out)
     return minv;
 }
 
+// One parameter's SGHMC update given its (possibly decayed) gradient gr, preconditioner mi and normal draw z
+// (sghmc.py:211-243 with fed / freshly adapted minv). Shared by the streaming operator below and by the epilogue of the
+// weight-gradient GEMM (sgmcmc_gemm.hip), so both give the same bits.
+template <typename T>
+__device__ __forceinline__ void sghmc_elem_update(T &th, T &v, T gr, T mi, T z, T e2, T c1, T c3, T e4, T mdecay)
+{
+    T noise_scale = (c1 * mi - (c3 * (mi * mi)) * T(0)) - e4;                            // :211-217
+    T sigma = rsqrt_rn<T>((noise_scale > T(1e-16)) ? noise_scale : T(1e-16));             // :220
+    T sample = sigma * z;
+    T v0 = v;
+    T v1 = v0 + (((((-e2) * mi) * gr) - mdecay * v0) + sample);                           // :233-238
+    v = v1;
+    th = th + v1;                                                                         // :241-243
+}
+
 // --------------------------------------------------------------------------
 // per-sampler quad operators
 // --------------------------------------------------------------------------
@@ -248,13 +263,7 @@ struct SghmcOp {
             T mi;
             if constexpr (ADAPT) { mi = adapt_stats<T>(gr, R.tau[j], R.g[j], R.vh[j], R.rr[j]); R.mi[j] = mi; }
             else mi = R.mi[j];
-            T noise_scale = (c1 * mi - (c3 * (mi * mi)) * T(0)) - e4;                    // :211-217
-            T sigma = rsqrt_rn<T>((noise_scale > T(1e-16)) ? noise_scale : T(1e-16));     // :220
-            T sample = sigma * R.z[j];
-            T v0 = R.v[j];
-            T v1 = v0 + (((((-e2) * mi) * gr) - mdecay * v0) + sample);                   // :233-238
-            R.v[j] = v1;
-            R.th[j] = R.th[j] + v1;                                                      // :241-243
+            sghmc_elem_update<T>(R.th[j], R.v[j], gr, mi, R.z[j], e2, c1, c3, e4, mdecay);
         }
     }
     template <bool NT> __device__ __forceinline__ void store_vec(size_t q, const Regs &R) const

@@ -25,6 +25,7 @@
 // summation order. The update arithmetic is bit-identical to K1 applied to the same gW (tests write gW out and check).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 
 #include "sgmcmc_hip.h"
@@ -65,8 +66,8 @@ template <typename TL, int TM, int TN>
 __device__ __forceinline__ void mainloop(const GemmArgs &g, int m0, int n0, int wm, int wn, f32x16 (&acc)[TM][TN])
 {
     constexpr int BK = TL::BK, BM = TL::BM, BN = TL::BN, NT = TL::NT, LA = TL::LA, LB = TL::LB;
-    constexpr int SUB = 8, NSUB = BK / 2 / SUB;             // k-steps (of 2) per sub-batch, sub-batches per chunk
-    static_assert(NSUB >= 1 && NSUB * SUB * 2 == BK, "BK must be a multiple of 16");
+    constexpr int SUB = 4, NSUB = BK / 2 / SUB;             // k-steps (of 2) per sub-batch, sub-batches per chunk
+    static_assert(NSUB >= 1 && NSUB * SUB * 2 == BK, "BK must be a multiple of 8");
     __shared__ float As[2][BK][BM];
     __shared__ float Bs[2][BK][BN];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -162,6 +163,166 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_tn_kernel(const GemmArgs g)
             }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// fused: weight-gradient GEMM + frozen SGHMC update of [W | the parameters that follow W in the arena]
+// ------------------------------------------------------------------------------------------------------------------
+
+struct FusedArgs {
+    GemmArgs g;                        // g.C: nullable, receives gW (tests); the product is [M][N] with ldc = N
+    float *theta, *V;                  // the layer's slice of the arena: W [M][N] dense, then n_tail more parameters
+    const float *minv;
+    const float *grad_tail;            // gradient of those n_tail parameters (bias gradient etc.), already computed
+    size_t n_tail;
+    float e2, c1, c3, e4, mdecay, grad_decay;
+    NoiseKey nk;                       // nk.q0 = global quad index of W[0][0] within the chain's parameter vector
+    double *stats;                     // nullable: one {sum theta'^2, 0, 0, 0} record per workgroup
+    unsigned rec_base, rec_total;
+    int n_gemm_blocks;                 // persistent workgroups of the product; blocks beyond them update the tail
+    int stagger_sleeps, stagger_mode;  // late start of half of the workgroups, in units of s_sleep(127) = 8128 cycles
+};
+
+template <int CTRL>
+__device__ __forceinline__ float quad_bcast(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// 64 x 64 output tile, 4 waves of 32 x 32, K in chunks of 32: a workgroup walks over tiles blockIdx.x, + gridDim, ...
+// (persistent), so the asynchronous theta'/V' stores of one tile drain under the MFMAs of the next.
+typedef Tile<1, 1, 2, 2, 32> FT;
+
+// 256-lane blocks for the n_tail parameters after W (one quad per lane per trip; at least one block if there are any)
+inline unsigned tail_blocks_for(size_t n_tail)
+{
+    if (n_tail == 0) return 0;
+    const size_t blocks = (n_tail / 4 + 255) / 256;
+    return (unsigned)(blocks ? blocks : 1);
+}
+
+// element e of the layer's slice, addressed as uniform base + 32-bit byte offset (M N < 2^30: one SGPR pair + one VGPR per
+// access instead of a 64-bit VGPR address each)
+__device__ __forceinline__ float ld32(const float *base, unsigned e) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (size_t)(e * 4u)); }
+__device__ __forceinline__ void st32(float *base, unsigned e, float v) { *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + (size_t)(e * 4u)) = v; }
+
+// One 64 x 64 tile: state prefetch, product, update. FULL: every row of the tile is inside the matrix (no guards).
+template <bool FULL>
+__device__ __forceinline__ void fused_tile(const FusedArgs &a, const NoiseKey &nk, int m0, int n0, int wm, int wn, int lane, float &tsq)
+{
+    const unsigned N = (unsigned)a.g.N;
+    const int M = a.g.M;
+    // this lane's 16 elements: rows rb + (r & 3) + 8 (r >> 2), one column
+    const int rb = m0 + wm + 4 * (lane >> 5);
+    const unsigned col = (unsigned)(n0 + wn + (lane & 31));
+    const unsigned e0 = (unsigned)rb * N + col;
+    // (1) state of the tile: requested now, consumed after the K loop (HBM latency hides under the MFMAs)
+    float th[16], v[16], mi[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        // rows beyond M (last tile of a ragged layer) read the matrix' last row instead: always a valid address, never stored
+        const unsigned e = (FULL || rb + dr < M) ? e0 + (unsigned)dr * N : (unsigned)(M - 1) * N + col;
+        th[r] = ld32(a.theta, e);
+        v[r] = ld32(a.V, e);
+        mi[r] = ld32(a.minv, e);
+    }
+    // (2) the product
+    f32x16 acc[1][1];
+    mainloop<FT, 1, 1>(a.g, m0, n0, wm, wn, acc);
+    // (3) epilogue. A Philox quad = 4 consecutive columns of one row = 4 adjacent lanes x one register: lane t of a lane
+    // quad draws the quad of row (r & 3) == t of each 4-row group, a 4 x 4 transpose over the lane quad (DPP quad_perm
+    // broadcasts) hands every lane the normal of ITS column.
+    const int t4 = lane & 3;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const unsigned qe = (unsigned)(rb + 8 * gq + t4) * N + (col & ~3u);
+        float z[4];
+        normal_quad(nk, (size_t)(qe >> 2), z);
+        float zz[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float b0 = quad_bcast<0x00>(z[c]), b1 = quad_bcast<0x55>(z[c]);
+            const float b2 = quad_bcast<0xAA>(z[c]), b3 = quad_bcast<0xFF>(z[c]);
+            if (c == 0 || t4 == c) { zz[0] = b0; zz[1] = b1; zz[2] = b2; zz[3] = b3; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 4 * gq + j, dr = j + 8 * gq;
+            const float gw = acc[0][0][r];
+            const float gr = (a.grad_decay != 0.f) ? gw + a.grad_decay * th[r] : gw;
+            sghmc_elem_update<float>(th[r], v[r], gr, mi[r], zz[j], a.e2, a.c1, a.c3, a.e4, a.mdecay);
+            if (FULL || rb + dr < M) {
+                const unsigned e = e0 + (unsigned)dr * N;
+                if (a.g.C != nullptr) st32(a.g.C, e, gw);
+                st32(a.theta, e, th[r]);
+                st32(a.V, e, v[r]);
+                tsq += th[r] * th[r];
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_tn_sghmc_kernel(const FusedArgs a)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    NoiseKey nk = a.nk;
+    nk.resolve();
+    float tsq = 0.f;                                       // this lane's share of sum theta'^2
+    if ((int)blockIdx.x >= a.n_gemm_blocks) {
+        // ---- the parameters after W (bias, ...): the streaming update K1 on their quads, same Philox stream
+        const size_t base = (size_t)a.g.M * a.g.N;         // multiple of 4 (N % 128 == 0)
+        SghmcOp<float, false, false> op{a.theta + base, a.V + base, a.grad_tail, nullptr, nullptr, nullptr,
+                                        const_cast<float *>(a.minv) + base, nullptr, nullptr,
+                                        a.e2, a.c1, a.c3, a.e4, a.mdecay, a.grad_decay, nk, nullptr};
+        op.nk.q0 = nk.q0 + base / 4;
+        const size_t nq_full = a.n_tail / 4;
+        const int tail = (int)(a.n_tail % 4);
+        const size_t G = (size_t)(gridDim.x - a.n_gemm_blocks) * blockDim.x;
+        const size_t gid = (size_t)(blockIdx.x - a.n_gemm_blocks) * blockDim.x + tid;
+        float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (size_t q = gid; q < nq_full; q += G) {
+            SghmcOp<float, false, false>::Regs R;
+            op.load_vec<false>(q, R);
+            op.compute(q, R);
+            op.store_vec<false>(q, R);
+            op.accumulate<true>(R, 4, acc4);
+        }
+        if (tail && gid == G - 1) {
+            SghmcOp<float, false, false>::Regs R;
+            op.load_part_(nq_full, tail, R);
+            op.compute(nq_full, R);
+            op.store_part_(nq_full, tail, R);
+            op.accumulate<true>(R, tail, acc4);
+        }
+        tsq = acc4[0];
+    } else {
+        const int tiles_n = a.g.N / FT::BN, tiles_m = (a.g.M + FT::BM - 1) / FT::BM;
+        const int n_tiles = tiles_m * tiles_n;
+        const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+        // de-phasing: co-resident workgroups that start together stay in lockstep (product, then update, product, ...), so the
+        // matrix cores idle while every workgroup of the CU updates. Half of the workgroups start late by about one update.
+        if (a.stagger_sleeps > 0 && (a.stagger_mode == 0 ? (blockIdx.x & 1) : ((int)blockIdx.x >= a.n_gemm_blocks / 2)))
+            for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+        for (int t = blockIdx.x; t < n_tiles; t += a.n_gemm_blocks) {
+            const int m0 = (t / tiles_n) * FT::BM, n0 = (t % tiles_n) * FT::BN;
+            if (m0 + FT::BM <= a.g.M) fused_tile<true>(a, nk, m0, n0, wm, wn, lane, tsq);
+            else fused_tile<false>(a, nk, m0, n0, wm, wn, lane, tsq);
+        }
+    }
+    if (a.stats != nullptr) {
+        __shared__ float red[4];
+        const float w = wave_sum_dpp_lane63(tsq);
+        if (lane == 63) red[wave] = w;
+        __syncthreads();
+        if (tid < 4) {
+            double val = 0.0;
+            if (tid == 0) val = (((double)red[0] + (double)red[1]) + (double)red[2]) + (double)red[3];
+            a.stats[4 + 4 * ((size_t)a.rec_base + blockIdx.x) + tid] = val;
+        }
+        if (blockIdx.x == 0 && tid == 0)
+            reinterpret_cast<unsigned long long *>(a.stats)[0] = a.rec_total ? a.rec_total : gridDim.x;
+    }
+}
+
 template <int TM, int TN, int WM, int WN, int BK>
 int launch_gemm(const GemmArgs &g, hipStream_t st)
 {
@@ -199,6 +360,56 @@ int sgmcmc_gemm_tn_f32(const float *A, const float *B, float *C, int M, int N, i
     case 8: return launch_gemm<1, 2, 2, 2, 64>(g, st);    //                                 64
     default: return fail(SGMCMC_EINVAL, "gemm_tn: unknown variant");
     }
+}
+
+/* see include/sgmcmc_hip.h */
+int sgmcmc_gemm_tn_sghmc_f32(const float *A, const float *B, int M, int N, int K, int lda, int ldb, float *theta, float *V,
+                             const float *minv, const float *grad_tail, size_t n_tail, float *grad_out, float eps,
+                             float scale_grad, float mdecay, float grad_decay, uint64_t seed, uint64_t step,
+                             const uint64_t *step_dev, uint64_t first_element, void *stats_ws, uint32_t stats_record_base,
+                             uint32_t stats_record_total, int gemm_blocks, sgmcmc_stream_t stream)
+{
+    if (!A || !B || !theta || !V || !minv || (n_tail && !grad_tail)) return fail(SGMCMC_EINVAL, "gemm_tn_sghmc: NULL argument");
+    if (M <= 0 || N <= 0 || K <= 0 || N % 128 || K % FT::BK || M % 4 || lda < M || ldb < N || lda % 4 || ldb % 4 ||
+        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15u))
+        return fail(SGMCMC_EINVAL, "gemm_tn_sghmc: needs N %% 128 == 0, K %% 32 == 0, M %% 4 == 0, 16-byte aligned operands");
+    if (first_element % 4 || ((reinterpret_cast<uintptr_t>(theta) | reinterpret_cast<uintptr_t>(V) |
+                               reinterpret_cast<uintptr_t>(minv) | reinterpret_cast<uintptr_t>(grad_tail)) & 15u))
+        return fail(SGMCMC_EINVAL, "gemm_tn_sghmc: the slice must start on a quad (first_element %% 4 == 0, 16-byte aligned arrays)");
+    FusedArgs a;
+    a.g = GemmArgs{A, B, grad_out, M, N, K, lda, ldb, N};
+    a.theta = theta; a.V = V; a.minv = minv; a.grad_tail = grad_tail; a.n_tail = n_tail;
+    // derived scalars exactly as sgmcmc_sghmc_step_f32 forms them (sghmc.py:111-117,211-217,235)
+    const float eps_s = eps / std::sqrt(scale_grad);
+    a.e2 = std::pow(eps, 2.0f);
+    a.c1 = (2.0f * std::pow(eps_s, 2.0f)) * mdecay;
+    a.c3 = 2.0f * std::pow(eps_s, 3.0f);
+    a.e4 = std::pow(eps_s, 4.0f);
+    a.mdecay = mdecay; a.grad_decay = grad_decay;
+    a.nk.k0 = (uint32_t)seed; a.nk.k1 = (uint32_t)(seed >> 32);
+    a.nk.s0 = (uint32_t)step; a.nk.s1 = (uint32_t)(step >> 32);
+    a.nk.step_dev = step_dev; a.nk.q0 = first_element / 4;
+    a.stats = static_cast<double *>(stats_ws); a.rec_base = stats_record_base; a.rec_total = stats_record_total;
+    const int n_tiles = ((M + FT::BM - 1) / FT::BM) * (N / FT::BN);
+    a.stagger_sleeps = (gemm_blocks >> 16) & 0xff;        // experiment knobs in the high bits (tools/gemm_probe3.py)
+    a.stagger_mode = (gemm_blocks >> 24) & 0xf;
+    gemm_blocks &= 0xffff;
+    if (gemm_blocks <= 0) gemm_blocks = 512;              // 2 persistent workgroups per CU
+    a.n_gemm_blocks = gemm_blocks < n_tiles ? gemm_blocks : n_tiles;
+    hipLaunchKernelGGL(gemm_tn_sghmc_kernel, dim3(a.n_gemm_blocks + tail_blocks_for(n_tail)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch gemm_tn_sghmc");
+}
+
+/* number of workgroups (= statistics records) sgmcmc_gemm_tn_sghmc_f32 launches for these sizes */
+int sgmcmc_gemm_tn_sghmc_blocks(int M, int N, size_t n_tail, int gemm_blocks)
+{
+    const int n_tiles = ((M + FT::BM - 1) / FT::BM) * (N / FT::BN);
+    gemm_blocks &= 0xffff;
+    if (gemm_blocks <= 0) gemm_blocks = 512;
+    const int gb = gemm_blocks < n_tiles ? gemm_blocks : n_tiles;
+    return gb + (int)tail_blocks_for(n_tail);
 }
 
 }  // extern "C"
