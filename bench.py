@@ -71,7 +71,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(mode, n, stats_variant=False):
+def pmc_traffic(mode, n, variant=""):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py: separate --pmc FETCH_SIZE /
     WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, calibrated on launches with
     known byte counts) -- but ONLY if that table was collected with the kernel sources this run uses (source hash
@@ -85,7 +85,7 @@ def pmc_traffic(mode, n, stats_variant=False):
         if have != want:
             return None, "%s was collected with kernel sources %s, this build is %s: traffic not reported" % (name, have, want)
         sizes = doc["sizes"][str(n)]
-        entry = sizes.get(mode + "_stats", sizes[mode]) if stats_variant else sizes[mode]
+        entry = sizes[mode + variant]         # "" plain, "_stats" every statistic, "_tsq" sum theta^2 only, "_tsq_mom" + fused moments
         return int(round(entry["bytes_per_param"] * n)), "%s (%s, kernel sources %s)" % (name, doc.get("collected", "?"), have)
     except (OSError, KeyError, ValueError):
         return None, "no PMC pass for n=%d in %s" % (n, name)
@@ -779,7 +779,7 @@ def main():
         k_us = k_us_sum / max(steps_plain, 1)                          # update time per step (sum of its launches)
         alg_bytes = BYTES_PER_PARAM[mode] * n
         big = alg_bytes > (640 << 20)
-        traffic, traffic_src = pmc_traffic(mode, n, stats_variant=True)   # the pipeline launches the STATS variant
+        traffic, traffic_src = pmc_traffic(mode, n, variant="_tsq")       # the pipeline launches the sum-theta^2-only variant
         # per-step device time: from the end of one step's last update launch to the end of the next one's
         step_ms = np.array([step_end[j].us_until(step_end[j + 1]) for j in range(len(step_end) - 1)]) * 1e-3 \
             if len(step_end) > 1 else None
