@@ -59,15 +59,20 @@ PRIME_STEADY = int(os.environ.get("BENCH_PRIME_STEADY", "124"))   # further froz
 N_HBM_RESIDENT = 49_826_818    # configs[4]'s parameter count: 1.2 GB per frozen SGHMC launch
 
 
+UPDATE_KERNEL_SOURCES = ("pysgmcmc_amd/csrc/sgmcmc_stream.hpp", "pysgmcmc_amd/csrc/sgmcmc_device.hpp",
+                         "pysgmcmc_amd/csrc/sgmcmc_sghmc.hip", "pysgmcmc_amd/csrc/sgmcmc_sgld.hip",
+                         "pysgmcmc_amd/csrc/sgmcmc_rsghmc.hip", "pysgmcmc_amd/csrc/sgmcmc_kernels.hip",
+                         "pysgmcmc_amd/csrc/Makefile", "include/sgmcmc_hip.h")
+
+
 def kernel_source_hash():
-    """sha256 over the kernel sources of the library (csrc/*.hip, *.hpp and the C ABI header): identifies the build a
-    PMC traffic table was collected with (tools/pmc_traffic.py stores it; there is no .git on the GPU box)."""
+    """sha256 over the sources the streaming update kernels K1-K5 are built from (kernel shape, operators, their host side,
+    build flags, the C ABI header): identifies the build a PMC traffic table was collected with (tools/pmc_traffic.py
+    stores it; there is no .git on the GPU box)."""
     h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "pysgmcmc_amd", "csrc")
-    files = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp")))
-    for path in [os.path.join(csrc, f) for f in files] + [os.path.join(ROOT, "include", "sgmcmc_hip.h")]:
-        with open(path, "rb") as fh:
-            h.update(fh.read())
+    for rel in UPDATE_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(rel.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
 
 
