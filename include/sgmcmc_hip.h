@@ -253,7 +253,8 @@ int sgmcmc_gemm_tn_sghmc_f32(const float *A, const float *B, int M, int N, int K
                              const float *minv, const float *grad_tail, size_t n_tail, float *grad_out, float eps,
                              float scale_grad, float mdecay, float grad_decay, uint64_t seed, uint64_t step,
                              const uint64_t *step_dev, uint64_t first_element, void *stats_ws, uint32_t stats_record_base,
-                             uint32_t stats_record_total, int gemm_blocks, sgmcmc_stream_t stream);
+                             uint32_t stats_record_total, int gemm_blocks, int *phase_counters /* NULL, or 2048 zeroed ints */,
+                             int phase_sleeps, sgmcmc_stream_t stream);
 int sgmcmc_gemm_tn_sghmc_blocks(int M, int N, size_t n_tail, int gemm_blocks);
 
 /* K5 -- write the N(0,1) stream itself: out[i] = xi(seed, step, i). Replaces

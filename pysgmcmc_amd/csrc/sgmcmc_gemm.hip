@@ -62,14 +62,26 @@ struct Tile {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // acc[i][j] = 32 x 32 tile (rows +32 i, cols +32 j) of this wave's part of the block tile at (m0, n0)
-template <typename TL, int TM, int TN>
-__device__ __forceinline__ void mainloop(const GemmArgs &g, int m0, int n0, int wm, int wn, f32x16 (&acc)[TM][TN])
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// LDS of one workgroup: two stages of a BK x BM and a BK x BN chunk
+template <typename TL>
+struct Stages {
+    float A[2][TL::BK][TL::BM];
+    float B[2][TL::BK][TL::BN];
+};
+
+// acc[i][j] = 32 x 32 tile (rows +32 i, cols +32 j) of this wave's part of the block tile at (m0, n0).
+// LastChunkHook: called once, right before the MFMAs of the LAST K chunk (peeled out of the loop) are issued -- the fused
+// kernel requests its tile's state there: the loads fly under that chunk's MFMAs, and nothing but the accumulators is live
+// across the loop.
+template <typename TL, int TM, int TN, typename LastChunkHook = NoHook>
+__device__ __forceinline__ void mainloop(const GemmArgs &g, Stages<TL> &lds, int m0, int n0, int wm, int wn,
+                                         f32x16 (&acc)[TM][TN], LastChunkHook hook = LastChunkHook())
 {
     constexpr int BK = TL::BK, BM = TL::BM, BN = TL::BN, NT = TL::NT, LA = TL::LA, LB = TL::LB;
     constexpr int SUB = 4, NSUB = BK / 2 / SUB;             // k-steps (of 2) per sub-batch, sub-batches per chunk
     static_assert(NSUB >= 1 && NSUB * SUB * 2 == BK, "BK must be a multiple of 8");
-    __shared__ float As[2][BK][BM];
-    __shared__ float Bs[2][BK][BN];
     const int tid = threadIdx.x, lane = tid & 63;
     const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4_t ra[LA], rb[LB];
@@ -91,12 +103,12 @@ __device__ __forceinline__ void mainloop(const GemmArgs &g, int m0, int n0, int 
 #pragma unroll
         for (int u = 0; u < LA; ++u) {
             const int f = tid + u * NT, r = f / (BM / 4), c = (f % (BM / 4)) * 4;
-            *reinterpret_cast<f32x4_t *>(&As[s][r][c]) = ra[u];
+            *reinterpret_cast<f32x4_t *>(&lds.A[s][r][c]) = ra[u];
         }
 #pragma unroll
         for (int u = 0; u < LB; ++u) {
             const int f = tid + u * NT, r = f / (BN / 4), c = (f % (BN / 4)) * 4;
-            *reinterpret_cast<f32x4_t *>(&Bs[s][r][c]) = rb[u];
+            *reinterpret_cast<f32x4_t *>(&lds.B[s][r][c]) = rb[u];
         }
     };
 #pragma unroll
@@ -115,15 +127,12 @@ __device__ __forceinline__ void mainloop(const GemmArgs &g, int m0, int n0, int 
 #pragma unroll
         for (int kk = 0; kk < SUB; ++kk) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[buf][kk][i] = As[s][2 * (sub * SUB + kk) + kl][wm + 32 * i + cl];
+            for (int i = 0; i < TM; ++i) af[buf][kk][i] = lds.A[s][2 * (sub * SUB + kk) + kl][wm + 32 * i + cl];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[buf][kk][j] = Bs[s][2 * (sub * SUB + kk) + kl][wn + 32 * j + cl];
+            for (int j = 0; j < TN; ++j) bf[buf][kk][j] = lds.B[s][2 * (sub * SUB + kk) + kl][wn + 32 * j + cl];
         }
     };
-    for (int kc = 0; kc < nk; ++kc) {
-        const int s = kc & 1;
-        frags(s, 0, 0);
-        if (kc + 1 < nk) fetch(kc + 1);                    // global loads of the next chunk fly under this chunk's MFMAs
+    auto mfmas = [&](int s) {
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
             if (sub + 1 < NSUB) frags(s, sub + 1, (sub + 1) & 1);   // next sub-batch's fragments are requested first ...
@@ -137,8 +146,21 @@ __device__ __forceinline__ void mainloop(const GemmArgs &g, int m0, int n0, int 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sub & 1][kk][i], bf[sub & 1][kk][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (kc + 1 < nk) stash(s ^ 1);                     // stage s ^ 1 was last read before the previous barrier
+    };
+    for (int kc = 0; kc + 1 < nk; ++kc) {
+        const int s = kc & 1;
+        frags(s, 0, 0);
+        fetch(kc + 1);                                     // global loads of the next chunk fly under this chunk's MFMAs
+        mfmas(s);
+        stash(s ^ 1);                                      // stage s ^ 1 was last read before the previous barrier
         __syncthreads();
+    }
+    {
+        const int s = (nk - 1) & 1;
+        frags(s, 0, 0);
+        hook();
+        mfmas(s);
+        __syncthreads();                                   // the stages may be overwritten by the next tile
     }
 }
 
@@ -149,8 +171,9 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_tn_kernel(const GemmArgs g)
     const int m0 = blockIdx.y * TL::BM, n0 = blockIdx.x * TL::BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave / WN) * 32 * TM, wn = (wave % WN) * 32 * TN;
+    __shared__ Stages<TL> lds;
     f32x16 acc[TM][TN];
-    mainloop<TL, TM, TN>(g, m0, n0, wm, wn, acc);
+    mainloop<TL, TM, TN>(g, lds, m0, n0, wm, wn, acc);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -178,7 +201,8 @@ struct FusedArgs {
     double *stats;                     // nullable: one {sum theta'^2, 0, 0, 0} record per workgroup
     unsigned rec_base, rec_total;
     int n_gemm_blocks;                 // persistent workgroups of the product; blocks beyond them update the tail
-    int stagger_sleeps, stagger_mode;  // late start of half of the workgroups, in units of s_sleep(127) = 8128 cycles
+    int *phase_counters;               // nullable: 2048 ints, one per CU (see the kernel): every second workgroup a CU receives starts late
+    int phase_sleeps;                  // ... by this many s_sleep(127) (8128 cycles each)
 };
 
 template <int CTRL>
@@ -199,80 +223,72 @@ inline unsigned tail_blocks_for(size_t n_tail)
     return (unsigned)(blocks ? blocks : 1);
 }
 
-// element e of the layer's slice, addressed as uniform base + 32-bit byte offset (M N < 2^30: one SGPR pair + one VGPR per
-// access instead of a 64-bit VGPR address each)
-__device__ __forceinline__ float ld32(const float *base, unsigned e) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (size_t)(e * 4u)); }
-__device__ __forceinline__ void st32(float *base, unsigned e, float v) { *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + (size_t)(e * 4u)) = v; }
+// One 64 x 64 tile: product, then the update of the tile. The accumulators go through LDS (the K loop's stage buffers are
+// free by then) so that the update runs on ROW-MAJOR QUADS exactly like the streaming kernel K1: a lane owns 4 consecutive
+// columns of a row = one Philox quad and one 16-byte access per array (16 lanes cover a 256-byte row segment), the arithmetic
+// is SghmcOp::compute itself. (A first version kept the MFMA accumulator layout -- one column per lane, dword accesses, a
+// 4 x 4 DPP transpose of the normals over each lane quad: 32.8 us at 2048 x 2048 against this version's figure in
+// profiles/r03_gemm_fusion_probe.txt.) Rows beyond M (last tile of a ragged layer) are skipped.
+constexpr int TP = FT::BN + 4;                             // LDS pitch of the accumulator tile (floats)
 
-// One 64 x 64 tile: state prefetch, product, update. FULL: every row of the tile is inside the matrix (no guards).
-template <bool FULL>
-__device__ __forceinline__ void fused_tile(const FusedArgs &a, const NoiseKey &nk, int m0, int n0, int wm, int wn, int lane, float &tsq)
+__device__ __forceinline__ void fused_tile(const FusedArgs &a, Stages<FT> &lds, const SghmcOp<float, false, false> &op, int m0, int n0,
+                                           int wm, int wn, int lane, float &tsq)
 {
-    const unsigned N = (unsigned)a.g.N;
-    const int M = a.g.M;
-    // this lane's 16 elements: rows rb + (r & 3) + 8 (r >> 2), one column
-    const int rb = m0 + wm + 4 * (lane >> 5);
-    const unsigned col = (unsigned)(n0 + wn + (lane & 31));
-    const unsigned e0 = (unsigned)rb * N + col;
-    // (1) state of the tile: requested now, consumed after the K loop (HBM latency hides under the MFMAs)
-    float th[16], v[16], mi[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int dr = (r & 3) + 8 * (r >> 2);
-        // rows beyond M (last tile of a ragged layer) read the matrix' last row instead: always a valid address, never stored
-        const unsigned e = (FULL || rb + dr < M) ? e0 + (unsigned)dr * N : (unsigned)(M - 1) * N + col;
-        th[r] = ld32(a.theta, e);
-        v[r] = ld32(a.V, e);
-        mi[r] = ld32(a.minv, e);
-    }
-    // (2) the product
+    static_assert(sizeof(Stages<FT>) >= sizeof(float) * FT::BM * TP, "the accumulator tile reuses the stage buffers");
+    float *T = &lds.A[0][0][0];
     f32x16 acc[1][1];
-    mainloop<FT, 1, 1>(a.g, m0, n0, wm, wn, acc);
-    // (3) epilogue. A Philox quad = 4 consecutive columns of one row = 4 adjacent lanes x one register: lane t of a lane
-    // quad draws the quad of row (r & 3) == t of each 4-row group, a 4 x 4 transpose over the lane quad (DPP quad_perm
-    // broadcasts) hands every lane the normal of ITS column.
-    const int t4 = lane & 3;
+    mainloop<FT, 1, 1>(a.g, lds, m0, n0, wm, wn, acc);          // ends with a barrier: the stages are free
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-        const unsigned qe = (unsigned)(rb + 8 * gq + t4) * N + (col & ~3u);
-        float z[4];
-        normal_quad(nk, (size_t)(qe >> 2), z);
-        float zz[4];
+    for (int r = 0; r < 16; ++r)
+        T[(wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TP + wn + (lane & 31)] = acc[0][0][r];
+    __syncthreads();
+    const unsigned N = (unsigned)a.g.N;
+    constexpr int QPR = FT::BN / 4;                        // quads per tile row
+    typedef SghmcOp<float, false, false>::Regs Regs;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float b0 = quad_bcast<0x00>(z[c]), b1 = quad_bcast<0x55>(z[c]);
-            const float b2 = quad_bcast<0xAA>(z[c]), b3 = quad_bcast<0xFF>(z[c]);
-            if (c == 0 || t4 == c) { zz[0] = b0; zz[1] = b1; zz[2] = b2; zz[3] = b3; }
+    for (int half = 0; half < 2; ++half) {
+        Regs R[2];
+        unsigned qg[2];
+        bool ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = (int)threadIdx.x + 256 * (2 * half + u), row = q / QPR, c4 = (q % QPR) * 4;
+            ok[u] = m0 + row < a.g.M;
+            qg[u] = ((unsigned)(m0 + (ok[u] ? row : 0)) * N + (unsigned)(n0 + c4)) >> 2;      // quad index within W
+            load_quad<false>(op.theta, qg[u], R[u].th);
+            load_quad<false>(op.V, qg[u], R[u].v);
+            load_quad<false>(op.minv, qg[u], R[u].mi);
+            const f32x4_t gq = *reinterpret_cast<const f32x4_t *>(&T[row * TP + c4]);
+            R[u].gr[0] = gq.x; R[u].gr[1] = gq.y; R[u].gr[2] = gq.z; R[u].gr[3] = gq.w;
         }
+        __builtin_amdgcn_sched_barrier(0);                 // all loads issued before the Philox rounds (cf. sgmcmc_stream.hpp)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = 4 * gq + j, dr = j + 8 * gq;
-            const float gw = acc[0][0][r];
-            const float gr = (a.grad_decay != 0.f) ? gw + a.grad_decay * th[r] : gw;
-            sghmc_elem_update<float>(th[r], v[r], gr, mi[r], zz[j], a.e2, a.c1, a.c3, a.e4, a.mdecay);
-            if (FULL || rb + dr < M) {
-                const unsigned e = e0 + (unsigned)dr * N;
-                if (a.g.C != nullptr) st32(a.g.C, e, gw);
-                st32(a.theta, e, th[r]);
-                st32(a.V, e, v[r]);
-                tsq += th[r] * th[r];
+        for (int u = 0; u < 2; ++u) {
+            if (a.g.C != nullptr && ok[u]) store_quad<false>(a.g.C, qg[u], R[u].gr);
+            op.compute(qg[u], R[u]);
+            if (ok[u]) {
+                store_quad<false>(op.theta, qg[u], R[u].th);
+                store_quad<false>(op.V, qg[u], R[u].v);
+                tsq += ((R[u].th[0] * R[u].th[0] + R[u].th[1] * R[u].th[1]) + R[u].th[2] * R[u].th[2]) + R[u].th[3] * R[u].th[3];
             }
         }
     }
+    __syncthreads();                                       // the next tile's K loop overwrites the stage buffers
 }
 
-__global__ void __launch_bounds__(256, 2) gemm_tn_sghmc_kernel(const FusedArgs a)
+__global__ void __launch_bounds__(256, 4) gemm_tn_sghmc_kernel(const FusedArgs a)
 {
+    __shared__ Stages<FT> lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     NoiseKey nk = a.nk;
     nk.resolve();
     float tsq = 0.f;                                       // this lane's share of sum theta'^2
+    SghmcOp<float, false, false> op{a.theta, a.V, nullptr, nullptr, nullptr, nullptr, const_cast<float *>(a.minv), nullptr, nullptr,
+                                    a.e2, a.c1, a.c3, a.e4, a.mdecay, a.grad_decay, nk, nullptr};
     if ((int)blockIdx.x >= a.n_gemm_blocks) {
         // ---- the parameters after W (bias, ...): the streaming update K1 on their quads, same Philox stream
         const size_t base = (size_t)a.g.M * a.g.N;         // multiple of 4 (N % 128 == 0)
-        SghmcOp<float, false, false> op{a.theta + base, a.V + base, a.grad_tail, nullptr, nullptr, nullptr,
-                                        const_cast<float *>(a.minv) + base, nullptr, nullptr,
-                                        a.e2, a.c1, a.c3, a.e4, a.mdecay, a.grad_decay, nk, nullptr};
+        op.theta += base; op.V += base; op.minv += base; op.grad = a.grad_tail;
         op.nk.q0 = nk.q0 + base / 4;
         const size_t nq_full = a.n_tail / 4;
         const int tail = (int)(a.n_tail % 4);
@@ -298,14 +314,25 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_sghmc_kernel(const FusedArgs a
         const int tiles_n = a.g.N / FT::BN, tiles_m = (a.g.M + FT::BM - 1) / FT::BM;
         const int n_tiles = tiles_m * tiles_n;
         const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-        // de-phasing: co-resident workgroups that start together stay in lockstep (product, then update, product, ...), so the
-        // matrix cores idle while every workgroup of the CU updates. Half of the workgroups start late by about one update.
-        if (a.stagger_sleeps > 0 && (a.stagger_mode == 0 ? (blockIdx.x & 1) : ((int)blockIdx.x >= a.n_gemm_blocks / 2)))
-            for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+        if (a.phase_counters != nullptr) {
+            // De-phasing. Workgroups that share a CU and start together stay in lockstep -- all in the product (matrix cores
+            // busy, HBM idle), then all in the update (HBM busy, matrix cores idle). Every second workgroup that arrives on a
+            // CU (counted per hardware CU id) therefore starts one update-phase late, so that one half updates while the other
+            // half multiplies.
+            __shared__ int late;
+            if (tid == 0) {
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+                const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID [3:0]
+                const unsigned key = ((xcc & 7u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+                late = atomicAdd(&a.phase_counters[key], 1) & 1;
+            }
+            __syncthreads();
+            if (late)
+                for (int i = 0; i < a.phase_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+        }
         for (int t = blockIdx.x; t < n_tiles; t += a.n_gemm_blocks) {
             const int m0 = (t / tiles_n) * FT::BM, n0 = (t % tiles_n) * FT::BN;
-            if (m0 + FT::BM <= a.g.M) fused_tile<true>(a, nk, m0, n0, wm, wn, lane, tsq);
-            else fused_tile<false>(a, nk, m0, n0, wm, wn, lane, tsq);
+            fused_tile(a, lds, op, m0, n0, wm, wn, lane, tsq);
         }
     }
     if (a.stats != nullptr) {
@@ -367,7 +394,8 @@ int sgmcmc_gemm_tn_sghmc_f32(const float *A, const float *B, int M, int N, int K
                              const float *minv, const float *grad_tail, size_t n_tail, float *grad_out, float eps,
                              float scale_grad, float mdecay, float grad_decay, uint64_t seed, uint64_t step,
                              const uint64_t *step_dev, uint64_t first_element, void *stats_ws, uint32_t stats_record_base,
-                             uint32_t stats_record_total, int gemm_blocks, sgmcmc_stream_t stream)
+                             uint32_t stats_record_total, int gemm_blocks, int *phase_counters, int phase_sleeps,
+                             sgmcmc_stream_t stream)
 {
     if (!A || !B || !theta || !V || !minv || (n_tail && !grad_tail)) return fail(SGMCMC_EINVAL, "gemm_tn_sghmc: NULL argument");
     if (M <= 0 || N <= 0 || K <= 0 || N % 128 || K % FT::BK || M % 4 || lda < M || ldb < N || lda % 4 || ldb % 4 ||
@@ -391,11 +419,9 @@ int sgmcmc_gemm_tn_sghmc_f32(const float *A, const float *B, int M, int N, int K
     a.nk.step_dev = step_dev; a.nk.q0 = first_element / 4;
     a.stats = static_cast<double *>(stats_ws); a.rec_base = stats_record_base; a.rec_total = stats_record_total;
     const int n_tiles = ((M + FT::BM - 1) / FT::BM) * (N / FT::BN);
-    a.stagger_sleeps = (gemm_blocks >> 16) & 0xff;        // experiment knobs in the high bits (tools/gemm_probe3.py)
-    a.stagger_mode = (gemm_blocks >> 24) & 0xf;
-    gemm_blocks &= 0xffff;
-    if (gemm_blocks <= 0) gemm_blocks = 512;              // 2 persistent workgroups per CU
+    if (gemm_blocks <= 0) gemm_blocks = 1024;             // 4 workgroups per CU
     a.n_gemm_blocks = gemm_blocks < n_tiles ? gemm_blocks : n_tiles;
+    a.phase_counters = phase_counters; a.phase_sleeps = phase_sleeps;
     hipLaunchKernelGGL(gemm_tn_sghmc_kernel, dim3(a.n_gemm_blocks + tail_blocks_for(n_tail)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), a);
     hipError_t e = hipGetLastError();
@@ -406,8 +432,7 @@ int sgmcmc_gemm_tn_sghmc_f32(const float *A, const float *B, int M, int N, int K
 int sgmcmc_gemm_tn_sghmc_blocks(int M, int N, size_t n_tail, int gemm_blocks)
 {
     const int n_tiles = ((M + FT::BM - 1) / FT::BM) * (N / FT::BN);
-    gemm_blocks &= 0xffff;
-    if (gemm_blocks <= 0) gemm_blocks = 512;
+    if (gemm_blocks <= 0) gemm_blocks = 1024;
     const int gb = gemm_blocks < n_tiles ? gemm_blocks : n_tiles;
     return gb + (int)tail_blocks_for(n_tail);
 }

@@ -324,7 +324,8 @@ def gemm_tn(a, b, out, variant=0):
 
 
 def gemm_tn_sghmc(a, b, theta, V, minv, grad_tail, eps, scale_grad, mdecay, grad_decay=0.0, seed=0, step=0, step_dev=None,
-                  first_element=0, stats=None, stats_base=0, stats_total=0, grad_out=None, gemm_blocks=0):
+                  first_element=0, stats=None, stats_base=0, stats_total=0, grad_out=None, gemm_blocks=0,
+                  phase_counters=None, phase_sleeps=0):
     """Weight-gradient product ``a[K, M]^T @ b[K, N]`` with the frozen SGHMC update of the layer as its epilogue
     (``sgmcmc_gemm_tn_sghmc_f32``). ``theta`` / ``V`` / ``minv``: the layer's slice of the arena rows -- the ``M * N``
     weights followed by ``grad_tail.numel()`` more parameters whose gradient ``grad_tail`` already holds."""
@@ -341,7 +342,7 @@ def gemm_tn_sghmc(a, b, theta, V, minv, grad_tail, eps, scale_grad, mdecay, grad
             a.data_ptr(), b.data_ptr(), M, N, K, a.stride(0), b.stride(0), _ptr(theta), _ptr(V, theta), _ptr(minv, theta),
             _ptr(grad_tail), n_tail, _ptr(grad_out), float(eps), float(scale_grad), float(mdecay), float(grad_decay),
             int(seed), int(step), _ctr(step_dev), int(first_element), None if stats is None else _ptr(stats.workspace),
-            int(stats_base), int(stats_total), int(gemm_blocks), _stream(a))
+            int(stats_base), int(stats_total), int(gemm_blocks), _ptr(phase_counters), int(phase_sleeps), _stream(a))
     check(rc, "sgmcmc_gemm_tn_sghmc_f32")
 
 

@@ -54,9 +54,15 @@ for (M, N, K, n_tail, first) in ((2048, 2048, 256, 2048, 1607680), (784, 2048, 2
         kernels.gemm_tn_sghmc(a, b, th, V, minv, gtail, 0.01, 1e5, 0.05, seed=11, step=5, first_element=first, stats=st,
                               gemm_blocks=blocks)
     print("    library GEMM + K1 slice: %.1f us" % t(separate), flush=True)
-    for blocks in (256, 512, 1024):
+    for blocks in (256, 512, 768, 1024, 2048):
         print("    fused, %4d persistent workgroups: %.1f us" % (blocks, t(lambda: fused(blocks))), flush=True)
     for mode in (0, 1):
-        for sl in (1, 2, 3, 4):
-            print("    fused, 512 workgroups, stagger mode %d x %d: %.1f us" % (mode, sl, t(lambda: fused(512 | (sl << 16) | (mode << 24)))), flush=True)
+        for sl in (1, 2):
+            print("    fused, 1024 workgroups, stagger mode %d x %d: %.1f us" % (mode, sl, t(lambda: fused(1024 | (sl << 16) | (mode << 24)))), flush=True)
+    pc = torch.zeros(2048, dtype=torch.int32, device=dev)
+    for sl in (1, 2, 3):
+        def fused_dephased():
+            kernels.gemm_tn_sghmc(a, b, th, V, minv, gtail, 0.01, 1e5, 0.05, seed=11, step=5, first_element=first, stats=st,
+                                  phase_counters=pc, phase_sleeps=sl)
+        print("    fused, de-phased by %d x 3.4 us: %.1f us   (CU keys seen: %d)" % (sl, t(fused_dephased), int((pc > 0).sum())), flush=True)
     th.copy_(theta0); V.copy_(V0); th2.copy_(theta0); V2.copy_(V0)
