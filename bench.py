@@ -938,7 +938,9 @@ def main():
             "gemm_flop_per_step": int(g_flops),
             "note": "gemm = the step's eight fp32 library GEMMs replayed alone from a hipGraph; small_launches = the captured "
                     "cost pipeline alone minus gemm (tanh, tanh-backward + bias gradient, loss head, window gather ...); "
-                    "update = the fused update launched once after the backward pass"}
+                    "update = the fused update launched once after the backward pass. Differences of graph replays: rocprofv3's "
+                    "per-kernel durations of the same step (profiles/r03_bench10m_kernel_stats.csv: GEMMs 136, seven small "
+                    "launches 37, update 35 us) carry ~1.5 us of profiler overhead per kernel"}
     if not args.no_update_only and kind == "sghmc":
         line["update_only"] = update_only(sampler)
         del moments, trace

@@ -186,6 +186,9 @@ class BNNCost(object):
         self.fuse_tanh_rowdot = True                      # measured 228.2 vs 231.3 us per step at 10 M parameters
         # loss head folded into the single-output layer's backward launch (every dependent launch of the step costs ~5 us)
         self.fuse_head = True
+        # weight-gradient products gW = h^T delta: "blas" (rocBLAS / hipBLASLt through torch) or "mfma" (kernels.gemm_tn, the
+        # product the fused GEMM + update kernel forms: same bits as that kernel's gradient)
+        self.gw_gemm = "blas"
         # (Forking the weight-gradient GEMMs onto a second stream inside the captured graph was measured
         # on MI355X at batch 256: 291 us/step vs 275 us on one stream -- not kept.)
 
@@ -227,13 +230,14 @@ class BNNCost(object):
         return ws
 
     @torch.no_grad()
-    def cost_and_grad(self, params, grad_views, theta_sumsq=None, theta_sumsq_partials=None):
+    def cost_and_grad(self, params, grad_views, theta_sumsq=None, theta_sumsq_partials=None, weight_update=None):
         """NLL at ``params`` with d NLL/d params written into ``grad_views`` (views of the sampler's
         gradient arena): rocBLAS GEMMs + the library's loss-head and fused tanh-backward/bias-gradient
         kernels (~20 launches per step for 4 layers)."""
         if self.use_hip_kernels:
             # no silent fallback: the HIP path needs device tensors (kernels.* raises on CPU tensors)
-            return self._cost_and_grad_hip(params, grad_views, theta_sumsq, theta_sumsq_partials)
+            return self._cost_and_grad_hip(params, grad_views, theta_sumsq, theta_sumsq_partials, weight_update)
+        assert weight_update is None, "the weight-update hook belongs to the HIP path"
         return self._cost_and_grad_torch(params, grad_views, theta_sumsq)
 
     def _forward(self, params, X, hs):
@@ -270,15 +274,19 @@ class BNNCost(object):
         cannot hold a grad-mode context across its yields)."""
         return self._hip_pipeline(params, grad_views, theta_sumsq, theta_sumsq_partials)
 
-    def _cost_and_grad_hip(self, params, grad_views, theta_sumsq, theta_sumsq_partials=None):
-        gen = self._hip_pipeline(params, grad_views, theta_sumsq, theta_sumsq_partials)
+    def _cost_and_grad_hip(self, params, grad_views, theta_sumsq, theta_sumsq_partials=None, weight_update=None):
+        gen = self._hip_pipeline(params, grad_views, theta_sumsq, theta_sumsq_partials, weight_update)
         while True:
             try:
                 next(gen)
             except StopIteration as stop:
                 return stop.value
 
-    def _hip_pipeline(self, params, grad_views, theta_sumsq, theta_sumsq_partials=None):
+    def _hip_pipeline(self, params, grad_views, theta_sumsq, theta_sumsq_partials=None, weight_update=None):
+        """``weight_update(l, h_in, delta_l)`` (optional): called where the weight-gradient product of hidden layer ``l``
+        would be issued -- every gradient that follows W_l in the arena up to the next layer's weights is complete and W_l is
+        no longer read. If it returns True the caller has consumed the product itself (the sampler's GEMM + update kernel,
+        ``kernels.gemm_tn_sghmc``) and ``grad_views[2 l]`` is NOT written."""
         from pysgmcmc_amd import kernels
         X, Y = self.x_placeholder.value, self.y_placeholder.value
         B = X.shape[0]
@@ -351,7 +359,11 @@ class BNNCost(object):
                 torch.mm(ds[l], W.t(), out=ds[l - 1])
             # gW_l = h_{l-1}^T delta_l written directly into the gradient arena. The weight-prior term
             # coef * theta is added by the update kernel (fold_prior) or rides in the GEMM epilogue (beta).
-            if self.fold_prior:
+            if weight_update is not None and weight_update(l, h_in, ds[l]):
+                pass                                          # product + update of this layer's slice done by the sampler's kernel
+            elif self.gw_gemm == "mfma" and self.fold_prior and W.dtype == torch.float32:
+                kernels.gemm_tn(h_in, ds[l], grad_views[2 * l])   # the library's own fp32 matrix-core product (k-ordered fmaf chain)
+            elif self.fold_prior:
                 torch.mm(h_in.t(), ds[l], out=grad_views[2 * l])
             else:
                 torch.addmm(W, h_in.t(), ds[l], beta=prior_coef, alpha=1.0, out=grad_views[2 * l])

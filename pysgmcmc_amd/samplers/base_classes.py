@@ -151,6 +151,13 @@ class MCMCSampler(object):
         # cross-queue synchronisation costs ~40 us per step whatever the update's grid): off by default, kept for
         # the measurement.
         self.overlap_update = False
+        # SGHMC + an MLP cost function (BNNCost), frozen phase: the weight-gradient GEMM of every hidden layer carries the
+        # update of that layer's slice of the arena as its epilogue (kernels.gemm_tn_sghmc) -- no separate update launch, no
+        # gradient round trip through HBM for the weights. Needs use_hip_graph = True. The chain differs from the default
+        # path only through the summation order of the weight-gradient products (BNNCost.gw_gemm = "mfma" reproduces it
+        # bit for bit with the un-fused kernels).
+        self.fuse_update_into_gemm = False
+        self._fused_plan = None
         self._slice_plan = None
         self._slice_launch = None
         self._side_stream = None
@@ -172,6 +179,7 @@ class MCMCSampler(object):
         self._graphs.clear()
         self._static_feeds.clear()
         self._slice_plan = None
+        self._fused_plan = None
         self._stats_valid = False
         self._view_cache = None
 
@@ -482,6 +490,11 @@ class MCMCSampler(object):
         self._ensure_stats()
         if self.use_hip_graph == "full":
             return self._step_graph_full(eps)
+        if self.fuse_update_into_gemm and self._fused_plan is not False and not getattr(self, "_adapting", False) \
+                and not self._moments_due() and hasattr(self, "_fused_gemm_plan"):
+            done = self._step_graph_fused_gemm(eps)
+            if done is not None:
+                return done
         entry = self._graphs.get(("cost",))
         if entry is None:
             entry = self._graphs[("cost",)] = self._capture_cost()
@@ -492,6 +505,39 @@ class MCMCSampler(object):
                 self._update(eps, None)
             else:
                 self._replay_overlapped(segments, eps)
+        self.cost = cost
+        return self._finish_step(cost)
+
+    def _step_graph_fused_gemm(self, eps):
+        """Frozen step whose update rides in the weight-gradient GEMMs (see ``fuse_update_into_gemm``): ONE graph holds the
+        cost pipeline, the fused GEMM + update launches (Philox step from the device counter) and the counter increment.
+        Returns None when the model does not fit the fused kernel (the caller then steps the usual way)."""
+        if self._fused_plan is None:
+            self._fused_plan = self._fused_gemm_plan() or False
+            if self._fused_plan is False:
+                return None
+        plan, total = self._fused_plan
+        if self._step_ctr is None:
+            self._step_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
+        if self._ctr_value != self.n_iterations:
+            self._step_ctr.fill_(self.n_iterations)
+            self._ctr_value = self.n_iterations
+        key = ("fused_gemm", float(eps))
+        entry = self._graphs.get(key)
+        if entry is None:
+            self._warm_cost()
+            graph = torch.cuda.CUDAGraph()
+            self._fused_grad_decay = float(getattr(self.cost_fun, "grad_theta_coef", 0.0))    # set by the warm-up evaluation
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"), torch.no_grad():
+                cost = self.cost_fun.cost_and_grad(self.params, self.arena.grad_views,
+                                                   weight_update=self._fused_weight_update(plan, total, eps), **self._cost_kwargs())
+                kernels.counter_add(self._step_ctr, 1)
+            cost = cost.detach() if isinstance(cost, torch.Tensor) else torch.as_tensor(cost)
+            entry = self._graphs[key] = (graph, cost)
+        graph, cost = entry
+        graph.replay()
+        self._ctr_value += 1
+        self._stats_written()
         self.cost = cost
         return self._finish_step(cost)
 

@@ -56,3 +56,59 @@ def test_fused_gemm_update_equals_k1_on_the_gradient_it_computed(gpu, M, N, K, n
         assert (gout.double() - a.double().t() @ b.double()).abs().max().item() < 1e-5
         assert np.isclose(kernels.step_stats_finish(st)[0].item(), (th.double() ** 2).sum().item(), rtol=1e-6)
         assert int(st.workspace.view(torch.int64)[0]) == kernels.gemm_tn_sghmc_blocks(M, N, n_tail, blocks)
+
+
+def _bnn_sghmc(gpu, fused, gw_gemm, graph=True, steps=12, moments_every=0):
+    from pysgmcmc_amd.data_batches import Placeholder, generate_batches
+    from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments
+    from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
+    from pysgmcmc_amd.samplers import SGHMCSampler
+    from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+    rng = np.random.RandomState(0)
+    X, y = rng.rand(600, 20), rng.rand(600)
+    xp, yp = Placeholder(dtype=torch.float32, device=gpu), Placeholder(dtype=torch.float32, device=gpu)
+    params = init_mlp_params(20, hidden=(128, 256, 128), seed=5, dtype=torch.float32, device=gpu)      # 20->128->256->128->1
+    cost = BNNCost(xp, yp, batch_size=64, n_examples=600)
+    cost.gw_gemm = gw_gemm
+    s = SGHMCSampler(params=params, cost_fun=cost, batch_generator=generate_batches(X, y, xp, yp, batch_size=64, seed=2),
+                     stepsize_schedule=ConstantStepsizeSchedule(0.01), burn_in_steps=4, scale_grad=600.0, session=gpu,
+                     dtype=torch.float32, seed=9)
+    s.sample_format = "view"
+    s.use_hip_graph = graph
+    s.collect_stats = "theta_sq"
+    s.fuse_update_into_gemm = fused
+    m = ChainMoments(s.arena.n, gpu)
+    if moments_every:
+        s.attach_moments(m, moments_every)
+    costs = [float(next(s)[1]) for _ in range(steps)]
+    torch.cuda.synchronize()
+    return s, m, costs
+
+
+def test_sampler_with_the_update_fused_into_the_weight_gradient_gemms(gpu):
+    """``fuse_update_into_gemm``: after burn-in every hidden layer's weight-gradient GEMM carries the update of that layer's
+    slice (no update launch). The chain equals, BIT FOR BIT, the un-fused sampler whose weight-gradient products come from
+    the same matrix-core kernel (``gw_gemm = "mfma"``) -- through the burn-in switch and moments steps (which step un-fused)
+    -- and agrees with the library-GEMM sampler to summation-order rounding."""
+    fused, mf, cf = _bnn_sghmc(gpu, True, "mfma", moments_every=5)
+    plain, mp, cp = _bnn_sghmc(gpu, False, "mfma", moments_every=5)
+    blas, _, cb = _bnn_sghmc(gpu, False, "blas", moments_every=5)
+    assert any(k[0] == "fused_gemm" for k in fused._graphs) and not any(k[0] == "fused_gemm" for k in plain._graphs)
+    plan, total = fused._fused_plan
+    assert [p["layer"] for p in plan] == [0, 1, 2] and plan[-1]["hi"] == fused.arena.n and plan[0]["lo"] == 0
+    for row in ("theta", "V", "minv"):
+        assert torch.equal(fused.arena.row(row), plain.arena.row(row)), row
+    assert torch.equal(mf.mean, mp.mean) and torch.equal(mf.m2, mp.m2) and mf.count == mp.count == 2
+    assert np.allclose(cf, cp, rtol=1e-6) and np.allclose(cf, cb, rtol=1e-4)
+    assert torch.allclose(fused.arena.row("theta"), blas.arena.row("theta"), rtol=1e-3, atol=1e-5)
+    st = fused.stats
+    assert np.isclose(st["theta_sq"], (fused.arena.row("theta").double() ** 2).sum().item(), rtol=1e-6)
+    # a model the kernel does not fit (fan_out not a multiple of 128) steps the usual way
+    from pysgmcmc_amd.samplers import SGHMCSampler
+    s = SGHMCSampler(params=[torch.zeros(8, device=gpu)], cost_fun=lambda p: (p[0] ** 2).sum(), burn_in_steps=1, session=gpu,
+                     dtype=torch.float32, seed=1)
+    s.use_hip_graph = True
+    s.fuse_update_into_gemm = True
+    for _ in range(4):
+        next(s)
+    assert s._fused_plan is False
