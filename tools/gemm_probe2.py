@@ -8,7 +8,7 @@ from pysgmcmc_amd.models.bayesian_neural_network import enable_gemm_tuning
 
 dev = torch.device("cuda:0")
 enable_gemm_tuning(True, max_duration_ms=30, max_iterations=20)
-for (M, N, K) in ((2048, 2048, 256), (784, 2048, 256), (132, 256, 64)):
+for (M, N, K) in ((2048, 2048, 256), (784, 2048, 256), (132, 256, 128)):
     g = torch.Generator(device=dev).manual_seed(0)
     a = torch.randn(K, M, device=dev, generator=g)
     b = torch.randn(K, N, device=dev, generator=g)
