@@ -248,7 +248,7 @@ int sgmcmc_gemm_tn_f32(const float *A, const float *B, float *C, int M, int N, i
  *   grad_out:      NULL, or [M][N]: also write gW (tests: K1 on this gradient gives the same theta', V' bit for bit)
  *   stats_ws / stats_record_*: as sgmcmc_step_opts_t; one {sum theta'^2, 0, 0, 0} record per workgroup,
  *                  sgmcmc_gemm_tn_sghmc_blocks() = the launch's workgroup count. gemm_blocks: 0 = default (512).
- *   K % 32 == 0, N % 128 == 0, M % 4 == 0.                                                                        */
+ *   K % 16 == 0, N % 128 == 0, M % 4 == 0.                                                                        */
 int sgmcmc_gemm_tn_sghmc_f32(const float *A, const float *B, int M, int N, int K, int lda, int ldb, float *theta, float *V,
                              const float *minv, const float *grad_tail, size_t n_tail, float *grad_out, float eps,
                              float scale_grad, float mdecay, float grad_decay, uint64_t seed, uint64_t step,

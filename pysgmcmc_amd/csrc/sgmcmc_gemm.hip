@@ -46,14 +46,19 @@ struct GemmArgs {
     const float *A, *B;       // [K][lda], [K][ldb]
     float *C;                 // [M][ldc] (plain mode, or the optional gradient copy of the fused mode)
     int M, N, K, lda, ldb, ldc;
+    int probe = 0;            // timing experiments (tools/gemm_probe2.py): 1 = no output store
 };
 
 // One workgroup = WM x WN waves, each wave owns TM x TN MFMA tiles of 32 x 32: block tile BM = 32 TM WM by BN = 32 TN WN.
 // K advances in chunks of BK through a double-buffered LDS stage; inside a chunk the MFMAs run in sub-batches of 8 k-steps
 // whose operand fragments are read from LDS one sub-batch ahead.
-template <int TM, int TN, int WM, int WN, int BK_>
+// SUB: k-steps whose fragments are read ahead; FENCE: pin "read the next sub-batch, then issue this one's MFMAs" with
+// sched_barriers (measured: the compiler's own interleave is 2-3 us faster at 2048 x 2048 x 256, so the default is off;
+// s_setprio around the MFMAs costs 1.5-2.5 us).
+template <int TM, int TN, int WM, int WN, int BK_, int SUB_ = 4, bool FENCE_ = false>
 struct Tile {
-    static constexpr int BK = BK_;
+    static constexpr int BK = BK_, SUB = SUB_;
+    static constexpr bool FENCE = FENCE_;
     static constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
     static constexpr int LA = BK * BM / 4 / NT, LB = BK * BN / 4 / NT;      // float4 loads per lane per chunk
     static_assert(LA >= 1 && LB >= 1 && LA * NT * 4 == BK * BM && LB * NT * 4 == BK * BN, "chunk must divide over the lanes");
@@ -80,8 +85,8 @@ __device__ __forceinline__ void mainloop(const GemmArgs &g, Stages<TL> &lds, int
                                          f32x16 (&acc)[TM][TN], LastChunkHook hook = LastChunkHook())
 {
     constexpr int BK = TL::BK, BM = TL::BM, BN = TL::BN, NT = TL::NT, LA = TL::LA, LB = TL::LB;
-    constexpr int SUB = 4, NSUB = BK / 2 / SUB;             // k-steps (of 2) per sub-batch, sub-batches per chunk
-    static_assert(NSUB >= 1 && NSUB * SUB * 2 == BK, "BK must be a multiple of 8");
+    constexpr int SUB = TL::SUB, NSUB = BK / 2 / SUB;       // k-steps (of 2) per sub-batch, sub-batches per chunk
+    static_assert(NSUB >= 1 && NSUB * SUB * 2 == BK, "BK must be a multiple of 2 SUB");
     const int tid = threadIdx.x, lane = tid & 63;
     const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4_t ra[LA], rb[LB];
@@ -136,7 +141,7 @@ __device__ __forceinline__ void mainloop(const GemmArgs &g, Stages<TL> &lds, int
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
             if (sub + 1 < NSUB) frags(s, sub + 1, (sub + 1) & 1);   // next sub-batch's fragments are requested first ...
-            __builtin_amdgcn_sched_barrier(0);
+            if (TL::FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < SUB; ++kk)                         // ... and land under these MFMAs
 #pragma unroll
@@ -144,7 +149,7 @@ __device__ __forceinline__ void mainloop(const GemmArgs &g, Stages<TL> &lds, int
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sub & 1][kk][i], bf[sub & 1][kk][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (TL::FENCE) __builtin_amdgcn_sched_barrier(0);
         }
     };
     for (int kc = 0; kc + 1 < nk; ++kc) {
@@ -164,10 +169,10 @@ __device__ __forceinline__ void mainloop(const GemmArgs &g, Stages<TL> &lds, int
     }
 }
 
-template <int TM, int TN, int WM, int WN, int BK>
+template <int TM, int TN, int WM, int WN, int BK, int SUB = 4, bool FENCE = false>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_tn_kernel(const GemmArgs g)
 {
-    typedef Tile<TM, TN, WM, WN, BK> TL;
+    typedef Tile<TM, TN, WM, WN, BK, SUB, FENCE> TL;
     const int m0 = blockIdx.y * TL::BM, n0 = blockIdx.x * TL::BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave / WN) * 32 * TM, wn = (wave % WN) * 32 * TN;
@@ -211,9 +216,9 @@ __device__ __forceinline__ float quad_bcast(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-// 64 x 64 output tile, 4 waves of 32 x 32, K in chunks of 32: a workgroup walks over tiles blockIdx.x, + gridDim, ...
+// 64 x 64 output tile, 4 waves of 32 x 32, K in chunks of 16: a workgroup walks over tiles blockIdx.x, + gridDim, ...
 // (persistent), so the asynchronous theta'/V' stores of one tile drain under the MFMAs of the next.
-typedef Tile<1, 1, 2, 2, 32> FT;
+typedef Tile<1, 1, 2, 2, 16> FT;
 
 // 256-lane blocks for the n_tail parameters after W (one quad per lane per trip; at least one block if there are any)
 inline unsigned tail_blocks_for(size_t n_tail)
@@ -223,8 +228,8 @@ inline unsigned tail_blocks_for(size_t n_tail)
     return (unsigned)(blocks ? blocks : 1);
 }
 
-// One 64 x 64 tile: product, then the update of the tile. The accumulators go through LDS (the K loop's stage buffers are
-// free by then) so that the update runs on ROW-MAJOR QUADS exactly like the streaming kernel K1: a lane owns 4 consecutive
+// One 64 x 64 tile: product, then the update of the tile. The accumulators go through LDS so that the update runs on
+// ROW-MAJOR QUADS exactly like the streaming kernel K1: a lane owns 4 consecutive
 // columns of a row = one Philox quad and one 16-byte access per array (16 lanes cover a 256-byte row segment), the arithmetic
 // is SghmcOp::compute itself. (A first version kept the MFMA accumulator layout -- one column per lane, dword accesses, a
 // 4 x 4 DPP transpose of the normals over each lane quad: 32.8 us at 2048 x 2048 against this version's figure in
@@ -234,10 +239,9 @@ constexpr int TP = FT::BN + 4;                             // LDS pitch of the a
 __device__ __forceinline__ void fused_tile(const FusedArgs &a, Stages<FT> &lds, const SghmcOp<float, false, false> &op, int m0, int n0,
                                            int wm, int wn, int lane, float &tsq)
 {
-    static_assert(sizeof(Stages<FT>) >= sizeof(float) * FT::BM * TP, "the accumulator tile reuses the stage buffers");
-    float *T = &lds.A[0][0][0];
+    __shared__ float T[FT::BM * TP];                       // the tile's accumulators, row-major (17 KB next to the 16 KB of stages)
     f32x16 acc[1][1];
-    mainloop<FT, 1, 1>(a.g, lds, m0, n0, wm, wn, acc);          // ends with a barrier: the stages are free
+    mainloop<FT, 1, 1>(a.g, lds, m0, n0, wm, wn, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r)
         T[(wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TP + wn + (lane & 31)] = acc[0][0][r];
@@ -273,7 +277,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &a, Stages<FT> &lds, 
             }
         }
     }
-    __syncthreads();                                       // the next tile's K loop overwrites the stage buffers
+    __syncthreads();                                       // T is rewritten by the next tile
 }
 
 __global__ void __launch_bounds__(256, 4) gemm_tn_sghmc_kernel(const FusedArgs a)
@@ -350,12 +354,12 @@ __global__ void __launch_bounds__(256, 4) gemm_tn_sghmc_kernel(const FusedArgs a
     }
 }
 
-template <int TM, int TN, int WM, int WN, int BK>
+template <int TM, int TN, int WM, int WN, int BK, int SUB = 4, bool FENCE = false>
 int launch_gemm(const GemmArgs &g, hipStream_t st)
 {
-    typedef Tile<TM, TN, WM, WN, BK> TL;
+    typedef Tile<TM, TN, WM, WN, BK, SUB, FENCE> TL;
     if (g.K % BK) return fail(SGMCMC_EINVAL, "gemm_tn: K must be a multiple of the variant's chunk");
-    hipLaunchKernelGGL((gemm_tn_kernel<TM, TN, WM, WN, BK>), dim3(g.N / TL::BN, (g.M + TL::BM - 1) / TL::BM), dim3(TL::NT), 0, st, g);
+    hipLaunchKernelGGL((gemm_tn_kernel<TM, TN, WM, WN, BK, SUB, FENCE>), dim3(g.N / TL::BN, (g.M + TL::BM - 1) / TL::BM), dim3(TL::NT), 0, st, g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch gemm_tn");
 }
@@ -374,17 +378,20 @@ int sgmcmc_gemm_tn_f32(const float *A, const float *B, float *C, int M, int N, i
         ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15u))
         return fail(SGMCMC_EINVAL, "gemm_tn: needs N %% 128 == 0, K %% 16 == 0, M %% 4 == 0, 16-byte aligned operands");
     GemmArgs g{A, B, C, M, N, K, lda, ldb, ldc};
+    g.probe = (variant >> 8) & 1;
+    if ((variant >> 9) & 1) g.K = 64;                     // probe: a quarter of the K loop
+    variant &= 0xff;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (variant) {
-    case 0: return launch_gemm<1, 2, 4, 2, 16>(g, st);    // 128 x 128, 8 waves of 32 x 64, K chunks of 16
-    case 1: return launch_gemm<1, 2, 4, 2, 32>(g, st);    //                                          ... of 32
-    case 2: return launch_gemm<1, 2, 4, 2, 64>(g, st);    //                                          ... of 64
-    case 3: return launch_gemm<2, 2, 2, 2, 32>(g, st);    // 128 x 128, 4 waves of 64 x 64, 32
-    case 4: return launch_gemm<2, 2, 2, 2, 64>(g, st);    //                                 64
-    case 5: return launch_gemm<1, 1, 2, 2, 32>(g, st);    //  64 x  64, 4 waves of 32 x 32, 32
-    case 6: return launch_gemm<1, 1, 2, 2, 64>(g, st);    //                                 64
-    case 7: return launch_gemm<1, 2, 2, 2, 32>(g, st);    //  64 x 128, 4 waves of 32 x 64, 32
-    case 8: return launch_gemm<1, 2, 2, 2, 64>(g, st);    //                                 64
+    case 0: return launch_gemm<1, 1, 2, 2, 16>(g, st);          //  64 x  64, 4 waves of 32 x 32, K chunks of 16 (the fused kernel's)
+    case 1: return launch_gemm<1, 1, 2, 2, 32>(g, st);          //                                              32
+    case 2: return launch_gemm<1, 1, 2, 2, 64>(g, st);          //                                              64
+    case 3: return launch_gemm<1, 2, 4, 2, 32>(g, st);          // 128 x 128, 8 waves of 32 x 64
+    case 4: return launch_gemm<1, 2, 4, 2, 64>(g, st);
+    case 5: return launch_gemm<2, 2, 2, 2, 32>(g, st);          // 128 x 128, 4 waves of 64 x 64
+    case 6: return launch_gemm<1, 2, 2, 2, 32>(g, st);          //  64 x 128, 4 waves of 32 x 64
+    case 7: return launch_gemm<2, 1, 2, 2, 32>(g, st);          // 128 x  64, 4 waves of 64 x 32
+    case 8: return launch_gemm<1, 1, 2, 2, 32, 4, true>(g, st); //  64 x  64 with the scheduling fences
     default: return fail(SGMCMC_EINVAL, "gemm_tn: unknown variant");
     }
 }
@@ -400,7 +407,7 @@ int sgmcmc_gemm_tn_sghmc_f32(const float *A, const float *B, int M, int N, int K
     if (!A || !B || !theta || !V || !minv || (n_tail && !grad_tail)) return fail(SGMCMC_EINVAL, "gemm_tn_sghmc: NULL argument");
     if (M <= 0 || N <= 0 || K <= 0 || N % 128 || K % FT::BK || M % 4 || lda < M || ldb < N || lda % 4 || ldb % 4 ||
         ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15u))
-        return fail(SGMCMC_EINVAL, "gemm_tn_sghmc: needs N %% 128 == 0, K %% 32 == 0, M %% 4 == 0, 16-byte aligned operands");
+        return fail(SGMCMC_EINVAL, "gemm_tn_sghmc: needs N %% 128 == 0, K %% 16 == 0, M %% 4 == 0, 16-byte aligned operands");
     if (first_element % 4 || ((reinterpret_cast<uintptr_t>(theta) | reinterpret_cast<uintptr_t>(V) |
                                reinterpret_cast<uintptr_t>(minv) | reinterpret_cast<uintptr_t>(grad_tail)) & 15u))
         return fail(SGMCMC_EINVAL, "gemm_tn_sghmc: the slice must start on a quad (first_element %% 4 == 0, 16-byte aligned arrays)");

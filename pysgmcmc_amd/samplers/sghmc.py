@@ -86,7 +86,7 @@ class SGHMCSampler(FusedBNNStepsMixin, BurnInMCMCSampler):
 
         def hook(l, h_in, delta):
             p = by_layer.get(l)
-            if p is None or h_in.shape[0] % 32:
+            if p is None or h_in.shape[0] % 16:
                 return False
             sl = slice(p["lo"], p["hi"])
             kernels.gemm_tn_sghmc(h_in, delta, a.row("theta")[sl], a.row("V")[sl], a.row("minv")[sl],

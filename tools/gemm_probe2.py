@@ -8,7 +8,7 @@ from pysgmcmc_amd.models.bayesian_neural_network import enable_gemm_tuning
 
 dev = torch.device("cuda:0")
 enable_gemm_tuning(True, max_duration_ms=30, max_iterations=20)
-for (M, N, K) in ((2048, 2048, 256), (784, 2048, 256), (132, 256, 128)):
+for (M, N, K) in ((2048, 2048, 256), (784, 2048, 256)):
     g = torch.Generator(device=dev).manual_seed(0)
     a = torch.randn(K, M, device=dev, generator=g)
     b = torch.randn(K, N, device=dev, generator=g)
@@ -38,4 +38,8 @@ for (M, N, K) in ((2048, 2048, 256), (784, 2048, 256), (132, 256, 128)):
         kernels.gemm_tn(a, b, out, variant=v)
         err = (out.double() - exact).abs().max().item()
         us = t(lambda: kernels.gemm_tn(a, b, out, variant=v))
-        print("    variant %d: max|err| %.2e  %.1f us (%.0f TF/s)" % (v, err, us, fl / us / 1e6), flush=True)
+        us_ns = t(lambda: kernels.gemm_tn(a, b, out, variant=v | 0x100))
+        us_q = t(lambda: kernels.gemm_tn(a, b, out, variant=v | 0x200)) if K >= 256 else float("nan")
+        us_qns = t(lambda: kernels.gemm_tn(a, b, out, variant=v | 0x300)) if K >= 256 else float("nan")
+        print("    variant %d: max|err| %.2e  %.1f us (%.0f TF/s) | no store %.1f | K/4 %.1f | K/4 no store %.1f" % (
+            v, err, us, fl / us / 1e6, us_ns, us_q, us_qns), flush=True)

@@ -56,9 +56,6 @@ for (M, N, K, n_tail, first) in ((2048, 2048, 256, 2048, 1607680), (784, 2048, 2
     print("    library GEMM + K1 slice: %.1f us" % t(separate), flush=True)
     for blocks in (256, 512, 768, 1024, 2048):
         print("    fused, %4d persistent workgroups: %.1f us" % (blocks, t(lambda: fused(blocks))), flush=True)
-    for mode in (0, 1):
-        for sl in (1, 2):
-            print("    fused, 1024 workgroups, stagger mode %d x %d: %.1f us" % (mode, sl, t(lambda: fused(1024 | (sl << 16) | (mode << 24)))), flush=True)
     pc = torch.zeros(2048, dtype=torch.int32, device=dev)
     for sl in (1, 2, 3):
         def fused_dephased():
