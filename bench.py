@@ -580,6 +580,25 @@ def cost_pipeline_us(sampler, iters=60):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+def update_kernel_instance(op_name, adapt, big, sampler, moments=False):
+    """Name of the stream_quads_vec instance the library launches for this sampler's update under the launch
+    configuration in effect (sampler.launch, else the Python-side default, else the library's defaults)."""
+    from pysgmcmc_amd import kernels
+    cfg = dict(kernels.get_launch_config())
+    if sampler.launch is not None:
+        cfg.update({k: v for k, v in sampler.launch.as_dict().items() if v != (-1 if k == "nontemporal" else 0)})
+    qpt = cfg["quads_per_thread"]
+    nt = big if cfg["nontemporal"] == 2 else bool(cfg["nontemporal"])
+    bt = cfg["block_threads"] if cfg["block_threads"] > 0 else (128 if big else 256)
+    loop = qpt != 1 or (sampler.arena.n // 4 + bt - 1) // bt > cfg["max_blocks"]
+    stats = {True: 1, "theta_sq": 2}.get(sampler.collect_stats, 0)
+    if loop and stats == 2:
+        stats = 1                                          # the looping variants reduce every statistic
+    return "stream_quads_vec<%s<float,%s,false>,%d,%s,%d,%s,%s> (%d-lane blocks)" % (
+        op_name, "true" if adapt else "false", qpt, "true" if nt else "false", stats, "true" if loop else "false",
+        "true" if (moments and not loop) else "false", bt)
+
+
 def launch_table(timer, n, bytes_per_param, moments_every):
     """Per-launch records of a timed region: (step, lo, hi, microseconds, algorithmic bytes). A launch of a moments
     step also carries the fused Welford update (+16 B per f32 parameter)."""
@@ -827,9 +846,10 @@ def main():
                        "prime_steps": {"burn_in": PRIME_BURN_IN, "frozen": PRIME_FROZEN + PRIME_STEADY},
                        "max_queue_depth": args.max_queue_depth,
                        "launch": kernels.get_launch_config(), "kernel_source_hash": kernel_source_hash()},
-            # template args: <Op<float, ADAPT, INJECT>, quads per lane, NT, STATS (2 = sum theta^2 only), LOOP, MOMENTS>
-            "roofline": {"bound": "hbm", "kernel": "stream_quads_vec<%s<float,%s,false>,1,%s,2,false,false>" % (
-                             op_name, "false" if frozen_phase else "true", "true" if big else "false"),
+            # template args: <Op<float, ADAPT, INJECT>, quads per lane, NT, STATS (2 = sum theta^2 only), LOOP, MOMENTS>, from
+            # the launch configuration in effect (library defaults: 1 quad per lane, nt iff the launch streams > 640 MiB,
+            # single-pass variant while the grid is uncapped)
+            "roofline": {"bound": "hbm", "kernel": update_kernel_instance(op_name, not frozen_phase, big, sampler),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
