@@ -127,6 +127,9 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="step eagerly instead of replaying one hipGraph per step")
     ap.add_argument("--max-queue-depth", type=int, default=64,
                     help="steps the host may run ahead of the device in the timed loop (0 = unbounded)")
+    ap.add_argument("--time-every", type=int, default=0,
+                    help="the update launches of every k-th timed step carry the HIP timestamp events (a timed launch costs ~8 us of "
+                         "device time per step); 0 = steps // 5 clamped to [1, 7]")
     ap.add_argument("--overlap", choices=["on", "off"], default=os.environ.get("BENCH_OVERLAP", "off"),
                     help="off (default): one update launch after the backward pass. on: update the arena layer by layer on a "
                          "side stream under the remaining backward GEMMs -- bit-identical chain, measured SLOWER on MI355X "
@@ -755,20 +758,27 @@ def main():
     # ---- phase 3: the timed region
     launches_per_step = len(sampler._graphs[("cost",)][0]) if sampler.use_hip_graph else 1
     timer.reserve(args.steps * launches_per_step)
+    time_every = args.time_every if args.time_every > 0 else max(1, min(7, args.steps // 5))
+    timer.sample_every = time_every                                    # a step is timed iff its number % time_every == 0
     timer.enabled = True
     periodic_exchange[0] = True
     fence()
     t0 = time.perf_counter()
     host_stamps = [t0]
     depth = args.max_queue_depth
-    step_end = []                                                      # the last update launch of every timed step
+    step_end = []                                                      # (i, last update launch) of every step that was timed
+    seen, synced = 0, 0
     for i in range(args.steps):
         one_step(i)
-        step_end.append(timer.kevents[-1])
-        if depth and i >= depth:
-            # host-side flow control: never run more than `depth` steps ahead of the device (the HIP runtime lets the
-            # host queue ~750 steps and then stalls host AND device for milliseconds while it recycles its pools)
-            step_end[i - depth].synchronize()
+        if len(timer.kevents) > seen:
+            seen = len(timer.kevents)
+            step_end.append((i, timer.kevents[-1]))
+            # host-side flow control: never run more than `depth` (+ time_every) steps ahead of the device (the HIP runtime
+            # lets the host queue ~750 steps and then stalls host AND device for milliseconds while it recycles its pools)
+            while depth and synced < len(step_end) and step_end[synced][0] <= i - depth:
+                synced += 1
+                if synced == len(step_end) or step_end[synced][0] > i - depth:
+                    step_end[synced - 1][1].synchronize()
         host_stamps.append(time.perf_counter())                        # host-side enqueue time of each step (no sync)
     if exchange is not None and exchange.pending:                      # inside the timed region
         rhat_finish()
@@ -805,8 +815,8 @@ def main():
         big = alg_bytes > (640 << 20)
         traffic, traffic_src = pmc_traffic(mode, n, variant="_tsq")       # the pipeline launches the sum-theta^2-only variant
         # per-step device time: from the end of one step's last update launch to the end of the next one's
-        step_ms = np.array([step_end[j].us_until(step_end[j + 1]) for j in range(len(step_end) - 1)]) * 1e-3 \
-            if len(step_end) > 1 else None
+        step_ms = np.array([step_end[j][1].us_until(step_end[j + 1][1]) / (step_end[j + 1][0] - step_end[j][0])
+                            for j in range(len(step_end) - 1)]) * 1e-3 if len(step_end) > 1 else None
         slices = None
         if launches_per_step > 1:
             slices = []
@@ -844,7 +854,7 @@ def main():
                                          launches_per_step if launches_per_step > 1 else "off: one launch after the backward pass",
                        "gemm_tuning": not args.no_gemm_tuning,
                        "prime_steps": {"burn_in": PRIME_BURN_IN, "frozen": PRIME_FROZEN + PRIME_STEADY},
-                       "max_queue_depth": args.max_queue_depth,
+                       "max_queue_depth": args.max_queue_depth, "time_every": time_every,
                        "launch": kernels.get_launch_config(), "kernel_source_hash": kernel_source_hash()},
             # template args: <Op<float, ADAPT, INJECT>, quads per lane, NT, STATS (2 = sum theta^2 only), LOOP, MOMENTS>, from
             # the launch configuration in effect (library defaults: 1 quad per lane, nt iff the launch streams > 640 MiB,
@@ -869,9 +879,11 @@ def main():
                          "cache_note": ("%.0f MB per step: HBM-resident (larger than the 256 MiB Infinity Cache)" if big else
                                         "%.0f MB per step fits the 256 MiB Infinity Cache: part of this rate is cache-"
                                         "assisted; the HBM-resident figure is `roofline_hbm_resident`") % (alg_bytes / 1e6),
-                         "timing": "every update launch of the timed region carries a HIP event pair that receives the kernel's "
-                                   "own start/stop timestamps (hipExtLaunchKernel; the duration rocprofv3 reports); achieved = "
-                                   "algorithmic bytes of the timed launches / the sum of their durations" + (
+                         "timing": "the update launches of every %d-th step of the timed region carry a HIP event pair that receives "
+                                   "the kernel's own start/stop timestamps (hipExtLaunchKernel; the duration rocprofv3 reports) -- "
+                                   "not every step, because a launch with events costs the step 8 us of device time "
+                                   "(tools/bench_overhead_probe.py); achieved = algorithmic bytes of the timed launches / the sum of "
+                                   "their durations; `roofline_unoverlapped` times EVERY launch of a second loop outside `value`" % time_every + (
                                        " -- the slices run CONCURRENTLY with the backward GEMMs, so this is the contended "
                                        "rate; `roofline_unoverlapped` is the same kernel alone in the pipeline"
                                        if launches_per_step > 1 else "")},

@@ -153,7 +153,7 @@ def _declare(lib):
         f = getattr(lib, "sgmcmc_summary_" + sfx)
         f.argtypes = [_vp, _sz, _vp, _vp, _vp]
         f.restype = _ci
-    lib.sgmcmc_gemm_tn_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _vp]
+    lib.sgmcmc_gemm_tn_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp]
     lib.sgmcmc_gemm_tn_f32.restype = _ci
     lib.sgmcmc_gemm_tn_sghmc_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _sz, _vp] + [ctypes.c_float] * 4 + [
         _u64, _u64, _vp, _u64, _vp, ctypes.c_uint32, ctypes.c_uint32, _ci, _vp, _ci, _vp]

@@ -308,7 +308,7 @@ def toy_chains(sampler, target, target_params, theta, mom, tau, g, v_hat, minv, 
     return kept
 
 
-def gemm_tn(a, b, out, variant=0):
+def gemm_tn(a, b, out, variant=0, phase_counters=None, phase_sleep=0):
     """``out[M, N] = a[K, M]^T @ b[K, N]`` (fp32, matrix cores): the weight-gradient product of a dense layer."""
     K, M = a.shape
     N = b.shape[1]
@@ -318,7 +318,7 @@ def gemm_tn(a, b, out, variant=0):
         raise ValueError("gemm_tn: shapes / strides do not match")
     with _on(a):
         rc = lib().sgmcmc_gemm_tn_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
-                                      int(variant), _stream(a))
+                                      int(variant), _ptr(phase_counters), int(phase_sleep), _stream(a))
     check(rc, "sgmcmc_gemm_tn_f32")
     return out
 

@@ -361,7 +361,8 @@ class BNNCost(object):
             # coef * theta is added by the update kernel (fold_prior) or rides in the GEMM epilogue (beta).
             if weight_update is not None and weight_update(l, h_in, ds[l]):
                 pass                                          # product + update of this layer's slice done by the sampler's kernel
-            elif self.gw_gemm == "mfma" and self.fold_prior and W.dtype == torch.float32:
+            elif (self.gw_gemm == "mfma" and self.fold_prior and W.dtype == torch.float32 and W.shape[1] % 128 == 0
+                  and W.shape[0] % 4 == 0 and h_in.shape[0] % 16 == 0 and grad_views[2 * l].data_ptr() % 16 == 0):
                 kernels.gemm_tn(h_in, ds[l], grad_views[2 * l])   # the library's own fp32 matrix-core product (k-ordered fmaf chain)
             elif self.fold_prior:
                 torch.mm(h_in.t(), ds[l], out=grad_views[2 * l])

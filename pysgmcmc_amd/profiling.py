@@ -10,7 +10,9 @@ section 5; this is what ``bench.py`` builds its ``roofline`` entry from).
     timer.kernel_us()          # duration of every update launch, from the kernel's own start/stop timestamps
 
 Every timed launch carries a pair of HIP events (``sgmcmc_launch_t.start_event / stop_event`` -> ``hipExtLaunchKernel``)
-that receive the KERNEL's start and stop timestamps -- the duration rocprofv3 reports for the kernel. ``bracket=True``
+that receive the KERNEL's start and stop timestamps -- the duration rocprofv3 reports for the kernel. The events are not
+free: a launch that carries them costs the 10 M-parameter chain 8 us of device time per step (tools/bench_overhead_probe.py),
+so ``timer.sample_every = k`` times the launches of every k-th step only. ``bracket=True``
 additionally records a ``hipEventRecord`` pair around the call on the same stream (it includes ~3-5 us of barrier-packet
 and dispatch latency). Timing applies to direct launches (eager stepping and ``use_hip_graph = True``); a launch captured
 into a hipGraph (``use_hip_graph = "full"``) cannot carry events and is not timed.
@@ -28,6 +30,8 @@ class UpdateKernelTimer(object):
         """``device``: the device of the sampler being timed (events belong to a device; default: the current one)."""
         self.device = device
         self.enabled = False
+        self.sample_every = 1      # time every k-th launch only (the events of a timed launch cost a few microseconds of device time)
+        self._seen = 0
         self.bracket = bool(bracket)
         self.kevents = []          # one KernelEvents per timed launch, in launch order
         self.tags = []             # per timed launch: None, or (step, lo, hi) for one slice of an overlapped update
@@ -46,6 +50,15 @@ class UpdateKernelTimer(object):
             return (kernels.KernelEvents(self.device), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
     # -- called by the sampler around its update launch --
+    def due(self, tag=None):
+        """Called once per launch while enabled: is this launch one of the timed ones? With ``sample_every = k`` the launches
+        of every k-th step are (all slices of an overlapped step together: the tag's first entry is the step number)."""
+        k = max(int(self.sample_every), 1)
+        if tag is not None:
+            return tag[0] % k == 0
+        self._seen += 1
+        return (self._seen - 1) % k == 0
+
     def begin(self, tag=None):
         self._tag = tag
         self._current = self._pool.pop() if self._pool else self._new_events()

@@ -360,7 +360,7 @@ class MCMCSampler(object):
     def _timed_kernel_step(self, eps, xi, sl=None, opts=None, tag=None):
         t = self.kernel_timer
         kw = {} if (sl is None and opts is None) else dict(sl=sl, opts=opts)
-        if t is None or not t.enabled or self._capturing:
+        if t is None or not t.enabled or self._capturing or not t.due(tag):
             return self._kernel_step(eps, xi, **kw)
         if t.device is None:
             t.device = self.device

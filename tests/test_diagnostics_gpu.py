@@ -233,7 +233,7 @@ def test_bench_n2_path_on_one_gpu(gpu):
     """``bench.py --gpus 2`` as the driver launches it (torch.distributed.run, one rank per process), with both ranks on
     cuda:0 over gloo: the line carries the rank count, the exchange timings and an R-hat summary, and N = 2 runs the
     same step code as N = 1."""
-    d = _bench_n2(["--steps", "24", "--warmup", "4", "--rhat-every", "8", "--moments-every", "2"])
+    d = _bench_n2(["--steps", "24", "--warmup", "4", "--rhat-every", "8", "--moments-every", "2", "--time-every", "1"])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "samples/s" and d["steps"] == 24
     assert d["value"] > 0 and np.isclose(d["value"], 2 * 24 / (d["ms_per_step"] * 24 / 1e3), rtol=1e-3)
     rc = d["rccl"]
@@ -255,7 +255,8 @@ def test_bench_n2_driver_arguments_contain_one_exchange(gpu):
     d = _bench_n2(["--steps", "20", "--warmup", "5"])
     assert d["steps"] == 20 and d["warmup"] == 5 and d["config"]["rhat_every"] == 14 and d["config"]["moments_every"] == 10
     assert d["rccl"]["exchanges_timed"] == 1 and d["rccl"]["rhat_exchange_ms"]["start_to_finish"] > 0
-    assert d["rhat"] is not None and d["roofline"]["launches_timed"] == 20
+    # the update launches of every 4th step carry timestamp events (20 // 5; a timed launch costs the step ~8 us)
+    assert d["rhat"] is not None and d["config"]["time_every"] == 4 and d["roofline"]["launches_timed"] == 5
 
 
 def _bench_self_launched(n, extra, timeout=800):

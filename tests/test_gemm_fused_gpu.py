@@ -16,8 +16,8 @@ def test_gemm_tn_equals_a_k_ordered_fp32_product(gpu, M, N, K):
     a, b = torch.randn(K, M, device=gpu, generator=g), torch.randn(K, N, device=gpu, generator=g)
     exact = a.double().t() @ b.double()
     outs = []
-    for variant in range(9):
-        if K % (16, 32, 64, 32, 64, 32, 32, 32, 32)[variant]:
+    for variant in range(13):                               # 0, 10, 11: direct-to-LDS operand loads; the others stage through registers
+        if K % (16, 32, 64, 32, 64, 32, 32, 32, 32, 16, 32, 16, 16)[variant]:
             continue
         out = torch.full((M + 3, N), -7.0, device=gpu)
         kernels.gemm_tn(a, b, out[:M], variant=variant)
@@ -42,7 +42,8 @@ def test_fused_gemm_update_equals_k1_on_the_gradient_it_computed(gpu, M, N, K, n
     theta0, V0 = torch.randn(n, device=gpu, generator=g) * 0.05, torch.randn(n, device=gpu, generator=g) * 0.01
     minv = torch.rand(n, device=gpu, generator=g) + 0.5
     gtail = torch.randn(n_tail, device=gpu, generator=g) * 0.1 if n_tail else None
-    for step, blocks in ((5, 0), (6, 3)):                   # default grid, and 3 persistent workgroups walking over the tiles
+    # default grid; 3 persistent workgroups walking over the tiles; the two flavours that request the state before the K loop
+    for step, blocks in ((5, 0), (6, 3), (7, 3 | (1 << 16)), (8, 2 << 16)):
         th, V = theta0.clone(), V0.clone()
         gout = torch.full((M, N), float("nan"), device=gpu)
         st = kernels.StepStats(n, gpu)

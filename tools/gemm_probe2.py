@@ -8,7 +8,7 @@ from pysgmcmc_amd.models.bayesian_neural_network import enable_gemm_tuning
 
 dev = torch.device("cuda:0")
 enable_gemm_tuning(True, max_duration_ms=30, max_iterations=20)
-for (M, N, K) in ((2048, 2048, 256), (784, 2048, 256)):
+for (M, N, K) in ((2048, 2048, 256), (784, 2048, 256), (132, 128, 64)):
     g = torch.Generator(device=dev).manual_seed(0)
     a = torch.randn(K, M, device=dev, generator=g)
     b = torch.randn(K, N, device=dev, generator=g)
@@ -33,13 +33,14 @@ for (M, N, K) in ((2048, 2048, 256), (784, 2048, 256)):
     us_lib = t(lambda: torch.mm(a.t(), b, out=ref))
     fl = 2.0 * M * N * K
     print("M=%d N=%d K=%d  max|err| mine %.2e lib %.2e | lib %.1f us (%.0f TF/s)" % (M, N, K, e_mine, e_lib, us_lib, fl / us_lib / 1e6), flush=True)
-    for v in range(9):
+    for v in (0, 9, 11, 12):
         out.zero_()
         kernels.gemm_tn(a, b, out, variant=v)
         err = (out.double() - exact).abs().max().item()
         us = t(lambda: kernels.gemm_tn(a, b, out, variant=v))
+        ph = " | frags once %.1f | bare MFMA chain %.1f" % (t(lambda: kernels.gemm_tn(a, b, out, variant=v | 0x400)), t(lambda: kernels.gemm_tn(a, b, out, variant=v | 0xC00)))
         us_ns = t(lambda: kernels.gemm_tn(a, b, out, variant=v | 0x100))
         us_q = t(lambda: kernels.gemm_tn(a, b, out, variant=v | 0x200)) if K >= 256 else float("nan")
         us_qns = t(lambda: kernels.gemm_tn(a, b, out, variant=v | 0x300)) if K >= 256 else float("nan")
         print("    variant %d: max|err| %.2e  %.1f us (%.0f TF/s) | no store %.1f | K/4 %.1f | K/4 no store %.1f" % (
-            v, err, us, fl / us / 1e6, us_ns, us_q, us_qns), flush=True)
+            v, err, us, fl / us / 1e6, us_ns, us_q, us_qns) + ph, flush=True)

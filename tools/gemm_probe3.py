@@ -32,6 +32,7 @@ for (M, N, K, n_tail, first) in ((2048, 2048, 256, 2048, 1607680), (784, 2048, 2
     print("M=%d N=%d K=%d tail=%d: theta bit-equal %s, V bit-equal %s, gW max|err| %.2e, sum theta^2 %.9g vs %.9g" % (
         M, N, K, n_tail, torch.equal(th, th2), torch.equal(V, V2), (gout.double() - exact).abs().max().item(),
         kernels.step_stats_finish(st)[0].item(), (th.double() ** 2).sum().item()), flush=True)
+    th_ref, V_ref = th.clone(), V.clone()
     if M < 500:
         continue
     def t(fn, nrep=200):
@@ -54,8 +55,16 @@ for (M, N, K, n_tail, first) in ((2048, 2048, 256, 2048, 1607680), (784, 2048, 2
         kernels.gemm_tn_sghmc(a, b, th, V, minv, gtail, 0.01, 1e5, 0.05, seed=11, step=5, first_element=first, stats=st,
                               gemm_blocks=blocks)
     print("    library GEMM + K1 slice: %.1f us" % t(separate), flush=True)
-    for blocks in (256, 512, 768, 1024, 2048):
-        print("    fused, %4d persistent workgroups: %.1f us" % (blocks, t(lambda: fused(blocks))), flush=True)
+    names = {0: "no prefetch, 4 WG/CU", 1: "2 of 4 quads prefetched, 4 WG/CU", 2: "4 of 4 prefetched, 4 WG/CU (spills)",
+             3: "4 of 4 prefetched, 3 WG/CU", 4: "no prefetch, 5 WG/CU (spills)", 5: "1 of 4 prefetched, 4 WG/CU",
+             6: "2 of 4 prefetched, 3 WG/CU"}
+    for fl in range(7):
+        th3, V3 = theta0.clone(), V0.clone()
+        kernels.gemm_tn_sghmc(a, b, th3, V3, minv, gtail, 0.01, 1e5, 0.05, grad_decay=1e-6, seed=11, step=5, first_element=first,
+                              gemm_blocks=1024 | (fl << 16))
+        ok = torch.equal(th3, th_ref) and torch.equal(V3, V_ref)
+        print("    flavour %d (%s): bit-equal %s, %s us" % (fl, names[fl], ok, " / ".join(
+            "%.1f" % t(lambda: fused(blocks | (fl << 16))) for blocks in (768, 1024, 2048))), flush=True)
     pc = torch.zeros(2048, dtype=torch.int32, device=dev)
     for sl in (1, 2, 3):
         def fused_dephased():

@@ -1,0 +1,81 @@
+// Can a SIMD of gfx950 run the fp32 matrix pipe and the vector ALU at the same time from DIFFERENT waves?
+// 512-lane workgroups, 2 per CU (= 4 waves per SIMD; waves w and w + 4 of a workgroup share a SIMD). A workgroup's waves 0-3 are
+// its "low" half, waves 4-7 its "high" half (roles by workgroup would not mix on a CU: consecutive workgroup ids go to
+// different XCDs). By mode:
+//   0: all waves run an MFMA chain                    (matrix pipe bound)
+//   1: all waves run a Philox-like integer chain      (vector ALU bound)
+//   2: high halves MFMA, low halves VALU (half of each kind of work of modes 0/1 per SIMD)
+//   3: every wave runs first the MFMA chain, then the VALU chain (the fused kernel's lockstep phases)
+//   4: high halves MFMA then VALU, low halves VALU then MFMA (perfectly de-phased)
+// Build: hipcc --offload-arch=gfx950 -O3 -o gpurun_out/mfma_valu_overlap tools/gpu/mfma_valu_overlap.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void mfma_chain(int n, f32x16 &acc, float a, float b)
+{
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void valu_chain(int n, unsigned &x0, unsigned &x1, unsigned &x2, unsigned &x3)
+{
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const unsigned long long p0 = (unsigned long long)0xD2511F53u * x0, p1 = (unsigned long long)0xCD9E8D57u * x2;
+            const unsigned y0 = (unsigned)(p1 >> 32) ^ x1 ^ (0x9E3779B9u * r), y1 = (unsigned)p1;
+            const unsigned y2 = (unsigned)(p0 >> 32) ^ x3 ^ (0xBB67AE85u * r), y3 = (unsigned)p0;
+            x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(512, 2) probe(int mode, int n_mfma, int n_valu, float *out)
+{
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    unsigned x0 = threadIdx.x, x1 = blockIdx.x, x2 = 7, x3 = 11;
+    const float a = 1.f + threadIdx.x * 1e-9f, b = 0.5f;
+    const bool odd = (threadIdx.x >> 8) & 1;
+    switch (mode) {
+    case 0: mfma_chain(n_mfma, acc, a, b); break;
+    case 1: valu_chain(n_valu, x0, x1, x2, x3); break;
+    case 2: if (odd) mfma_chain(2 * n_mfma, acc, a, b); else valu_chain(2 * n_valu, x0, x1, x2, x3); break;
+    case 3: mfma_chain(n_mfma, acc, a, b); valu_chain(n_valu, x0, x1, x2, x3); break;
+    case 4:
+        if (odd) { mfma_chain(n_mfma, acc, a, b); valu_chain(n_valu, x0, x1, x2, x3); }
+        else { valu_chain(n_valu, x0, x1, x2, x3); mfma_chain(n_mfma, acc, a, b); }
+        break;
+    }
+    float s = (float)(x0 ^ x1 ^ x2 ^ x3);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[r];
+    if (s == 1.2345e33f) out[0] = s;
+}
+
+int main()
+{
+    float *out;
+    hipMalloc(&out, 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int n_mfma = 64, n_valu = 48;
+    const char *names[5] = {"all MFMA", "all VALU", "half the workgroups MFMA x2, half VALU x2", "MFMA then VALU (lockstep)",
+                            "odd: MFMA then VALU, even: VALU then MFMA"};
+    for (int mode = 0; mode < 5; ++mode) {
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(probe, dim3(512), dim3(512), 0, 0, mode, n_mfma, n_valu, out);
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(probe, dim3(512), dim3(512), 0, 0, mode, n_mfma, n_valu, out);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("mode %d (%s): %.1f us per launch\n", mode, names[mode], ms / 20 * 1e3);
+    }
+    return 0;
+}
