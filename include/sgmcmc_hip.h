@@ -424,6 +424,16 @@ int sgmcmc_tanh_rowdot_f32(float *a, const float *w, size_t rows, size_t cols, f
                            double *tsq_parts, sgmcmc_stream_t stream);
 int sgmcmc_tanh_rowdot_f64(double *a, const double *w, size_t rows, size_t cols, double *out, const void *stats_ws,
                            double *tsq_parts, sgmcmc_stream_t stream);
+/* the same with the layer's bias added first: a = tanh(a + bias[c]) (bias NULL = none); the forward product is then a
+ * plain GEMM -- at batch 256 the library's plain product is 1.4-2.1 us faster than its bias-epilogue one.         */
+int sgmcmc_bias_tanh_rowdot_f32(float *a, const float *bias, const float *w, size_t rows, size_t cols, float *out,
+                                const void *stats_ws, double *tsq_parts, sgmcmc_stream_t stream);
+int sgmcmc_bias_tanh_rowdot_f64(double *a, const double *bias, const double *w, size_t rows, size_t cols, double *out,
+                                const void *stats_ws, double *tsq_parts, sgmcmc_stream_t stream);
+/* Hidden-layer activation (bayesian_neural_network.py:28-56, fully_connected with tanh): a[rows][cols] =
+ * tanh(a + bias[c]) in place.                                                                                    */
+int sgmcmc_bias_tanh_f32(float *a, const float *bias, size_t rows, size_t cols, sgmcmc_stream_t stream);
+int sgmcmc_bias_tanh_f64(double *a, const double *bias, size_t rows, size_t cols, sgmcmc_stream_t stream);
 
 /* sgmcmc_bnn_head_* and sgmcmc_bnn_last_layer_backward_* in ONE launch (every dependent launch of the step costs
  * ~5 us): `mean` [rows] is the single-output layer's pre-bias output (sgmcmc_tanh_rowdot_*), tsq_parts the slices of

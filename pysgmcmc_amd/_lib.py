@@ -134,6 +134,12 @@ def _declare(lib):
         f = getattr(lib, "sgmcmc_tanh_rowdot_" + sfx)
         f.argtypes = [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]
         f.restype = _ci
+        f = getattr(lib, "sgmcmc_bias_tanh_rowdot_" + sfx)
+        f.argtypes = [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]
+        f.restype = _ci
+        f = getattr(lib, "sgmcmc_bias_tanh_" + sfx)
+        f.argtypes = [_vp, _vp, _sz, _sz, _vp]
+        f.restype = _ci
         f = getattr(lib, "sgmcmc_bnn_head_last_layer_backward_" + sfx)
         f.argtypes = ([_vp] * 5 + [_sz, _sz] + [ctypes.c_double] * 6 + [_ci, _vp, _vp, _vp, real] + [_vp] * 7 + [_vp])
         f.restype = _ci

@@ -350,11 +350,38 @@ __device__ __forceinline__ double tanh_dev(double x) { return tanh(x); }
 // the sum(theta^2) partials the previous step kernel left in its statistics workspace and write it to tsq_parts[slice];
 // the fused head (head_last_layer_backward_kernel) adds the slices in order. Saves the loss head's own pass over the
 // ~10 k partials, and with it the separate head launch (each dependent launch of the step costs ~5 us).
+// a[r][c] = tanh(a[r][c] + bias[c]) in place: the hidden layers' activation with the bias add that the forward GEMM then
+// does not need as an epilogue (the library's plain product is 1.4-2.1 us faster than its bias-epilogue one at batch 256,
+// tools/fwd_gemm_probe.py). One quad per lane per trip, 16-byte accesses when the pitch allows.
+template <typename T>
+__global__ void __launch_bounds__(256) bias_tanh_kernel(T *__restrict__ a, const T *__restrict__ bias, unsigned rows, unsigned cols)
+{
+    // 32-bit indices (the host checks rows * cols < 2^32): a 64-bit modulo per quad would cost more than the tanh
+    const unsigned G = gridDim.x * blockDim.x, gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool vec = (cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(bias)) % (4 * sizeof(T)) == 0);
+    if (vec) {
+        struct alignas(4 * sizeof(T)) Q { T v[4]; };
+        Q *aq = reinterpret_cast<Q *>(a);
+        const Q *bq = reinterpret_cast<const Q *>(bias);
+        const unsigned qpr = cols / 4, nq = rows * qpr;
+        for (unsigned q = gid; q < nq; q += G) {
+            Q x = aq[q];
+            const Q b = bq[q % qpr];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x.v[j] = tanh_dev(x.v[j] + b.v[j]);
+            aq[q] = x;
+        }
+    } else {
+        const unsigned n = rows * cols;
+        for (unsigned i = gid; i < n; i += G) a[i] = tanh_dev(a[i] + bias[i % cols]);
+    }
+}
+
 constexpr int TSQ_SLICES = 16;
 template <typename T>
 __global__ void __launch_bounds__(256) tanh_rowdot_kernel(T *__restrict__ a, const T *__restrict__ w, size_t cols,
                                                           T *__restrict__ out, const double *__restrict__ stats_ws,
-                                                          double *__restrict__ tsq_parts)
+                                                          double *__restrict__ tsq_parts, const T *__restrict__ bias)
 {
     __shared__ T lds[4];
     __shared__ double lds_d[4];
@@ -369,17 +396,21 @@ __global__ void __launch_bounds__(256) tanh_rowdot_kernel(T *__restrict__ a, con
     }
     T *row = a + (size_t)blockIdx.x * cols;
     T acc = T(0);
-    const bool vec = (cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w)) % (4 * sizeof(T)) == 0);
+    const bool vec = (cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w) |
+                                          reinterpret_cast<uintptr_t>(bias)) % (4 * sizeof(T)) == 0);
     if (vec) {
         struct alignas(4 * sizeof(T)) Q { T v[4]; };
         Q *rq = reinterpret_cast<Q *>(row);
         const Q *wq = reinterpret_cast<const Q *>(w);
+        const Q *bq = reinterpret_cast<const Q *>(bias);
+        const Q zero = {{T(0), T(0), T(0), T(0)}};
         const size_t nq = cols / 4;
         size_t q = threadIdx.x;
         for (; q + 256 < nq; q += 512) {                      // two quads per lane in flight
             Q x0 = rq[q], x1 = rq[q + 256], w0 = wq[q], w1 = wq[q + 256];
+            const Q b0 = bias ? bq[q] : zero, b1 = bias ? bq[q + 256] : zero;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { x0.v[j] = tanh_dev(x0.v[j]); x1.v[j] = tanh_dev(x1.v[j]); }
+            for (int j = 0; j < 4; ++j) { x0.v[j] = tanh_dev(x0.v[j] + b0.v[j]); x1.v[j] = tanh_dev(x1.v[j] + b1.v[j]); }
             rq[q] = x0; rq[q + 256] = x1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc += x0.v[j] * w0.v[j];
@@ -388,15 +419,16 @@ __global__ void __launch_bounds__(256) tanh_rowdot_kernel(T *__restrict__ a, con
         }
         for (; q < nq; q += 256) {
             Q x0 = rq[q], w0 = wq[q];
+            const Q b0 = bias ? bq[q] : zero;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x0.v[j] = tanh_dev(x0.v[j]);
+            for (int j = 0; j < 4; ++j) x0.v[j] = tanh_dev(x0.v[j] + b0.v[j]);
             rq[q] = x0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc += x0.v[j] * w0.v[j];
         }
     } else {
         for (size_t c = threadIdx.x; c < cols; c += 256) {
-            const T h = tanh_dev(row[c]);
+            const T h = tanh_dev(row[c] + (bias ? bias[c] : T(0)));
             row[c] = h;
             acc += h * w[c];
         }
@@ -877,8 +909,8 @@ SGMCMC_WINDOW_GATHER(f64, double)
 #undef SGMCMC_WINDOW_GATHER
 
 #define SGMCMC_TANH_ROWDOT(SFX, T)                                                                                   \
-    int sgmcmc_tanh_rowdot_##SFX(T *a, const T *w, size_t rows, size_t cols, T *out, const void *stats_ws,          \
-                                 double *tsq_parts, sgmcmc_stream_t stream)                                          \
+    int sgmcmc_bias_tanh_rowdot_##SFX(T *a, const T *bias, const T *w, size_t rows, size_t cols, T *out,             \
+                                      const void *stats_ws, double *tsq_parts, sgmcmc_stream_t stream)               \
     {                                                                                                                \
         if (rows == 0 || cols == 0) return 0;                                                                        \
         if (!a || !w || !out) return fail(SGMCMC_EINVAL, "tanh_rowdot: NULL argument");                             \
@@ -886,9 +918,25 @@ SGMCMC_WINDOW_GATHER(f64, double)
             return fail(SGMCMC_EINVAL, "tanh_rowdot: stats_ws and tsq_parts go together");                           \
         if (rows > 0x7fffffffull) return fail(SGMCMC_EINVAL, "tanh_rowdot: too many rows");                          \
         hipLaunchKernelGGL((tanh_rowdot_kernel<T>), dim3((unsigned)rows), dim3(256), 0, static_cast<hipStream_t>(stream), \
-                           a, w, cols, out, static_cast<const double *>(stats_ws), tsq_parts);                       \
+                           a, w, cols, out, static_cast<const double *>(stats_ws), tsq_parts, bias);                 \
         hipError_t e = hipGetLastError();                                                                            \
         return e == hipSuccess ? 0 : hip_fail(e, "launch tanh_rowdot");                                              \
+    }                                                                                                                \
+    int sgmcmc_tanh_rowdot_##SFX(T *a, const T *w, size_t rows, size_t cols, T *out, const void *stats_ws,          \
+                                 double *tsq_parts, sgmcmc_stream_t stream)                                          \
+    {                                                                                                                \
+        return sgmcmc_bias_tanh_rowdot_##SFX(a, nullptr, w, rows, cols, out, stats_ws, tsq_parts, stream);           \
+    }                                                                                                                \
+    int sgmcmc_bias_tanh_##SFX(T *a, const T *bias, size_t rows, size_t cols, sgmcmc_stream_t stream)                \
+    {                                                                                                                \
+        if (rows == 0 || cols == 0) return 0;                                                                        \
+        if (!a || !bias) return fail(SGMCMC_EINVAL, "bias_tanh: NULL argument");                                     \
+        if (rows * cols >= 0xffffffffull) return fail(SGMCMC_EINVAL, "bias_tanh: more than 2^32 - 1 elements");      \
+        const size_t lanes = (rows * cols + 3) / 4, blocks = (lanes + 255) / 256;                                    \
+        hipLaunchKernelGGL((bias_tanh_kernel<T>), dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,   \
+                           static_cast<hipStream_t>(stream), a, bias, (unsigned)rows, (unsigned)cols);               \
+        hipError_t e = hipGetLastError();                                                                            \
+        return e == hipSuccess ? 0 : hip_fail(e, "launch bias_tanh");                                                \
     }                                                                                                                \
     int sgmcmc_bnn_head_last_layer_backward_##SFX(                                                                   \
         const T *mean, const T *y, const T *log_var, const double *tsq_parts, const T *last_bias, size_t rows,       \

@@ -16,7 +16,7 @@ __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
     "LaunchConfig", "KernelEvents", "StepOpts", "step_stats_records", "step_scalars", "toy_chains", "gemm_tn", "gemm_tn_sghmc", "gemm_tn_sghmc_blocks", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
-    "bnn_fused_sgld_steps", "window_gather", "tanh_rowdot", "bnn_head_last_layer_backward", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
+    "bnn_fused_sgld_steps", "window_gather", "tanh_rowdot", "bias_tanh", "bnn_head_last_layer_backward", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
 ]
 
 _SFX = {torch.float32: "f32", torch.float64: "f64"}
@@ -528,18 +528,30 @@ def bnn_fused_sgld_steps(theta, grad, tau, g, v_hat, minv, layer_sizes, X, y, wi
     return cost_out
 
 
-def tanh_rowdot(a, w, out, stats_workspace=None, tsq_parts=None):
-    """``a = tanh(a)`` in place (``[rows, cols]``) and ``out[r] = a[r] . w`` in one launch. With ``stats_workspace``
+def bias_tanh(a, bias):
+    """``a = tanh(a + bias)`` in place (``a``: contiguous ``[rows, cols]``, ``bias``: ``[cols]``): a hidden layer's activation
+    after a plain forward GEMM."""
+    rows, cols = int(a.shape[0]), int(a.shape[1])
+    if bias.numel() != cols or bias.dtype != a.dtype or not a.is_contiguous() or not bias.is_contiguous():
+        raise ValueError("pysgmcmc_amd: bias_tanh shapes / dtypes do not match")
+    with _on(a):
+        rc = getattr(lib(), "sgmcmc_bias_tanh_" + _sfx(a))(_ptr(a), _ptr(bias), rows, cols, _stream(a))
+    check(rc, "sgmcmc_bias_tanh")
+    return a
+
+
+def tanh_rowdot(a, w, out, stats_workspace=None, tsq_parts=None, bias=None):
+    """``a = tanh(a [+ bias])`` in place (``[rows, cols]``) and ``out[r] = a[r] . w`` in one launch. With ``stats_workspace``
     (a ``StepStats.workspace``) and ``tsq_parts`` (float64[16] device tensor) the launch also adds up the
     sum(theta^2) partials into 16 slices for :func:`bnn_head_last_layer_backward`."""
-    f = getattr(lib(), "sgmcmc_tanh_rowdot_" + _sfx(a))
+    f = getattr(lib(), "sgmcmc_bias_tanh_rowdot_" + _sfx(a))
     rows, cols = int(a.shape[0]), int(a.shape[1])
-    if w.numel() != cols or out.numel() != rows:
+    if w.numel() != cols or out.numel() != rows or (bias is not None and (bias.numel() != cols or bias.dtype != a.dtype)):
         raise ValueError("pysgmcmc_amd: tanh_rowdot shapes do not match")
     if tsq_parts is not None and (tsq_parts.dtype != torch.float64 or tsq_parts.numel() < 16):
         raise TypeError("tsq_parts must be a float64 device tensor of 16 elements")
     with _on(a):
-        rc = f(_ptr(a), _ptr(w), rows, cols, _ptr(out), _ptr(stats_workspace), _ptr(tsq_parts), _stream(a))
+        rc = f(_ptr(a), _ptr(bias), _ptr(w), rows, cols, _ptr(out), _ptr(stats_workspace), _ptr(tsq_parts), _stream(a))
     check(rc, "sgmcmc_tanh_rowdot")
 
 

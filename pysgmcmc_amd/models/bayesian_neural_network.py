@@ -307,15 +307,19 @@ class BNNCost(object):
             if l == L and single_out:
                 if not fuse_top:
                     torch.mv(h, W.view(-1), out=hs[l].view(-1))
+            elif l < L:
+                # hidden layer: plain product, the bias rides in the activation launch (the library's plain GEMM is 1.4-2.1 us
+                # faster than its bias-epilogue one at batch 256: tools/fwd_gemm_probe.py)
+                torch.mm(h, W, out=hs[l])
             else:
                 torch.addmm(b, h, W, out=hs[l])
             if l == L - 1 and fuse_top:
-                # tanh of the last hidden layer and the output unit's dot product in one launch
+                # bias + tanh of the last hidden layer and the output unit's dot product in one launch
                 kernels.tanh_rowdot(hs[l], params[2 * L].view(-1), hs[L].view(-1),
                                     stats_workspace=theta_sumsq_partials if fuse_head else None,
-                                    tsq_parts=ws["tsq_parts"] if fuse_head else None)
+                                    tsq_parts=ws["tsq_parts"] if fuse_head else None, bias=b.view(-1))
             elif l < L:
-                torch.tanh_(hs[l])
+                kernels.bias_tanh(hs[l], b.view(-1))
             h = hs[l]
         n_params = float(sum(p.numel() for p in params))
         if theta_sumsq is None and theta_sumsq_partials is None:

@@ -398,12 +398,13 @@ def test_update_kernel_timer_through_the_sampler(gpu):
     eager and cost-graph stepping, none while disabled; the chain is unchanged by the instrumentation."""
     from pysgmcmc_amd.profiling import UpdateKernelTimer
 
-    def chain(graph, timed):
+    def chain(graph, timed, every=1):
         s = SGHMCSampler(params=[torch.zeros(500_000, device=gpu)], cost_fun=lambda p: 0.5 * (p[0] ** 2).sum(),
                          burn_in_steps=3, session=gpu, dtype=torch.float32, seed=4)
         s.sample_format = "view"
         s.use_hip_graph = graph
         t = UpdateKernelTimer(reserve=4, bracket=True)
+        t.sample_every = every
         s.kernel_timer = t
         for _ in range(3):
             next(s)                                   # not enabled yet: nothing recorded
@@ -420,6 +421,10 @@ def test_update_kernel_timer_through_the_sampler(gpu):
         assert us.shape == (7,) and steps.shape == (6,) and br.shape == (7,)
         assert np.all(us > 1.0) and np.all(us < 500.0) and np.all(steps >= us[1:] * 0.99)
         assert torch.equal(s.arena.row("theta"), ref.arena.row("theta"))
+    # sample_every = 3: only the launches of steps 3, 6, 9 of the enabled steps 3 .. 9 carry events (a timed launch costs device time)
+    s, t = chain(True, True, every=3)
+    assert [tag[0] for tag in t.tags] == [3, 6, 9] and t.kernel_us().shape == (3,)
+    assert torch.equal(s.arena.row("theta"), ref.arena.row("theta"))
     assert UpdateKernelTimer.empty_bracket_us(20) >= 0.0
 
 
