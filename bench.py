@@ -537,7 +537,7 @@ def gemm_only_us(sampler, iters=60):
     def gemms():
         h, flops = X, 0
         for l in range(L):
-            torch.addmm(params[2 * l + 1], h, params[2 * l], out=hs[l])
+            torch.mm(h, params[2 * l], out=hs[l])                  # the bias rides in the activation launch
             flops += 2 * h.shape[0] * h.shape[1] * params[2 * l].shape[1]
             h = hs[l]
         for l in range(L - 1, -1, -1):
@@ -969,7 +969,7 @@ def main():
             "gemm_frac_of_fp32_mfma_peak": round(g_flops / (g_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3),
             "gemm_flop_per_step": int(g_flops),
             "note": "gemm = the step's eight fp32 library GEMMs replayed alone from a hipGraph; small_launches = the captured "
-                    "cost pipeline alone minus gemm (tanh, tanh-backward + bias gradient, loss head, window gather ...); "
+                    "cost pipeline alone minus gemm (bias + tanh, tanh-backward + bias gradient, loss head ...); "
                     "update = the fused update launched once after the backward pass. Differences of graph replays: rocprofv3's "
                     "per-kernel durations of the same step (profiles/r03_bench10m_kernel_stats.csv: GEMMs 136, seven small "
                     "launches 37, update 35 us) carry ~1.5 us of profiler overhead per kernel"}
