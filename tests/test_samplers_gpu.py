@@ -322,6 +322,31 @@ def test_bnn_cost_path_hip_equals_autograd(gpu, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_bias_tanh_kernels(gpu, dt):
+    """``bias_tanh`` (hidden-layer activation after a plain forward GEMM) and ``tanh_rowdot(bias=)`` against torch, for row
+    pitches with and without 16-byte accesses; ``tanh_rowdot`` without a bias is unchanged."""
+    from pysgmcmc_amd import kernels
+    g = torch.Generator(device=gpu).manual_seed(3)
+    tol = 1e-6 if dt == torch.float32 else 1e-14
+    for rows, cols in ((256, 2048), (7, 50), (1, 4), (33, 130)):
+        a = torch.randn(rows, cols, device=gpu, dtype=dt, generator=g)
+        b = torch.randn(cols, device=gpu, dtype=dt, generator=g)
+        w = torch.randn(cols, device=gpu, dtype=dt, generator=g)
+        ref = torch.tanh(a + b)
+        out = kernels.bias_tanh(a.clone(), b)
+        assert (out - ref).abs().max().item() <= tol
+        h, dot = a.clone(), torch.empty(rows, device=gpu, dtype=dt)
+        kernels.tanh_rowdot(h, w, dot, bias=b)
+        assert torch.equal(h, out)                                   # the same arithmetic in both kernels
+        assert (dot - ref @ w).abs().max().item() <= 50 * tol * cols ** 0.5
+        h2, dot2 = a.clone(), torch.empty(rows, device=gpu, dtype=dt)
+        kernels.tanh_rowdot(h2, w, dot2)
+        assert (h2 - torch.tanh(a)).abs().max().item() <= tol
+    with pytest.raises(ValueError):
+        kernels.bias_tanh(torch.zeros(4, 8, device=gpu, dtype=dt), torch.zeros(7, device=gpu, dtype=dt))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
 def test_fused_head_launch_equals_separate_kernels(gpu, dt):
     """The loss head folded into the last layer's backward launch (``BNNCost.fuse_head``; sum(theta^2) slices from the
     rowdot launch) against the separate head + backward kernels: every gradient bit-equal, cost / mse to the last bits
