@@ -14,7 +14,7 @@ out = torch.empty(M, N, device=dev)
 st = kernels.StepStats(n, dev)
 ref = torch.empty(M, N, device=dev)
 for rep in range(4):
-    for v in (2, 4, 5):
+    for v in (0, 9, 12):             # direct-to-LDS (4 workgroups per CU), register-staged, direct-to-LDS with 6 per CU
         kernels.gemm_tn(a, b, out, variant=v)
     kernels.gemm_tn_sghmc(a, b, th, V, minv, gt, 0.01, 1e5, 0.05, seed=1, step=rep, stats=st)
     torch.mm(a.t(), b, out=ref)
