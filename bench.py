@@ -198,6 +198,37 @@ def update_only(sampler, iters=200):
     return out
 
 
+def chains_per_gpu_leg(dev, sampler, workload, rounds=200):
+    """Ensemble throughput of ONE GPU outside `value` (which stays one chain per GPU, as BASELINE.json's north_star shards the
+    ensemble): the timed chain alone, then together with a second independent chain of the same workload, each chain on its own
+    stream with its own hipGraph (pysgmcmc_amd.samplers.ConcurrentChains), bare loops of `rounds` steps per chain."""
+    from pysgmcmc_amd.samplers import ConcurrentChains
+    sampler.attach_moments(None)
+    sampler.kernel_timer = None
+    other = build_chain(dev, 1, workload, burn_in=PRIME_BURN_IN)
+    other.sample_format, other.use_hip_graph, other.collect_stats = "view", sampler.use_hip_graph, sampler.collect_stats
+    out = {}
+    for label, chains in (("one_chain", [sampler]), ("two_chains", [sampler, other])):
+        group = ConcurrentChains(chains)
+        group.run(PRIME_BURN_IN + 60)
+        group.synchronize()
+        best = 0.0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            group.run(rounds)
+            group.synchronize()
+            best = max(best, len(chains) * rounds / (time.perf_counter() - t0))
+        group.join()
+        out[label + "_samples_per_s"] = round(best, 1)
+    out["two_over_one"] = round(out["two_chains_samples_per_s"] / out["one_chain_samples_per_s"], 3)
+    out["note"] = ("not part of `value`: independent chains share the GPU, one stream and one hipGraph each, stepped round-robin "
+                   "by one host thread, no moments / timer; the second chain's launches fill the idle parts of the first one's "
+                   "(launch ramps and tails of ~15 dependent launches per step, M = 256 GEMMs at ~62 % of the matrix pipe)")
+    del other
+    torch.cuda.empty_cache()
+    return out
+
+
 def hbm_resident_roofline(dev, n=N_HBM_RESIDENT, iters=40):
     """The update kernels on a working set that cannot live in the 256 MiB Infinity Cache (configs[4]'s
     49 826 818 parameters: 0.8-2.4 GB per launch). Every launch carries its own HIP event pair that receives the
@@ -974,6 +1005,8 @@ def main():
                     "per-kernel durations of the same step (profiles/r03_bench10m_kernel_stats.csv: GEMMs 136, seven small "
                     "launches 37, update 35 us) carry ~1.5 us of profiler overhead per kernel"}
     if not args.no_update_only and kind == "sghmc":
+        if sampler.use_hip_graph:
+            line["chains_per_gpu"] = chains_per_gpu_leg(dev, sampler, args.workload)
         line["update_only"] = update_only(sampler)
         del moments, trace
         line["roofline_hbm_resident"] = hbm_resident_roofline(dev)

@@ -453,6 +453,48 @@ def test_update_kernel_timer_through_the_sampler(gpu):
     assert UpdateKernelTimer.empty_bracket_us(20) >= 0.0
 
 
+def test_concurrent_chains_on_one_gpu_equal_the_chains_alone(gpu):
+    """``ConcurrentChains``: independent chains on their own streams (own hipGraphs), enqueued round-robin, compute exactly
+    what they compute one after the other -- eager and graph stepping, through the burn-in switch."""
+    from pysgmcmc_amd.data_batches import Placeholder, generate_batches
+    from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
+    from pysgmcmc_amd.samplers import ConcurrentChains
+    from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+    rng = np.random.RandomState(0)
+    X, y = rng.rand(500, 12), rng.rand(500)
+
+    def chain(k, graph):
+        xp, yp = Placeholder(dtype=torch.float32, device=gpu), Placeholder(dtype=torch.float32, device=gpu)
+        params = init_mlp_params(12, hidden=(64, 128, 64), seed=10 + k, dtype=torch.float32, device=gpu)
+        s = SGHMCSampler(params=params, cost_fun=BNNCost(xp, yp, batch_size=32, n_examples=500),
+                         batch_generator=generate_batches(X, y, xp, yp, batch_size=32, seed=k),
+                         stepsize_schedule=ConstantStepsizeSchedule(0.01), burn_in_steps=5, scale_grad=500.0, session=gpu,
+                         dtype=torch.float32, seed=20 + k)
+        s.sample_format = "view"
+        s.use_hip_graph = graph
+        return s
+    for graph in (False, True):
+        alone = [chain(k, graph) for k in range(3)]
+        costs_alone = [[float(next(s)[1]) for _ in range(14)] for s in alone]
+        group = ConcurrentChains([chain(k, graph) for k in range(3)])
+        costs = [[] for _ in range(3)]
+        for i in range(14):
+            results = next(group)
+            if i % 3 == 0:
+                group.join()                  # the cost is a view of the chain's buffer: read it before the next step
+                for k, (_, cost) in enumerate(results):
+                    costs[k].append((i, float(cost)))
+        group.join()
+        torch.cuda.synchronize()
+        assert len(group) == 3 and len({st.cuda_stream for st in group.streams}) == 3
+        for k in range(3):
+            assert costs[k] == [(i, costs_alone[k][i]) for i in range(0, 14, 3)]
+            for row in ("theta", "V", "minv"):
+                assert torch.equal(group.samplers[k].arena.row(row), alone[k].arena.row(row)), (graph, k, row)
+    with pytest.raises(ValueError):
+        ConcurrentChains([])
+
+
 def test_draw_noise_sample_api(gpu):
     s = SGHMCSampler(params=[torch.zeros(3, 2)], cost_fun=lambda p: (p[0] ** 2).sum(), session=gpu,
                      dtype=torch.float32, seed=4)
