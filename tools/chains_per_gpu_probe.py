@@ -10,12 +10,14 @@ from pysgmcmc_amd.models.bayesian_neural_network import enable_gemm_tuning
 dev = torch.device("cuda:0")
 enable_gemm_tuning(True, max_duration_ms=30, max_iterations=20)
 STEPS = 300
+MODE = {"full": "full"}.get(os.environ.get("PROBE_GRAPH", ""), True)    # PROBE_GRAPH=full: the update inside the graph (less host work per step)
+print("use_hip_graph =", MODE)
 for n_chains in (1, 2, 3, 4):
     chains, streams = [], []
     for c in range(n_chains):
         s = bench.build_chain(dev, c, "bnn10m-sghmc", burn_in=8)
         s.sample_format = "view"
-        s.use_hip_graph = True
+        s.use_hip_graph = MODE
         s.collect_stats = "theta_sq"
         chains.append(s)
         streams.append(torch.cuda.Stream(device=dev))
