@@ -5,7 +5,8 @@
 The reference runs an ensemble's chains one after the other (pysgmcmc/diagnostics/sample_chains.py:369-382). Here every chain
 has its own HIP stream and hipGraph and one host thread enqueues them round-robin: the second chain's kernels fill the parts of
 the chip the first one's leave idle. Prints the ensemble's samples/s next to the same chains stepped one after the other, and
-the Gelman-Rubin statistic over the chains' second halves.
+the Gelman-Rubin statistic of ALL parameters across the chains (Welford moments folded into every 10th update launch,
+RhatExchange over the local chains: no collective, no host copy of any sample).
 """
 import os
 import sys
@@ -15,7 +16,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pysgmcmc_amd.data_batches import Placeholder, generate_batches  # noqa: E402
-from pysgmcmc_amd.diagnostics.sampler_diagnostics import gelman_rubin_from_chains  # noqa: E402
+from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange  # noqa: E402
 from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params  # noqa: E402
 from pysgmcmc_amd.samplers import ConcurrentChains, SGHMCSampler  # noqa: E402
 from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule  # noqa: E402
@@ -45,26 +46,25 @@ for label in ("one after the other", "concurrently"):
     group = ConcurrentChains(chains)
     group.run(150)                      # burn-in + graph capture
     group.synchronize()
-    coords = torch.tensor([0, chains[0].arena.n // 2, chains[0].arena.n - 1], device=dev)
-    kept = torch.zeros(n_chains, STEPS // 10, 3, device=dev)
+    moments = [ChainMoments(s.arena.n, dev) for s in chains]
+    for s, m in zip(chains, moments):
+        s.attach_moments(m, every=10)   # theta' of every 10th step is folded into the chain's moments inside the update launch
     t0 = time.perf_counter()
     if label == "concurrently":
-        for i in range(STEPS):
-            next(group)
-            if i % 10 == 9:             # thinned trace of three coordinates, gathered on each chain's own stream
-                for k, (s, st) in enumerate(zip(chains, group.streams)):
-                    with torch.cuda.stream(st):
-                        torch.index_select(s.arena.row("theta"), 0, coords, out=kept[k, i // 10])
+        group.run(STEPS)
         group.synchronize()
     else:
-        for k, s in enumerate(chains):
-            for i in range(STEPS):
+        for s in chains:
+            for _ in range(STEPS):
                 next(s)
-                if i % 10 == 9:
-                    torch.index_select(s.arena.row("theta"), 0, coords, out=kept[k, i // 10])
         torch.cuda.synchronize()
     rates[label] = n_chains * STEPS / (time.perf_counter() - t0)
-    rhat = [round(float(r), 3) for r in gelman_rubin_from_chains(kept[:, STEPS // 20:].cpu().numpy().astype("float64"))] \
-        if n_chains > 1 else None
-    print("%d chains %-20s %8.0f samples/s   R-hat of 3 coordinates: %s" % (n_chains, label + ":", rates[label], rhat))
+    summary = None
+    if n_chains > 1:
+        group.join()
+        exchange = RhatExchange(chains[0].arena.n, dev, mode="allreduce")
+        exchange.start(moments)         # several local chains: their packs are added, nothing crosses a link
+        summary = {k: round(v, 4) for k, v in exchange.finish(with_summary=True)[1].items()}
+    print("%d chains %-20s %8.0f samples/s   R-hat over %d parameters x %d kept samples: %s" % (
+        n_chains, label + ":", rates[label], chains[0].arena.n, moments[0].count, summary))
 print("ensemble speed-up from sharing the GPU: %.2fx" % (rates["concurrently"] / rates["one after the other"]))

@@ -107,6 +107,13 @@ def cross_chain_rhat(moments, group=None, pack=None, rhat=None, with_summary=Tru
     return rhat, summ.as_dict()
 
 
+class _NoCollective(object):
+    """Stands in for the async work handle when the chains are all local (nothing to wait for)."""
+
+    def wait(self):
+        return True
+
+
 class RhatExchange(object):
     """Non-blocking form of :func:`cross_chain_rhat`: ``start`` packs a snapshot of the moments and
     issues the collective asynchronously on RCCL's own stream, sampling continues, ``finish`` waits
@@ -124,7 +131,13 @@ class RhatExchange(object):
 
     ``finish()`` never synchronises with the host: the R-hat summary stays in device memory
     (``exchange.summary``) and is read when the caller asks for it.
-    ``finish(with_summary=True)`` reads it immediately (a ``.cpu()`` sync; end-of-run reporting)."""
+    ``finish(with_summary=True)`` reads it immediately (a ``.cpu()`` sync; end-of-run reporting).
+
+    Several chains per rank (chains that share a GPU, ``samplers.ConcurrentChains``): ``start([moments_a, moments_b, ...])``
+    adds the local chains' packs before the collective -- the pack is a sum over chains -- and R-hat is over
+    ``world x len(list)`` chains (every rank must pass equally many, with equal counts). With ``mode="allreduce"`` and no
+    process group (or one rank) the same call gives the R-hat of the local chains alone, no collective at all. The caller
+    orders the chains' streams before ``start`` (``ConcurrentChains.join()``)."""
 
     def __init__(self, n, device, group=None, dtype=torch.float32, mode="allreduce"):
         assert mode in ("allreduce", "reduce_scatter")
@@ -134,6 +147,8 @@ class RhatExchange(object):
         self.exchanges = 0
         self._work = None
         self._count = 0
+        self._local_chains = 1
+        self._pack_more = None
         if mode == "allreduce":
             self.n_shards, self.shard_len, self.n_valid, self.rank = 1, self.n, self.n, 0
             self.pack = torch.empty(3 * self.n, dtype=dtype, device=device)
@@ -165,17 +180,33 @@ class RhatExchange(object):
         return self._work is not None
 
     def start(self, moments):
-        if moments.mean.dtype != self.pack.dtype:
-            # the pack kernel is chosen from the moments' dtype: an f64 pack into this f32 buffer would overrun it
-            raise TypeError("RhatExchange was built for %s but the chain's moments are %s: pass dtype=%s" % (
-                self.pack.dtype, moments.mean.dtype, moments.mean.dtype))
+        local = list(moments) if isinstance(moments, (list, tuple)) else [moments]
+        if not local:
+            raise ValueError("RhatExchange.start: no moments")
+        for mom in local:
+            if mom.mean.dtype != self.pack.dtype:
+                # the pack kernel is chosen from the moments' dtype: an f64 pack into this f32 buffer would overrun it
+                raise TypeError("RhatExchange was built for %s but the chain's moments are %s: pass dtype=%s" % (
+                    self.pack.dtype, mom.mean.dtype, mom.mean.dtype))
+        if any(mom.count != local[0].count for mom in local):
+            raise ValueError("RhatExchange.start: the local chains' moments hold different sample counts")
         dist = _dist()
-        if dist is None or dist.get_world_size(self.group) < 2:
-            raise RuntimeError("RhatExchange needs an initialised process group with >= 2 chains")
+        world = 1 if dist is None else dist.get_world_size(self.group)
+        if world * len(local) < 2 or (world < 2 and self.mode != "allreduce"):
+            raise RuntimeError("RhatExchange needs >= 2 chains: an initialised process group with >= 2 ranks, or (mode="
+                               "'allreduce') several local chains")
         assert not self.pending, "finish() the previous exchange first"
-        kernels.rhat_pack(moments.mean, moments.m2, moments.count, self.pack, self.n_shards, self.shard_len)
-        self._count = moments.count
-        if self.mode == "reduce_scatter" and self._native_rs:
+        kernels.rhat_pack(local[0].mean, local[0].m2, local[0].count, self.pack, self.n_shards, self.shard_len)
+        for mom in local[1:]:                 # the pack is additive over chains: local chains are summed before the collective
+            if self._pack_more is None:
+                self._pack_more = torch.empty_like(self.pack)
+            kernels.rhat_pack(mom.mean, mom.m2, mom.count, self._pack_more, self.n_shards, self.shard_len)
+            self.pack.add_(self._pack_more)
+        self._count = local[0].count
+        self._local_chains = len(local)
+        if world < 2:
+            self._work = _NoCollective()
+        elif self.mode == "reduce_scatter" and self._native_rs:
             self._work = dist.reduce_scatter_tensor(self.shard_sum, self.pack, group=self.group, async_op=True)
         else:
             self._work = dist.all_reduce(self.pack, group=self.group, async_op=True)
@@ -183,8 +214,9 @@ class RhatExchange(object):
     def finish(self, with_summary=False):
         dist = _dist()
         self._work.wait()                     # stream-level wait: the current stream now depends on the collective
+        local_only = isinstance(self._work, _NoCollective)
         self._work = None
-        m = dist.get_world_size(self.group)
+        m = (1 if local_only else dist.get_world_size(self.group)) * self._local_chains
         if self.mode == "reduce_scatter" and not self._native_rs:
             L3 = 3 * self.shard_len
             self.shard_sum.copy_(self.pack[self.rank * L3:(self.rank + 1) * L3])

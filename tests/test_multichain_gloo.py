@@ -72,8 +72,31 @@ def _worker(rank, world, port, out_dir):
     assert torch.equal(rs.gather(), rhat)                                    # all-gather of the shards = full vector
     ssum = rs.summary.as_dict()
     assert np.isclose(ssum["mean"], summ["mean"], rtol=1e-12) and ssum["max"] == summ["max"]
+    # two chains PER RANK (chains that share a GPU): the local packs are added before the one collective, R-hat is over
+    # world x 2 chains, in both exchange layouts
+    x_b = torch.full((n,), -2.0 + rank, dtype=torch.float32)
+    s_b = SGHMCSampler(params=[x_b], cost_fun=lambda p: 0.5 * (p[0] ** 2).sum(), burn_in_steps=50, session="cpu",
+                       stepsize_schedule=ConstantStepsizeSchedule(0.1), dtype=torch.float32, seed=500 + rank)
+    s_b.sample_format = "view"
+    mom_a, mom_b, kept_b = ChainMoments(n, "cpu"), ChainMoments(n, "cpu"), []
+    for arr in kept:
+        mom_a.update(torch.from_numpy(arr))
+    for t, (sample, cost) in enumerate(islice(s_b, 650)):
+        if t >= 50 and t % 3 == 0:
+            mom_b.update(s_b.arena.row("theta"))
+            kept_b.append(sample.clone().numpy())
+    ex.start([mom_a, mom_b])
+    rhat4 = ex.finish()[0].clone()
+    rs.start([mom_a, mom_b])
+    shard4 = rs.finish()[0]
+    assert torch.equal(shard4[:rs.n_valid], rhat4[lo:lo + rs.n_valid]) and torch.equal(rs.gather(), rhat4)
+    with pytest.raises(ValueError):
+        short = ChainMoments(n, "cpu")
+        short.update(torch.zeros(n))
+        ex.start([mom_a, short])                                            # unequal sample counts
     ess = ess_across_ranks(torch.tensor(trace, dtype=torch.float32))
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), kept=np.array(kept), rhat=rhat.numpy(),
+             kept_b=np.array(kept_b), rhat4=rhat4.numpy(),
              rhat_mean=summ["mean"], rhat_max=summ["max"], ess=np.array(ess), trace=np.array(trace),
              final=s.arena.row("theta").numpy())
     dist.barrier()
@@ -94,6 +117,10 @@ def test_two_chains_rhat_and_ess_over_gloo(tmp_path, oracle):
     assert np.allclose(r[0]["rhat"], want, rtol=2e-3, atol=1e-4)
     assert np.isclose(r[0]["rhat_mean"], want.mean(), rtol=2e-3) and np.isclose(r[0]["rhat_max"], want.max(), rtol=2e-3)
     assert 0.9 < want.mean() < 1.3
+    # two chains per rank: R-hat over all four chains
+    assert np.array_equal(r[0]["rhat4"], r[1]["rhat4"])
+    want4 = oracle.gelman_rubin(np.stack([r[0]["kept"], r[0]["kept_b"], r[1]["kept"], r[1]["kept_b"]]))
+    assert np.allclose(r[0]["rhat4"], want4, rtol=2e-3, atol=1e-4) and not np.allclose(r[0]["rhat4"], r[0]["rhat"], rtol=1e-3)
     # ESS: identical on both ranks, equal to the oracle's variogram estimate
     assert np.array_equal(r[0]["ess"], r[1]["ess"])
     traces = np.stack([r[0]["trace"], r[1]["trace"]])                   # (m, n, K)

@@ -495,6 +495,40 @@ def test_concurrent_chains_on_one_gpu_equal_the_chains_alone(gpu):
         ConcurrentChains([])
 
 
+def test_rhat_of_chains_that_share_a_gpu(gpu):
+    """``RhatExchange.start([moments, ...])`` with no process group: R-hat over the local chains (fused Welford moments of
+    ``ConcurrentChains``) equals the formula on the chains' explicit samples."""
+    from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange, gelman_rubin_from_chains
+    from pysgmcmc_amd.samplers import ConcurrentChains
+    n = 1001
+    chains = [SGHMCSampler(params=[torch.full((n,), 2.0 * k - 2.0, device=gpu)], cost_fun=lambda p: 0.5 * (p[0] ** 2).sum(),
+                           burn_in_steps=30, session=gpu, dtype=torch.float32, seed=40 + k) for k in range(3)]
+    moments = [ChainMoments(n, gpu) for _ in chains]
+    for s in chains:
+        s.sample_format = "view"
+        s.use_hip_graph = True
+    group = ConcurrentChains(chains)
+    group.run(60)
+    for s, m in zip(chains, moments):
+        s.attach_moments(m, every=2)
+    kept = [[] for _ in chains]
+    for i in range(120):
+        next(group)
+        if i % 2 == 1:                                     # the steps whose update launch folded theta' into the moments
+            for k, (s, st) in enumerate(zip(chains, group.streams)):
+                with torch.cuda.stream(st):
+                    kept[k].append(s.arena.row("theta").clone())
+    group.join()
+    assert all(m.count == 60 for m in moments)
+    ex = RhatExchange(n, gpu, mode="allreduce")
+    ex.start(moments)
+    rhat, summ = ex.finish(with_summary=True)
+    want = gelman_rubin_from_chains(torch.stack([torch.stack(c) for c in kept]))
+    assert torch.allclose(rhat.double().cpu(), want.cpu(), rtol=2e-4) and np.isclose(summ["max"], want.max().item(), rtol=2e-4)
+    with pytest.raises(RuntimeError):
+        ex.start(moments[0])                               # one chain, no process group: no R-hat
+
+
 def test_draw_noise_sample_api(gpu):
     s = SGHMCSampler(params=[torch.zeros(3, 2)], cost_fun=lambda p: (p[0] ** 2).sum(), session=gpu,
                      dtype=torch.float32, seed=4)
