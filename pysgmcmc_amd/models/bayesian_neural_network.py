@@ -492,9 +492,10 @@ class BayesianNeuralNetwork(object):
         self.dtype = dtype
         self.session = session
         self.hidden = tuple(hidden)
-        # n_chains > 1 (extension): that many independent chains advance together in the fused small-model kernel
-        # and every collection point contributes one network per chain, so `n_nets` networks need 1/n_chains of
-        # the sampling iterations (the reference would run the chains one after the other)
+        # n_chains > 1 (extension): that many independent chains advance together -- in the fused small-model kernel (one
+        # launch per chunk for all chains), or, for a net that kernel does not take, each chain through its own cost pipeline
+        # on its own stream (samplers.ConcurrentChains) -- and every collection point contributes one network per chain, so
+        # `n_nets` networks need 1/n_chains of the sampling iterations (the reference would run the chains one after the other)
         self.n_chains = n_chains
         self.chains = None
         self.is_trained = False
@@ -605,10 +606,10 @@ class BayesianNeuralNetwork(object):
         self.used_fused_steps = fused
         self.chains = None
         if self.n_chains > 1:
-            if not fused:
-                raise ValueError("BayesianNeuralNetwork(n_chains > 1) needs the fused small-model path (a net whose "
-                                 "activations fit the LDS, SGHMC or SGLD, on an AMD GPU); got a configuration without it")
-            self.chains = self._build_chain_group(X.shape[0], X.shape[1], device)
+            if not fused and device.type != "cuda":
+                raise ValueError("BayesianNeuralNetwork(n_chains > 1) needs an AMD GPU: the chains advance together, in the "
+                                 "fused small-model kernel or as concurrent streams; got device %s" % device)
+            self.chains = self._build_chain_group(X.shape[0], X.shape[1], device, fused)
         if self.chains is not None:
             advance = self.chains.steps          # every chain, n steps, one launch
         elif fused:
@@ -624,9 +625,12 @@ class BayesianNeuralNetwork(object):
                 break
         self.is_trained = True
 
-    def _build_chain_group(self, n_datapoints, n_inputs, device):
+    def _build_chain_group(self, n_datapoints, n_inputs, device, fused=True):
         """Chains 1 .. n_chains-1 next to ``self.sampler`` (chain 0): own initial weights (init seed + c), own window
-        stream (RandomState(seed + c)) and Philox seed ``seed_0 + c``; one resident copy of the dataset."""
+        stream (RandomState(seed + c)) and Philox seed ``seed_0 + c``; one resident copy of the dataset. ``fused``: all
+        chains advance in the fused small-model kernel (one launch per chunk); otherwise -- a model that kernel does not
+        fit -- every chain steps through its own cost pipeline on its own stream (``ConcurrentChains``)."""
+        from pysgmcmc_amd.samplers.concurrent_chains import ConcurrentChains
         from pysgmcmc_amd.samplers.fused_chains import FusedBNNChains
         first = self.sampler
         gen0 = first.batch_generator
@@ -634,20 +638,27 @@ class BayesianNeuralNetwork(object):
         for c in range(1, self.n_chains):
             params = init_mlp_params(n_inputs, hidden=self.hidden, seed=None if self.seed is None else self.seed + c,
                                      dtype=self._torch_dtype, device=device)
+            if fused:
+                xp, yp = self.X_Minibatch, self.Y_Minibatch
+            else:                                 # a captured cost pipeline reads the chain's own static feed buffers
+                xp = Placeholder(dtype=self._torch_dtype, shape=(None, n_inputs), name="X_Minibatch_%d" % c, device=device)
+                yp = Placeholder(dtype=self._torch_dtype, name="Y_Minibatch_%d" % c, device=device)
+            cost = BNNCost(xp, yp, self.batch_size, n_datapoints)
             kw = dict(self.sampler_kwargs)
             kw.update({
                 "params": params,
-                "cost_fun": BNNCost(self.X_Minibatch, self.Y_Minibatch, self.batch_size, n_datapoints),
-                "batch_generator": type(gen0)(gen0.x_dev, gen0.y_dev, self.X_Minibatch, self.Y_Minibatch,
-                                              gen0.batch_size,
+                "cost_fun": cost if self.fused_cost else (lambda ps, *_, cost=cost: cost(ps)),
+                "batch_generator": type(gen0)(gen0.x_dev, gen0.y_dev, xp, yp, gen0.batch_size,
                                               np.random.RandomState(None if self.seed is None else self.seed + c)),
                 "seed": int((first._philox_seed + c) & 0xFFFFFFFFFFFFFFFF),
                 "stepsize_schedule": copy.deepcopy(self.stepsize_schedule),
             })
             member = Sampler.get_sampler(self.sampling_method, **kw)
             member.sample_format = "view"
+            member.collect_stats = first.collect_stats
+            member.use_hip_graph = first.use_hip_graph
             members.append(member)
-        return FusedBNNChains(members)
+        return FusedBNNChains(members) if fused else ConcurrentChains(members)
 
     def compute_network_output(self, params, input_data):
         """Network output ``(N, 2)`` for one set of sampled weights (``:535-557``)."""

@@ -53,6 +53,21 @@ class ConcurrentChains(object):
                 out.append(next(sampler))
         return out
 
+    def fork(self):
+        """Every chain's stream waits (on the device) for what the current stream has enqueued so far -- e.g. copies of the
+        chains' parameters taken after a ``join()``, before the chains move on."""
+        current = torch.cuda.current_stream(self.device)
+        for stream in self.streams:
+            stream.wait_stream(current)
+
+    def steps(self, n_steps):
+        """``fork()``, ``n_steps`` steps of every chain, ``join()``: the chains advance concurrently, the caller's stream sees
+        the result (the interface of ``FusedBNNChains.steps``)."""
+        self.fork()
+        last = self.run(n_steps)
+        self.join()
+        return last
+
     def run(self, n_steps):
         """``n_steps`` steps of every chain; returns the last step's results."""
         last = None

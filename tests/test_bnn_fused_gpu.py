@@ -267,7 +267,21 @@ def test_bnn_train_with_several_chains(gpu):
     # chain 0 is the single-chain run; the other chains are different draws
     assert torch.equal(four.samples[0][0], one.samples[0][0])
     assert not torch.equal(four.samples[0][0], four.samples[1][0])
-    with pytest.raises(ValueError):
-        b = BayesianNeuralNetwork(n_chains=2, **kw)
-        b.use_fused_steps = False
-        b.train(X, y)
+    # a configuration the fused kernel does not take (here: switched off): the chains advance as concurrent streams
+    # (ConcurrentChains), chain 0 is again the single-chain run of the same configuration
+    kw2 = dict(kw, burn_in_steps=200, sample_steps=20, n_nets=6)
+    solo = BayesianNeuralNetwork(**kw2)
+    solo.use_fused_steps = False
+    solo.train(X, y)
+    duo = BayesianNeuralNetwork(n_chains=2, **kw2)
+    duo.use_fused_steps = False
+    duo.train(X, y)
+    from pysgmcmc_amd.samplers import ConcurrentChains
+    assert isinstance(duo.chains, ConcurrentChains) and not duo.used_fused_steps and len(duo.samples) == 6
+    assert solo.sampler.n_iterations == 200 + 6 * 20 + 1 and duo.sampler.n_iterations == 200 + 3 * 20 + 1
+    for a, b in zip(duo.samples[0], solo.samples[0]):
+        assert torch.equal(a, b)
+    assert torch.equal(duo.samples[2][0], solo.samples[1][0]) and not torch.equal(duo.samples[0][0], duo.samples[1][0])
+    assert np.all(np.isfinite(duo.predict(Xt)[0]))
+    with pytest.raises(ValueError, match="needs an AMD GPU"):
+        BayesianNeuralNetwork(n_chains=2, **dict(kw, session="cpu")).train(X, y)
