@@ -5,21 +5,24 @@
 //                                             B = the layer's back-propagated deltas     [K = batch][N = fan_out]
 //
 // is the last thing the backward pass computes for a layer, and the ONLY consumer of gW is the sampler's update of W
-// (pysgmcmc/samplers/sghmc.py:211-251). Fused form: the tile of gW a workgroup has just accumulated in its MFMA
-// accumulators never goes to HBM -- the workgroup loads the same tile of theta, V and minv (prefetched under the K loop),
-// draws the tile's Philox normals (the stream of the streaming kernel K1: counter = (step, global quad index)), applies
-// the frozen SGHMC update arithmetic (SghmcOp, one IEEE rounding per reference op) and writes theta', V'. Per parameter
-// that is 20 B of HBM traffic instead of 4 (GEMM writes gW) + 24 (K1), and the HBM-bound update hides under the
-// matrix-core-bound product instead of running after it (second-stream and any-order overlap do not work on this
-// stack: profiles/r03_overlap_probe.txt).
+// (pysgmcmc/samplers/sghmc.py:211-251). Fused form (gemm_tn_sghmc_kernel): the tile of gW a workgroup has just accumulated
+// never goes to HBM -- the workgroup loads the same tile of theta, V and minv, draws the tile's Philox normals (the stream of
+// the streaming kernel K1: counter = (step, global quad index)), applies the frozen SGHMC update (SghmcOp::compute, one IEEE
+// rounding per reference op) and writes theta', V'. Per parameter that is 20 B of HBM traffic instead of 4 (GEMM writes gW)
+// + 24 (K1) and one launch less. What it does NOT do is hide the update's arithmetic: fp32 MFMA and vector-ALU work of
+// different waves on one SIMD take the sum of their times on gfx950 (tools/gpu/mfma_valu_overlap.hip), so the fused kernel
+// costs product time + ~8 us of Philox / Box-Muller / update ALU work per 2048 x 2048 layer, and in the sampler it is a draw
+// with library GEMM + one K1 launch (profiles/r03_gemm_fusion_probe.txt). It stays opt-in (sampler.fuse_update_into_gemm).
 //
-// Tiling for gfx950: 128 x 128 output tile per 256-lane workgroup (4 waves in 2 x 2, each 64 x 64 = 2 x 2
-// v_mfma_f32_32x32x2_f32 tiles, 64 accumulator registers), K in chunks of 16 through a double-buffered LDS stage
-// (2 x 16 KB). Operand fragments are single floats per lane (A[m = lane & 31][k = lane >> 5], B[k][n = lane & 31]) read
-// from k-major LDS rows: conflict-free ds_read_b32. The accumulator map (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5),
-// col = lane & 31) makes every accumulator register of a wave two 128-byte row segments: dword accesses of the epilogue
-// are fully coalesced. A Philox quad = 4 consecutive parameters = the same row in 4 adjacent lanes; lane t of each lane
-// quad draws the quad of row t and a 4 x 4 DPP transpose hands every lane its own column.
+// Tiling for gfx950: 64 x 64 output tile per 256-lane workgroup (4 waves in 2 x 2, each one v_mfma_f32_32x32x2_f32 tile = 16
+// accumulator registers), four workgroups per CU. Operand fragments are single floats per lane (A[m = lane & 31][k = lane
+// >> 5], B[k][n = lane & 31]) read from k-major LDS rows: conflict-free ds_read_b32. The K loop of the default variant
+// (mainloop_dma) requests its operands with global_load_lds_dwordx4 -- 16 bytes per lane from global memory straight into LDS
+// -- in chunks of 16, two chunks ahead, into a ring of three stages, with an explicit vmcnt wait and ONE bare s_barrier per
+// chunk; it runs at the MFMA rate (12.9 us of a 22.0 us launch at 2048 x 2048 x 256; the rest is launch, first-chunk latency,
+// tail and the output store). The other variants (Tile<...>/mainloop: operands staged through registers, bigger tiles) are
+// kept for tools/gemm_probe2.py. The accumulators leave through LDS so that stores (and the fused update) work on row-major
+// quads: a lane owns 4 consecutive columns of a row = one Philox quad and one 16-byte access per array.
 //
 // fp32 MFMA is an exact fmaf chain in k order (MI355X_MICROARCH.md): the product differs from a library GEMM only in
 // summation order. The update arithmetic is bit-identical to K1 applied to the same gW (tests write gW out and check).
