@@ -88,9 +88,6 @@ struct Tile {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-// acc[i][j] = 32 x 32 tile (rows +32 i, cols +32 j) of this wave's part of the block tile at (m0, n0)
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-
 // LDS of one workgroup: two stages of a BK x BM and a BK x BN chunk
 template <typename TL>
 struct Stages {
@@ -98,13 +95,11 @@ struct Stages {
     float B[2][TL::BK][TL::BN];
 };
 
-// acc[i][j] = 32 x 32 tile (rows +32 i, cols +32 j) of this wave's part of the block tile at (m0, n0).
-// LastChunkHook: called once, right before the MFMAs of the LAST K chunk (peeled out of the loop) are issued -- the fused
-// kernel requests its tile's state there: the loads fly under that chunk's MFMAs, and nothing but the accumulators is live
-// across the loop.
-template <typename TL, int TM, int TN, typename LastChunkHook = NoHook>
+// The register-staged K loop (probe variants 1-9): acc[i][j] = 32 x 32 tile (rows +32 i, cols +32 j) of this wave's part of
+// the block tile at (m0, n0); the last chunk is peeled out of the loop (no fetch of a chunk that does not exist).
+template <typename TL, int TM, int TN>
 __device__ __forceinline__ void mainloop(const GemmArgs &g, Stages<TL> &lds, int m0, int n0, int wm, int wn,
-                                         f32x16 (&acc)[TM][TN], LastChunkHook hook = LastChunkHook())
+                                         f32x16 (&acc)[TM][TN])
 {
     constexpr int BK = TL::BK, BM = TL::BM, BN = TL::BN, NT = TL::NT, LA = TL::LA, LB = TL::LB;
     constexpr int SUB = TL::SUB, NSUB = BK / 2 / SUB;       // k-steps (of 2) per sub-batch, sub-batches per chunk
@@ -204,7 +199,6 @@ __device__ __forceinline__ void mainloop(const GemmArgs &g, Stages<TL> &lds, int
     {
         const int s = (nk - 1) & 1;
         frags(s, 0, 0);
-        hook();
         mfmas(s);
         __syncthreads();                                   // the stages may be overwritten by the next tile
     }
