@@ -127,6 +127,9 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="step eagerly instead of replaying one hipGraph per step")
     ap.add_argument("--max-queue-depth", type=int, default=64,
                     help="steps the host may run ahead of the device in the timed loop (0 = unbounded)")
+    ap.add_argument("--chains-per-gpu", type=int, default=1,
+                    help="independent chains that SHARE each GPU (own stream + hipGraph each, pysgmcmc_amd.samplers."
+                         "ConcurrentChains); the default 1 is BASELINE.json's sharding (one chain per GPU)")
     ap.add_argument("--time-every", type=int, default=0,
                     help="the update launches of every k-th timed step carry the HIP timestamp events (a timed launch costs ~8 us of "
                          "device time per step); 0 = steps // 5 clamped to [1, 7]")
@@ -695,6 +698,20 @@ def main():
     sampler.kernel_timer = timer
     from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange
     moments = ChainMoments(n, dev)
+    # --chains-per-gpu K > 1: K - 1 more independent chains on this GPU (chain ids rank + world * c: distinct seeds, initial
+    # weights and window streams across the whole job), stepped concurrently with the first one, each on its own stream
+    K = max(int(args.chains_per_gpu), 1)
+    chains, all_moments, group = [sampler], [moments], None
+    if K > 1:
+        if kind != "sghmc" or args.eager or sampler.overlap_update:
+            raise SystemExit("--chains-per-gpu > 1 is implemented for the SGHMC workload in hipGraph mode without --overlap")
+        from pysgmcmc_amd.samplers import ConcurrentChains
+        for c in range(1, K):
+            other = build_chain(dev, rank + world * c, args.workload, burn_in=PRIME_BURN_IN)
+            other.sample_format, other.use_hip_graph, other.collect_stats = "view", sampler.use_hip_graph, sampler.collect_stats
+            chains.append(other)
+            all_moments.append(ChainMoments(n, dev))
+        group = ConcurrentChains(chains)
     exchange = RhatExchange(n, dev, mode=args.rhat_mode) if world > 1 else None
     # R-hat cadence: --rhat-every steps (configs[3]: 100). A timed region shorter than that would contain no
     # collective at all, so one exchange is then placed mid-run: its cost is inside `value` at every N > 1.
@@ -713,11 +730,16 @@ def main():
     def one_step(i, every=None):
         every = args.moments_every if every is None else every
         # K4 rides in the update launch of every `every`-th step (sgmcmc_step_opts_t.moments_*): no separate pass over theta
-        sampler.attach_moments(moments if every else None, every or 1)
-        _, cost = next(sampler)
+        for chain, mom in zip(chains, all_moments):
+            chain.attach_moments(mom if every else None, every or 1)
+        if group is None:
+            _, cost = next(sampler)
+        else:
+            cost = next(group)[0][1]                                   # every chain of this GPU, round-robin on their streams
         if every and sampler.n_iterations % every == 0:                # this step's update folded theta' into the moments
-            trace[kept[0], 0:1].copy_(cost.reshape(1))
-            torch.index_select(sampler.arena.row("theta"), 0, coords, out=trace[kept[0], 1:4])
+            with torch.cuda.stream(group.streams[0] if group is not None else torch.cuda.current_stream(dev)):
+                trace[kept[0], 0:1].copy_(cost.reshape(1))             # (the thinned ESS trace follows the GPU's first chain)
+                torch.index_select(sampler.arena.row("theta"), 0, coords, out=trace[kept[0], 1:4])
             kept[0] += 1
         if exchange is not None and periodic_exchange[0]:
             # the only exchange on the path: ONE all-reduce of 3P floats over RCCL/xGMI, issued
@@ -731,7 +753,11 @@ def main():
     def rhat_start():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        exchange.start(moments)                                        # pack kernel + async all-reduce (RCCL stream)
+        if group is not None:
+            group.join()                                               # the pack reads every local chain's moments ...
+        exchange.start(all_moments if K > 1 else moments)              # pack kernel(s) + async collective (RCCL stream)
+        if group is not None:
+            group.fork()                                               # ... before the chains update them again
         ev[1].record()
         ex_events.append(ev)
 
@@ -860,7 +886,7 @@ def main():
         with_mom = [r for r in rows if r[5]]
         line = {
             "metric": "MCMC samples/sec + fused-update HBM GB/s (% roofline), BNN 10M params",
-            "value": round(world * args.steps / elapsed, 2),
+            "value": round(world * K * args.steps / elapsed, 2),
             "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -874,10 +900,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s (%s) full next(sampler) step: BNN fwd+bwd + fused update; "
-                                   "4-layer tanh MLP BNN %s-1, %d params, batch %d, 1 chain per GPU" % (
+                                   "4-layer tanh MLP BNN %s-1, %d params, batch %d, %d chain(s) per GPU" % (
                                        args.workload, kind.upper(), mode, "-".join(map(str, WORKLOADS[args.workload]["layers"])),
-                                       n, BATCH),
-                       "params": n, "batch": BATCH, "chains": world,
+                                       n, BATCH, K),
+                       "params": n, "batch": BATCH, "chains": world * K, "chains_per_gpu": K,
                        "rhat_every": rhat_every if world > 1 else None,
                        "moments_every": args.moments_every, "moments": "fused into the update launch (K4 in K1)",
                        "hip_graph": bool(sampler.use_hip_graph),
@@ -917,7 +943,10 @@ def main():
                                    "their durations; `roofline_unoverlapped` times EVERY launch of a second loop outside `value`" % time_every + (
                                        " -- the slices run CONCURRENTLY with the backward GEMMs, so this is the contended "
                                        "rate; `roofline_unoverlapped` is the same kernel alone in the pipeline"
-                                       if launches_per_step > 1 else "")},
+                                       if launches_per_step > 1 else "") + (
+                                       " -- with %d chains per GPU the timed launches (first chain) run CONCURRENTLY with the other "
+                                       "chains' kernels: contended rate; `roofline_unoverlapped` is the kernel alone in its pipeline" % K
+                                       if K > 1 else "")},
         }
         if exchange is not None:
             timed = ex_events[prime_rhat_events:]
@@ -962,6 +991,12 @@ def main():
         dist.destroy_process_group()
     if rank != 0:
         return
+    if group is not None:                                              # the legs below step the GPU's first chain alone
+        group.join()
+        torch.cuda.synchronize()
+        del chains[1:], all_moments[1:]
+        group = None
+        torch.cuda.empty_cache()
     if kind == "sghmc" and sampler.use_hip_graph:
         # ---- un-overlapped figures + where the step time goes (identical code path at every N: SCALE N = 1 equals BENCH)
         legs = max(min(args.steps, 60), 20)
@@ -1005,7 +1040,7 @@ def main():
                     "per-kernel durations of the same step (profiles/r03_bench10m_kernel_stats.csv: GEMMs 136, seven small "
                     "launches 37, update 35 us) carry ~1.5 us of profiler overhead per kernel"}
     if not args.no_update_only and kind == "sghmc":
-        if sampler.use_hip_graph:
+        if sampler.use_hip_graph and K == 1:
             line["chains_per_gpu"] = chains_per_gpu_leg(dev, sampler, args.workload)
         line["update_only"] = update_only(sampler)
         del moments, trace

@@ -248,6 +248,22 @@ def test_bench_n2_path_on_one_gpu(gpu):
 
 
 @pytest.mark.timeout(900)
+def test_bench_with_two_chains_per_gpu(gpu):
+    """``--chains-per-gpu 2``: every rank steps two independent chains concurrently (own stream + hipGraph each), `value`
+    counts all of them, and the one R-hat exchange covers ranks x 2 chains (local packs added before the collective)."""
+    d = _bench_n2(["--steps", "20", "--warmup", "5", "--chains-per-gpu", "2"])
+    assert d["n_gpus"] == 2 and d["config"]["chains"] == 4 and d["config"]["chains_per_gpu"] == 2
+    assert np.isclose(d["value"], 4 * 20 / (d["ms_per_step"] * 20 / 1e3), rtol=1e-3)
+    assert d["rccl"]["exchanges_timed"] == 1 and d["rhat"] is not None and d["rhat"]["max"] >= d["rhat"]["mean"] > 0
+    assert d["roofline"]["launches_timed"] == 5 and "2 chain(s) per GPU" in d["config"]["workload"]
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--chains-per-gpu", "2",
+                          "--no-update-only", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    one = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert one["n_gpus"] == 1 and one["config"]["chains"] == 2 and one["value"] > 0 and "rccl" not in one
+
+
+@pytest.mark.timeout(900)
 def test_bench_n2_driver_arguments_contain_one_exchange(gpu):
     """With the driver's arguments (20 steps, 5 warm-up, default cadences) the timed region is shorter than the R-hat
     period of configs[3]; exactly ONE exchange is then placed inside it (started after 2/3 of the steps, collected
