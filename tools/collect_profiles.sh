@@ -12,6 +12,7 @@ cp $O/bench_driver_cmd_a.json profiles/${R}_bench_driver_cmd_a.json
 cp $O/bench_driver_cmd_b.json profiles/${R}_bench_driver_cmd_b.json
 cp $O/bench_default.json profiles/${R}_bench_n1.json
 cp $O/bench_2000.json profiles/${R}_bench_2000.json
+cp $O/bench_2chains_per_gpu.json profiles/${R}_bench_2chains_per_gpu.json
 cp $O/bench_50m_sgld.json profiles/${R}_bench_50m_sgld.json
 cp $O/bench_50m_rsghmc.json profiles/${R}_bench_50m_rsghmc.json
 cp $O/bench_selflaunch_n2_gloo.json profiles/${R}_bench_selflaunch_n2_gloo.json

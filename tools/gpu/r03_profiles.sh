@@ -6,6 +6,7 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd_a.json 2> 
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd_b.json 2>> $O/bench.err
 python3 bench.py > $O/bench_default.json 2>> $O/bench.err
 python3 bench.py --steps 2000 --warmup 20 --no-cpu-baseline --no-update-only > $O/bench_2000.json 2>> $O/bench.err
+python3 bench.py --chains-per-gpu 2 --steps 200 --warmup 20 --no-cpu-baseline --no-update-only > $O/bench_2chains_per_gpu.json 2>> $O/bench.err
 python3 bench.py --workload bnn50m-sgld --steps 100 --warmup 10 > $O/bench_50m_sgld.json 2>> $O/bench.err
 python3 bench.py --workload bnn50m-rsghmc --steps 100 --warmup 10 > $O/bench_50m_rsghmc.json 2>> $O/bench.err
 # N > 1 started WITHOUT a launcher (all ranks on this box's one GPU over gloo: the code path, not xGMI timings)
