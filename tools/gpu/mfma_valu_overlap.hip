@@ -12,12 +12,20 @@
 #include <cstdio>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
+// KIND 0: v_mfma_f32_32x32x2_f32 (fp32 operands, 64 cycles); KIND 1: v_mfma_f32_32x32x8_bf16_1k (bf16 operands, 64 cycles too on
+// this part? -- measured below): does the answer depend on the operand type of the matrix instruction?
+template <int KIND>
 __device__ __forceinline__ void mfma_chain(int n, f32x16 &acc, float a, float b)
 {
+    const bf16x4 ah = {(short)__float_as_int(a), 0x3f80, 0x3f80, 0x3f80}, bh = {0x3f00, 0x3f00, 0x3f00, (short)__float_as_int(b)};
     for (int i = 0; i < n; ++i) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int k = 0; k < 8; ++k) {
+            if (KIND == 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah, bh, acc, 0, 0, 0);
+        }
     }
 }
 
@@ -34,6 +42,7 @@ __device__ __forceinline__ void valu_chain(int n, unsigned &x0, unsigned &x1, un
     }
 }
 
+template <int KIND>
 __global__ void __launch_bounds__(512, 2) probe(int mode, int n_mfma, int n_valu, float *out)
 {
     f32x16 acc;
@@ -43,13 +52,13 @@ __global__ void __launch_bounds__(512, 2) probe(int mode, int n_mfma, int n_valu
     const float a = 1.f + threadIdx.x * 1e-9f, b = 0.5f;
     const bool odd = (threadIdx.x >> 8) & 1;
     switch (mode) {
-    case 0: mfma_chain(n_mfma, acc, a, b); break;
+    case 0: mfma_chain<KIND>(n_mfma, acc, a, b); break;
     case 1: valu_chain(n_valu, x0, x1, x2, x3); break;
-    case 2: if (odd) mfma_chain(2 * n_mfma, acc, a, b); else valu_chain(2 * n_valu, x0, x1, x2, x3); break;
-    case 3: mfma_chain(n_mfma, acc, a, b); valu_chain(n_valu, x0, x1, x2, x3); break;
+    case 2: if (odd) mfma_chain<KIND>(2 * n_mfma, acc, a, b); else valu_chain(2 * n_valu, x0, x1, x2, x3); break;
+    case 3: mfma_chain<KIND>(n_mfma, acc, a, b); valu_chain(n_valu, x0, x1, x2, x3); break;
     case 4:
-        if (odd) { mfma_chain(n_mfma, acc, a, b); valu_chain(n_valu, x0, x1, x2, x3); }
-        else { valu_chain(n_valu, x0, x1, x2, x3); mfma_chain(n_mfma, acc, a, b); }
+        if (odd) { mfma_chain<KIND>(n_mfma, acc, a, b); valu_chain(n_valu, x0, x1, x2, x3); }
+        else { valu_chain(n_valu, x0, x1, x2, x3); mfma_chain<KIND>(n_mfma, acc, a, b); }
         break;
     }
     float s = (float)(x0 ^ x1 ^ x2 ^ x3);
@@ -58,24 +67,32 @@ __global__ void __launch_bounds__(512, 2) probe(int mode, int n_mfma, int n_valu
     if (s == 1.2345e33f) out[0] = s;
 }
 
-int main()
+template <int KIND>
+void run(const char *what, float *out)
 {
-    float *out;
-    hipMalloc(&out, 4);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int n_mfma = 64, n_valu = 48;
-    const char *names[5] = {"all MFMA", "all VALU", "half the workgroups MFMA x2, half VALU x2", "MFMA then VALU (lockstep)",
-                            "odd: MFMA then VALU, even: VALU then MFMA"};
+    const char *names[5] = {"all waves MFMA", "all waves VALU", "half of each SIMD's waves MFMA x2, the other half VALU x2",
+                            "every wave MFMA then VALU (lockstep)", "half MFMA then VALU, half VALU then MFMA (de-phased)"};
+    printf("-- %s\n", what);
     for (int mode = 0; mode < 5; ++mode) {
-        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(probe, dim3(512), dim3(512), 0, 0, mode, n_mfma, n_valu, out);
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(probe<KIND>, dim3(512), dim3(512), 0, 0, mode, n_mfma, n_valu, out);
         hipEventRecord(e0, 0);
-        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(probe, dim3(512), dim3(512), 0, 0, mode, n_mfma, n_valu, out);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(probe<KIND>, dim3(512), dim3(512), 0, 0, mode, n_mfma, n_valu, out);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         printf("mode %d (%s): %.1f us per launch\n", mode, names[mode], ms / 20 * 1e3);
     }
+}
+
+int main()
+{
+    float *out;
+    hipMalloc(&out, 4);
+    run<0>("v_mfma_f32_32x32x2_f32 (fp32 operands) next to Philox-like integer VALU work", out);
+    run<1>("v_mfma_f32_32x32x8_bf16_1k (bf16 operands) next to the same VALU work", out);
     return 0;
 }
