@@ -79,13 +79,16 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16x(const u16 *__restrict__ PA,
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64 * TNW;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32 * TNW;
     const size_t planeA = (size_t)(K / 8) * M * 8, planeB = (size_t)(K / 8) * N * 8;
+    // split-K: slice blockIdx.z of gridDim.z works on k in [z K / Z, (z + 1) K / Z) and writes its own partial C + z M N
+    const int kc0 = blockIdx.z * (K / (int)gridDim.z / BK);
+    C += (size_t)blockIdx.z * M * N;
     auto issue = [&](int kc, int st) {
 #pragma unroll
         for (int u = 0; u < PER_WAVE; ++u) {
             const int item = wave + 4 * u;                 // items 0 .. 3 KO - 1: A; then B in 64-column slabs
             if (item >= ITEMS) break;
             const int op = item / (3 * KO), part = (item / KO) % 3, ko = item % KO;
-            const int kog = kc * KO + ko;
+            const int kog = (kc0 + kc) * KO + ko;
             if (op == 0)
                 __builtin_amdgcn_global_load_lds(PA + part * planeA + ((size_t)kog * M + m0) * 8 + lane * 8, &lds.A[st][part][ko][0][0], 16, 0, 0);
             else
@@ -98,7 +101,7 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16x(const u16 *__restrict__ PA,
     for (int t = 0; t < TNW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accs[t][r] = 0.f; acc2s[t][r] = 0.f; }
-    const int nk = K / BK;
+    const int nk = K / (int)gridDim.z / BK;
     issue(0, 0);
     if (nk > 1) issue(1, 1);
     const int kh = lane >> 5, cl = lane & 31;
@@ -145,6 +148,16 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16x(const u16 *__restrict__ PA,
             if (STORE || v == 1.2345e33f) C[(size_t)row * N + n0 + wn + 32 * t + (lane & 31)] = v;
         }
 #endif
+}
+
+// C[i] = sum_z P[z][i] (in the product this sum would ride in the consumer: the bias + tanh launch)
+__global__ void sum_partials(const float *__restrict__ P, float *__restrict__ C, size_t n, int Z)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < Z; ++z) s += P[(size_t)z * n + i];
+    C[i] = s;
 }
 
 // references: one thread per output element, k-ordered chain
@@ -228,6 +241,43 @@ int main()
         RUN(32, 3, 9) RUN(32, 3, 9, true) RUN(32, 3, 6, true) RUN(16, 3, 9, true, true, 2) RUN(16, 3, 6, true, true, 2) RUN(16, 3, 9, true, false, 2) RUN(16, 4, 9, true, true, 2)
         printf("    splitting both operands into planes: %.1f us\n", time_us(split));
         hipFree(A); hipFree(B); hipFree(C); hipFree(D); hipFree(PA); hipFree(PB);
+    }
+    {
+        // the long-K shape of the forward / delta products: 256 x 2048 outputs, K = 2048 -> 128 tiles of 64 x 64, so the K range
+        // is split over blockIdx.z and the partial outputs are summed by a second launch (the consumer's job in a pipeline)
+        const int M = 256, N = 2048, KL = 2048;
+        float *A, *B, *C, *P;
+        double *D;
+        u16 *PA, *PB;
+        hipMalloc(&A, (size_t)KL * M * 4); hipMalloc(&B, (size_t)KL * N * 4); hipMalloc(&C, (size_t)M * N * 4);
+        hipMalloc(&P, (size_t)16 * M * N * 4); hipMalloc(&D, (size_t)M * N * 8);
+        hipMalloc(&PA, (size_t)3 * KL * M * 2); hipMalloc(&PB, (size_t)3 * KL * N * 2);
+        hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, A, (size_t)KL * M, 3u, 2.0f);      // activations
+        hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, B, (size_t)KL * N, 4u, 0.05f);     // weights
+        std::vector<float> c((size_t)M * N);
+        std::vector<double> ref((size_t)M * N);
+        hipLaunchKernelGGL(ref_tn<double>, dim3((N + 255) / 256, M), dim3(256), 0, 0, A, B, D, M, N, KL);
+        hipMemcpy(ref.data(), D, ref.size() * 8, hipMemcpyDeviceToHost);
+        printf("M=%d N=%d K=%d (operands stored k-major like above; the planes do not care)\n", M, N, KL);
+        hipLaunchKernelGGL(ref_tn<float>, dim3((N + 255) / 256, M), dim3(256), 0, 0, A, B, C, M, N, KL);
+        hipMemcpy(c.data(), C, c.size() * 4, hipMemcpyDeviceToHost);
+        errors("fp32 fmaf chain in k order (= fp32 MFMA)", c, ref);
+        hipLaunchKernelGGL(split_planes, dim3((unsigned)(((size_t)(KL / 8) * M + 255) / 256)), dim3(256), 0, 0, A, PA, KL, M);
+        hipLaunchKernelGGL(split_planes, dim3((unsigned)(((size_t)(KL / 8) * N + 255) / 256)), dim3(256), 0, 0, B, PB, KL, N);
+#define RUNZ(BK, NS, TERMS, Z, TNWV)                                                                                          \
+        {                                                                                                                     \
+            const dim3 grid(N / 64 / TNWV, M / 64, Z);                                                                        \
+            auto g = [&] { hipLaunchKernelGGL((gemm_tn_bf16x<BK, NS, TERMS, true, true, TNWV>), grid, dim3(256), 0, 0, PA, PB, P, M, N, KL); }; \
+            auto r = [&] { hipLaunchKernelGGL(sum_partials, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, 0, P, C, (size_t)M * N, Z); }; \
+            g(); r();                                                                                                         \
+            hipMemcpy(c.data(), C, c.size() * 4, hipMemcpyDeviceToHost);                                                      \
+            char what[96];                                                                                                    \
+            snprintf(what, sizeof what, "bf16 x %d, BK %d, ring %d, split-K %d, %d tiles/wave", TERMS, BK, NS, Z, TNWV);      \
+            errors(what, c, ref);                                                                                             \
+            printf("        product %.1f us + sum of the %d partials %.1f us\n", time_us(g), Z, time_us(r));                  \
+        }
+        RUNZ(32, 3, 9, 8, 1) RUNZ(32, 3, 6, 8, 1) RUNZ(32, 3, 6, 4, 1) RUNZ(16, 3, 6, 8, 2) RUNZ(16, 3, 6, 16, 2) RUNZ(16, 3, 9, 8, 2) RUNZ(32, 3, 6, 2, 1)
+        hipFree(A); hipFree(B); hipFree(C); hipFree(P); hipFree(D); hipFree(PA); hipFree(PB);
     }
     return 0;
 }
