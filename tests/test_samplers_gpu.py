@@ -495,6 +495,37 @@ def test_concurrent_chains_on_one_gpu_equal_the_chains_alone(gpu):
         ConcurrentChains([])
 
 
+def test_concurrent_chains_of_different_sampler_classes(gpu):
+    """Chains of different samplers and dtypes (SGHMC f32 graph, SGLD f64 eager, relativistic SGHMC f32 full-graph) stepped as
+    one ``ConcurrentChains`` group equal the chains alone; ``steps()`` = fork + run + join."""
+    from pysgmcmc_amd.samplers import ConcurrentChains, RelativisticSGHMCSampler, SGLDSampler
+
+    def make():
+        cost = lambda p: 0.5 * (p[0] ** 2).sum() + 0.25 * (p[0] ** 4).sum()
+        a = SGHMCSampler(params=[torch.linspace(-1, 1, 5003, device=gpu)], cost_fun=cost, burn_in_steps=6, session=gpu,
+                         dtype=torch.float32, seed=1)
+        b = SGLDSampler(params=[torch.linspace(-2, 2, 777, device=gpu, dtype=torch.float64)], cost_fun=cost, burn_in_steps=4,
+                        session=gpu, dtype=torch.float64, seed=2)
+        c = RelativisticSGHMCSampler(params=[torch.linspace(-1, 1, 1024, device=gpu)], cost_fun=cost, session=gpu,
+                                     dtype=torch.float32, seed=3)
+        for s, mode in ((a, True), (b, False), (c, "full")):
+            s.sample_format = "view"
+            s.use_hip_graph = mode
+        return [a, b, c]
+    alone = make()
+    for s in alone:
+        for _ in range(15):
+            next(s)
+    group = ConcurrentChains(make())
+    group.steps(7)
+    snapshot = [s.arena.row("theta").clone() for s in group.samplers]        # on the caller's stream, after the join
+    group.steps(8)                                                            # fork: the chains wait for the clones
+    torch.cuda.synchronize()
+    for s, ref, snap in zip(group.samplers, alone, snapshot):
+        assert torch.equal(s.arena.row("theta"), ref.arena.row("theta")) and s.n_iterations == 15
+        assert not torch.equal(snap, s.arena.row("theta")) and torch.isfinite(snap).all()
+
+
 def test_rhat_of_chains_that_share_a_gpu(gpu):
     """``RhatExchange.start([moments, ...])`` with no process group: R-hat over the local chains (fused Welford moments of
     ``ConcurrentChains``) equals the formula on the chains' explicit samples."""
