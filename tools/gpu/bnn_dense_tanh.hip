@@ -1,0 +1,384 @@
+// bnn_dense_tanh.hip -- EXPERIMENT (round 4), not part of libsgmcmc_hip.so: one hidden layer of the BNN
+// forward pass (pysgmcmc/models/bayesian_neural_network.py:30-52) as a hand-written fp32 matrix-core product with bias + tanh
+// (and optionally the single output unit's dot product) as its epilogue, against library GEMM + sgmcmc_bias_tanh_f32.
+// Result (profiles/r04_fwd_epilogue_probe.txt): correct to fp32 rounding, but at M = 256, K = N = 2048 it only TIES
+// library GEMM + bias_tanh (21.4 vs 21.1 us), +2.0 us on the K = 784 layer, +3.3 us over the whole forward pass -- below the
+// gate of 3 us per product, so the cost path keeps the library products. Build: make -C tools/gpu; run: tools/fwd_fused_probe.py.
+//
+//   forward:   out[m][n] = tanh( sum_k h[m][k] W[k][n] + b[n] )            h [M = batch][K], W [K][N] row-major
+//              (+ optionally dot_parts[t][m] = sum_{n in column tile t} out[m][n] w_next[n], the single output unit)
+//
+// Decomposition for M = 256: the output is 512 MFMA tiles of 32 x 32 for 1024 SIMDs, so K must be split; a workgroup (ONE per
+// CU, 8 waves = 2 per SIMD) owns a 32 x 64 output tile = 2 MFMA tiles x 4 quarters of every 64-deep K chunk and adds the
+// quarters through LDS in a fixed order before the epilogue -- the sums are complete inside the workgroup, which is what lets
+// the activation ride in the launch. Operands go from global memory DIRECTLY into LDS (global_load_lds_dwordx4) into a ring of
+// NS stages (A 32 x 64, B 64 x 64 floats = 24 KB), NS - 2 chunks in flight across bare s_barriers with counted vmcnt waits;
+// the fragments of chunk c + 1 are read from LDS while the MFMAs of chunk c issue.
+//   A (k contiguous in memory): LDS image [m][64 k], 16-byte quads XOR-swizzled with m & 15 -- applied to the per-lane
+//     GLOBAL address, the LDS side of a direct load is lane-linear -- so that ds_read_b128 of 4 k values per lane is
+//     conflict-free; a lane's 8 k values feed 8 MFMAs (the k order inside a chunk is permuted, a sum over k does not care).
+//   B (n contiguous): LDS image [k][64 n], one ds_read_b32 per MFMA, 32 consecutive lanes = 32 consecutive banks.
+// Workgroup -> tile map is XCD-aware (workgroup b runs on XCD b % 8): every XCD owns a contiguous range of column tiles, so
+// each slice of W is pulled into exactly one XCD's L2.
+// What was measured on the way (all at 256 x 2048 x 2048, us per launch in a hipGraph of 20):
+//   * 4 waves (one per SIMD), loads + reads bunched after the 2nd MFMA: 28.3; spread between the MFMAs: 29.5; 4 extra loader
+//     waves: 29.8 -- an in-order wave alone on its SIMD leaves the matrix pipe idle for everything it issues beyond 64 cycles;
+//   * 8 waves (two per SIMD): 24.7; de-phasing the pair (loads after the 2nd / 5th MFMA): 24.6 (no gain);
+//   * per-lane 64-bit address arithmetic replaced by scalar bases + a constant 32-bit lane offset, ring stages as
+//     compile-time constants: 21.4-23.8 depending on the operand DATA (the chip clocks to its power budget);
+//   * operands staged through registers (global_load_dwordx4 four chunks ahead + ds_write_b128) instead of direct loads: 23.6,
+//     the same; the K loop with no loads at all (MFMAs on whatever LDS holds): 17.1; the loads alone: 9.8;
+//   * library product alone: 17.9-18.9; + bias_tanh: 21.1-21.6.
+//
+// fp32 MFMA is an exact fmaf chain (MI355X_MICROARCH.md): the product differs from a library GEMM in summation order only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 32, BN = 64;
+constexpr int TP = BN + 4;                                  // pitch of the accumulator tiles in LDS (floats)
+
+// s_waitcnt immediate on gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14; expcnt/lgkmcnt = no wait
+constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm()
+{
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(N));
+}
+
+// at most `chunks` chunks (3 direct loads per wave each) may still be in flight
+template <int MAXC>
+__device__ __forceinline__ void wait_chunks_in_flight(int chunks)
+{
+    if constexpr (MAXC == 0) {
+        wait_vm<0>();
+    } else {
+        if (chunks >= MAXC) wait_vm<3 * MAXC>();
+        else wait_chunks_in_flight<MAXC - 1>(chunks);
+    }
+}
+
+struct FwdArgs {
+    const float *h, *W, *bias;
+    float *out;
+    const float *w_next;        // nullable
+    float *dot_parts;           // [N / 64][M]
+    int M, N, K, ldh, ldw, ldo;
+};
+
+__device__ __forceinline__ float tanh_f32(float x) { return tanhf(x); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// sum over the 16 lanes of a DPP row; the total arrives in the row's lane 15 (fixed order)
+__device__ __forceinline__ float row16_sum_lane15(float v)
+{
+    v += dpp_mov<0x111>(v);     // row_shr:1
+    v += dpp_mov<0x112>(v);     // row_shr:2
+    v += dpp_mov<0x114>(v);     // row_shr:4
+    v += dpp_mov<0x118>(v);     // row_shr:8
+    return v;
+}
+
+// PROBE (timing experiments, compile-time): bit 0 = no MFMAs, bit 1 = no direct loads
+// 8 waves = 2 per SIMD: (column half nt) x (quarter kq of every 64-deep K chunk). A wave issues in order, so whatever it
+// issues between two MFMAs (direct loads, LDS reads, address arithmetic) beyond the 64 cycles the previous MFMA covers is
+// idle time of the matrix pipe -- unless a second wave on the SIMD has MFMAs to issue meanwhile. (One wave per SIMD with the
+// other work bunched after the second MFMA: 50 % MFMA utilisation, 66 % with the loads taken out, SQ counters.)
+constexpr int BK = 64;
+constexpr int KQ = 4;                                       // K quarters of a chunk = partial tiles the epilogue adds
+
+template <int NS>
+struct __attribute__((aligned(16))) FwdLds {
+    union {
+        struct {
+            float A[NS][BM][BK];
+            float B[NS][BK][BN];
+        } ring;
+        float T[KQ][BM][TP];
+    };
+};
+
+template <int NS, int PROBE>
+__global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
+{
+    static_assert(NS >= 4 && NS % 2 == 0, "ring: one chunk being read, one landing, one free; unrolled by NS with two fragment sets");
+    constexpr int D = NS - 1;                               // chunk kc + D is requested in iteration kc
+    constexpr bool NO_MFMA = PROBE & 1, NO_LOAD = PROBE & 2, REGSTAGE = PROBE & 8;
+    __shared__ FwdLds<NS> lds;
+    static_assert(sizeof(lds.ring) >= sizeof(lds.T), "the accumulator tiles reuse the ring");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = wave & 1, kq = wave >> 1;                // this wave's MFMA tile (columns 32 nt ...) and quarter of every chunk
+    // ---- workgroup -> tile, XCD-aware: XCD x owns tiles [x T/8, (x+1) T/8), consecutive tiles share the column tile
+    const int tiles_m = g.M / BM, tiles = tiles_m * (g.N / BN);
+    int t = blockIdx.x;
+    if (tiles % 8 == 0) t = (t & 7) * (tiles >> 3) + (t >> 3);
+    const int n0 = (t / tiles_m) * BN, m0 = (t % tiles_m) * BM;
+    const int nk = (g.K + BK - 1) / BK;                     // K % 16 == 0: the last chunk may hold 16, 32 or 48 valid k only
+    // ---- direct loads: wave w requests 4 rows of A (256 B each) and 2 x 4 rows of B per chunk. The global source of a lane is
+    // (wave-uniform base, advanced by SCALAR arithmetic) + (a 32-bit per-lane byte offset that never changes): on gfx950 fp32
+    // MFMA and vector-ALU instructions share the SIMD's lanes, so every VALU instruction in this loop is MFMA time lost
+    // (address arithmetic per lane cost 4.5 us of a 22.8 us launch). The LDS side is lane-linear.
+    const int ar = 4 * wave + (lane >> 4);                  // A row of this lane's 16 bytes
+    const int aq = (lane & 15) ^ (ar & 15);                 // logical quad stored at physical slot lane & 15
+    const int br = 8 * wave + (lane >> 4);                  // B rows br, br + 4
+    const unsigned a_lane = (unsigned)(ar * g.ldh + 4 * aq) * 4u;
+    const unsigned b_lane = (unsigned)(br * g.ldw + 4 * (lane & 15)) * 4u;
+    const char *a_base = reinterpret_cast<const char *>(g.h + (size_t)m0 * g.ldh);
+    const char *b_base = reinterpret_cast<const char *>(g.W + n0);
+    const size_t b_chunk = (size_t)BK * g.ldw * 4, b_rows4 = (size_t)4 * g.ldw * 4;
+    auto issue = [&](int kc, int st) {                      // chunks that lie wholly below K
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (NO_LOAD) return;
+        const char *pa = a_base + (size_t)kc * (BK * 4);
+        const char *pb = b_base + (size_t)kc * b_chunk;
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(pa + a_lane), &lds.ring.A[st][4 * wave][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(pb + b_lane), &lds.ring.B[st][8 * wave][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(pb + b_rows4 + b_lane), &lds.ring.B[st][8 * wave + 4][0], 16, 0, 0);
+#endif
+    };
+    auto issue_clamped = [&](int kc, int st) {              // the last chunk: beyond K any valid address will do (values never used)
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (NO_LOAD) return;
+        int ka = kc * BK + 4 * aq, kb0 = kc * BK + br, kb1 = kc * BK + br + 4;
+        if (ka + 4 > g.K) ka = g.K - 4;
+        if (kb0 >= g.K) kb0 = g.K - 1;
+        if (kb1 >= g.K) kb1 = g.K - 1;
+        __builtin_amdgcn_global_load_lds(g.h + (size_t)(m0 + ar) * g.ldh + ka, &lds.ring.A[st][4 * wave][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g.W + (size_t)kb0 * g.ldw + n0 + 4 * (lane & 15), &lds.ring.B[st][8 * wave][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g.W + (size_t)kb1 * g.ldw + n0 + 4 * (lane & 15), &lds.ring.B[st][8 * wave + 4][0], 16, 0, 0);
+#endif
+    };
+    // ---- fragment addresses
+    const int fm = lane & 31, kl = lane >> 5;
+    const int sw = fm & 15;
+    const int aoff0 = fm * BK + 4 * ((4 * kq + 2 * kl) ^ sw), aoff1 = fm * BK + 4 * ((4 * kq + 2 * kl + 1) ^ sw);
+    const int boff = (16 * kq + 8 * kl) * BN + 32 * nt + fm;
+    struct Frag {
+        f32x4_t a0, a1;
+        float b[8];
+    };
+    auto read_frags = [&](int st, Frag &f) {
+        const float *A = &lds.ring.A[st][0][0];
+        const float *B = &lds.ring.B[st][0][0];
+        f.a0 = *reinterpret_cast<const f32x4_t *>(A + aoff0);
+        f.a1 = *reinterpret_cast<const f32x4_t *>(A + aoff1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.b[j] = B[boff + j * BN];
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    // a chunk's 8 MFMAs alternate between two accumulators (added in the epilogue): consecutive MFMAs are independent
+    auto mfmas = [&](const Frag &f, int j0, int j1) {
+        if (NO_MFMA) return;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j >= j0 && j < j1) {
+                const float a = j < 4 ? f.a0[j & 3] : f.a1[j & 3];
+                if (!(j & 1)) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f.b[j], acc0, 0, 0, 0);
+                else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f.b[j], acc1, 0, 0, 0);
+            }
+    };
+    Frag fa, fb;
+    if constexpr (REGSTAGE) {
+        // ---- operands through registers (what the library's kernel does): global_load_dwordx4 four chunks ahead into three
+        // register sets, ds_write_b128 two chunks ahead into a ring of three stages (the LDS image of the direct loads)
+        struct Regs { f32x4_t a, b0, b1; };
+        auto load = [&](int c, Regs &r) {
+            if (c > nk - 1) c = nk - 1;                     // past the end: re-read the last chunk (never consumed)
+            const char *pa = a_base + (size_t)c * (BK * 4);
+            const char *pb = b_base + (size_t)c * b_chunk;
+            r.a = *reinterpret_cast<const f32x4_t *>(pa + a_lane);
+            r.b0 = *reinterpret_cast<const f32x4_t *>(pb + b_lane);
+            r.b1 = *reinterpret_cast<const f32x4_t *>(pb + b_rows4 + b_lane);
+        };
+        auto stash = [&](int st, const Regs &r) {
+            *reinterpret_cast<f32x4_t *>(&lds.ring.A[st][4 * wave][0] + 4 * lane) = r.a;
+            *reinterpret_cast<f32x4_t *>(&lds.ring.B[st][8 * wave][0] + 4 * lane) = r.b0;
+            *reinterpret_cast<f32x4_t *>(&lds.ring.B[st][8 * wave + 4][0] + 4 * lane) = r.b1;
+        };
+        Regs r0, r1, r2;
+        load(0, r0);
+        load(1, r1);
+        stash(0, r0);
+        stash(1, r1);
+        load(2, r2);
+        load(3, r0);
+        __syncthreads();
+        read_frags(0, fa);
+        auto it = [&](int kc, const Frag &cur, Frag &nxt, Regs &r_issue, const Regs &r_write, auto stage) {
+            constexpr int I = decltype(stage)::value;       // kc % 3
+            __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): this wave's ds_writes of chunk kc + 1 are in LDS ...
+            __builtin_amdgcn_s_barrier();                   // ... and everybody's: chunk kc + 1 is visible; the stage of chunk kc - 1 is free
+            mfmas(cur, 0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            load(kc + 4, r_issue);
+            read_frags((I + 1) % 3, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(cur, 2, 5);
+            __builtin_amdgcn_sched_barrier(0);
+            stash((I + 2) % 3, r_write);                    // chunk kc + 2, requested two iterations ago
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(cur, 5, 8);
+        };
+        typedef std::integral_constant<int, 0> S0;
+        typedef std::integral_constant<int, 1> S1;
+        typedef std::integral_constant<int, 2> S2;
+        int kc = 0;
+        for (; kc + 6 < nk; kc += 6) {                      // chunk c lives in register set c % 3, stage c % 3, fragments c % 2
+            it(kc, fa, fb, r1, r2, S0());
+            it(kc + 1, fb, fa, r2, r0, S1());
+            it(kc + 2, fa, fb, r0, r1, S2());
+            it(kc + 3, fb, fa, r1, r2, S0());
+            it(kc + 4, fa, fb, r2, r0, S1());
+            it(kc + 5, fb, fa, r0, r1, S2());
+        }
+        // up to six more iterations, the same sequence cut short
+        if (kc + 1 < nk) { it(kc, fa, fb, r1, r2, S0()); ++kc;
+            if (kc + 1 < nk) { it(kc, fb, fa, r2, r0, S1()); ++kc;
+                if (kc + 1 < nk) { it(kc, fa, fb, r0, r1, S2()); ++kc;
+                    if (kc + 1 < nk) { it(kc, fb, fa, r1, r2, S0()); ++kc;
+                        if (kc + 1 < nk) { it(kc, fa, fb, r2, r0, S1()); ++kc; fa = fb; }
+                    } else fa = fb;
+                }
+            } else fa = fb;
+        }
+    } else {
+    // ---- prologue: chunks 0 .. D - 1 requested, chunk 0 landed and read
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+        if (c < nk) issue_clamped(c, c);
+    if (!NO_LOAD) wait_chunks_in_flight<D - 1>(nk - 1);
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, fa);
+    // One iteration: chunk kc + 1 is waited for and read from LDS (into the other fragment set) while the MFMAs of chunk kc
+    // issue. The steady state is unrolled by NS: ring stages are compile-time constants (LDS addresses = a per-lane register
+    // + an immediate, M0 = a constant) and the two fragment sets swap roles without register copies.
+    auto steady = [&](int kc, const Frag &cur, Frag &nxt, auto stage) {
+        constexpr int I = decltype(stage)::value;           // kc % NS
+        if (!NO_LOAD) wait_vm<3 * (D - 2)>();               // chunk kc + 1 landed: chunks kc + 2 .. kc + D - 1 may be in flight
+        __builtin_amdgcn_s_barrier();                       // ... for every wave; and the stage of chunk kc - 1 is free
+        mfmas(cur, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(kc + D, (I + D) % NS);
+        read_frags((I + 1) % NS, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(cur, 2, 8);
+    };
+    int kc = 0;
+    for (; kc + D + NS < nk; kc += NS) {                    // every chunk requested here (up to kc + NS - 1 + D) lies wholly below K
+        steady(kc, fa, fb, std::integral_constant<int, 0>());
+        steady(kc + 1, fb, fa, std::integral_constant<int, 1>());
+        steady(kc + 2, fa, fb, std::integral_constant<int, 2>());
+        steady(kc + 3, fb, fa, std::integral_constant<int, 3>());
+        if constexpr (NS == 6) {
+            steady(kc + 4, fa, fb, std::integral_constant<int, 4>());
+            steady(kc + 5, fb, fa, std::integral_constant<int, 5>());
+        }
+    }
+    int st_read = 1, st_issue = D % NS;                     // kc % NS == 0 here: stage of chunk kc + 1, stage of chunk kc + D
+    for (; kc + 1 < nk; ++kc) {                             // the last chunks: counted waits, the (possibly short) last chunk requested
+        if (!NO_LOAD) wait_chunks_in_flight<D - 2>(nk - 2 - kc);
+        __builtin_amdgcn_s_barrier();
+        mfmas(fa, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kc + D < nk) issue_clamped(kc + D, st_issue);
+        read_frags(st_read, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fa, 2, 8);
+        fa = fb;
+        st_read = st_read + 1 == NS ? 0 : st_read + 1;
+        st_issue = st_issue + 1 == NS ? 0 : st_issue + 1;
+    }
+    }
+    // last chunk: only the quarters that lie below K exist
+    if ((nk - 1) * BK + 16 * kq < g.K) mfmas(fa, 0, 8);
+    // ---- epilogue: the four K quarters meet in LDS (fixed order), bias + tanh on row-major quads, 16-byte stores
+    __syncthreads();                                        // every fragment read is done: the ring is free
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds.T[kq][(r & 3) + 8 * (r >> 2) + 4 * kl][32 * nt + fm] = acc0[r] + acc1[r];
+    __syncthreads();
+    {
+        const int row = tid >> 4, c4 = (tid & 15) * 4;
+        f32x4_t s = *reinterpret_cast<const f32x4_t *>(&lds.T[0][row][c4]);
+#pragma unroll
+        for (int p = 1; p < KQ; ++p) {
+            const f32x4_t sp = *reinterpret_cast<const f32x4_t *>(&lds.T[p][row][c4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += sp[j];
+        }
+        const f32x4_t b = *reinterpret_cast<const f32x4_t *>(g.bias + n0 + c4);
+        f32x4_t v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = tanh_f32(s[j] + b[j]);
+        *reinterpret_cast<f32x4_t *>(g.out + (size_t)(m0 + row) * g.ldo + n0 + c4) = v;
+        if (g.w_next != nullptr) {
+            const f32x4_t w = *reinterpret_cast<const f32x4_t *>(g.w_next + n0 + c4);
+            float d = ((v[0] * w[0] + v[1] * w[1]) + v[2] * w[2]) + v[3] * w[3];
+            d = row16_sum_lane15(d);                        // the 16 lanes of a DPP row hold one tile row
+            if ((lane & 15) == 15) g.dot_parts[(size_t)(n0 / BN) * g.M + m0 + row] = d;
+        }
+    }
+}
+
+template <int NS, int PROBE = 0>
+int launch_fwd(const FwdArgs &g, hipStream_t st)
+{
+    const int tiles = (g.M / BM) * (g.N / BN);
+    hipLaunchKernelGGL((bnn_dense_tanh_kernel<NS, PROBE>), dim3(tiles), dim3(512), 0, st, g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* returns 0, -1 (bad arguments) or a hipError_t */
+int bnn_dense_tanh_probe_f32(const float *h, const float *W, const float *bias, float *out, int M, int N, int K, int ldh,
+                              int ldw, int ldo, const float *w_next, float *dot_parts, void *stream)
+{
+    if (!h || !W || !bias || !out || ((w_next != nullptr) != (dot_parts != nullptr)))
+        return -1;
+    if (M <= 0 || N <= 0 || K < 64 || M % BM || N % BN || K % 16 || ldh < K || ldw < N || ldo < N || ldh % 4 || ldw % 4 || ldo % 4 ||
+        ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(bias) |
+          reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(w_next)) & 15u))
+        return -1;
+    FwdArgs g{h, W, bias, out, w_next, dot_parts, M, N, K, ldh, ldw, ldo};
+    if (const char *e = getenv("BNN_DENSE_TANH_PROBE")) {
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        switch (atoi(e)) {
+        case 1: return launch_fwd<4, 1>(g, st);
+        case 2: return launch_fwd<4, 2>(g, st);
+        case 3: return launch_fwd<4, 3>(g, st);
+        case 10: return launch_fwd<6, 0>(g, st);
+        case 8: return launch_fwd<4, 8>(g, st);
+        case 9: return launch_fwd<4, 9>(g, st);
+        default: break;
+        }
+    }
+    // ring depth: with at most one tile per CU the launch is one wave of workgroups and a deep ring (84 KB: also keeps the
+    // dispatcher from packing two workgroups on one CU) hides the L2 / HBM latency; bigger grids run 2-3 workgroups per CU
+    const int tiles = (M / BM) * (N / BN);
+    (void)tiles;
+    return launch_fwd<4>(g, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"
