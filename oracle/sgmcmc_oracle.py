@@ -653,10 +653,12 @@ def svgd_kernel(X):
     n = X.shape[0]
     D = svgd_pairwise_sqdist(X)
     h = np.sqrt(T(0.5) * svgd_median(D) / np.log(T(n) + T(1.0)))       # :169-171
-    K = np.exp(-D / (h * h) / T(2))                                     # :173
+    with np.errstate(divide="ignore", invalid="ignore"):                # one particle: h = 0 and 0 / 0 = nan, as in the reference
+        K = np.exp(-D / (h * h) / T(2))                                 # :173
     ksum = np.sum(K, axis=1, dtype=X.dtype)                             # :174
     kgrad = -(K @ X) + X * ksum[:, None]                                # :176-179
-    return K, kgrad / (h * h), h, D                                     # :181
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return K, kgrad / (h * h), h, D                                 # :181
 
 
 def svgd_step(X, G, hist, eps, alpha=0.9, fudge=1e-6, repulsion_sign=1.0):

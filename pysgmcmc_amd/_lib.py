@@ -26,7 +26,7 @@ def lib_path():
 def build(force=False):
     """Compile ``csrc/libsgmcmc_hip.so`` for gfx950 with hipcc (no GPU needed)."""
     import subprocess
-    deps = [os.path.join(_CSRC, f) for f in ("sgmcmc_kernels.hip", "sgmcmc_sghmc.hip", "sgmcmc_sgld.hip", "sgmcmc_rsghmc.hip", "sgmcmc_toy.hip", "sgmcmc_gemm.hip", "sgmcmc_stream.hpp", "sgmcmc_bnn_fused.hip", "sgmcmc_svgd.hip", "sgmcmc_device.hpp",
+    deps = [os.path.join(_CSRC, f) for f in ("sgmcmc_kernels.hip", "sgmcmc_sghmc.hip", "sgmcmc_sgld.hip", "sgmcmc_rsghmc.hip", "sgmcmc_toy.hip", "sgmcmc_stream.hpp", "sgmcmc_bnn_fused.hip", "sgmcmc_svgd.hip", "sgmcmc_device.hpp",
                                              "sgmcmc_host.hpp")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "sgmcmc_hip.h"))
     stale = (not os.path.exists(_LIB_PATH)
@@ -37,7 +37,7 @@ def build(force=False):
 
 
 _lib = None
-ABI_VERSION = 3               # SGMCMC_ABI_VERSION of include/sgmcmc_hip.h
+ABI_VERSION = 4               # SGMCMC_ABI_VERSION of include/sgmcmc_hip.h
 
 _u64 = ctypes.c_uint64
 _sz = ctypes.c_size_t
@@ -159,13 +159,6 @@ def _declare(lib):
         f = getattr(lib, "sgmcmc_summary_" + sfx)
         f.argtypes = [_vp, _sz, _vp, _vp, _vp]
         f.restype = _ci
-    lib.sgmcmc_gemm_tn_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp]
-    lib.sgmcmc_gemm_tn_f32.restype = _ci
-    lib.sgmcmc_gemm_tn_sghmc_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _sz, _vp] + [ctypes.c_float] * 4 + [
-        _u64, _u64, _vp, _u64, _vp, ctypes.c_uint32, ctypes.c_uint32, _ci, _vp, _ci, _vp]
-    lib.sgmcmc_gemm_tn_sghmc_f32.restype = _ci
-    lib.sgmcmc_gemm_tn_sghmc_blocks.argtypes = [_ci, _ci, _sz, _ci]
-    lib.sgmcmc_gemm_tn_sghmc_blocks.restype = _ci
     lib.sgmcmc_philox_bits_u32.argtypes = [_vp, _sz, _u64, _u64, _vp, _vp]
     lib.sgmcmc_counter_add_u64.argtypes = [_vp, _u64, _vp]
     lib.sgmcmc_counter_add_u64.restype = _ci

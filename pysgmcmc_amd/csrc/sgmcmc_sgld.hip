@@ -51,7 +51,9 @@ int sgld_step(T *theta, const T *grad, T *tau, T *g, T *v_hat, T *minv, T *r, si
 #undef SGLD_GO
     if (rc == 0 && se.want_moments && !mom_done) {
         MomentsOp<T> mop{theta, se.ex.mom_mean, se.ex.mom_m2, se.ex.mom_inv};
-        rc = launch(mop, n, aligned16(theta) && aligned16(se.ex.mom_mean) && aligned16(se.ex.mom_m2), 5 * sizeof(T), lc, st);
+        sgmcmc_launch_t lc_mom = lc ? *lc : sgmcmc_launch_t{};      // same geometry, but NOT the caller's timestamp events: they
+        lc_mom.start_event = lc_mom.stop_event = nullptr;           // belong to the step kernel above
+        rc = launch(mop, n, aligned16(theta) && aligned16(se.ex.mom_mean) && aligned16(se.ex.mom_m2), 5 * sizeof(T), lc ? &lc_mom : nullptr, st);
     }
     return rc;
 }

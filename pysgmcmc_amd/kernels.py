@@ -15,7 +15,7 @@ from pysgmcmc_amd._lib import SgmcmcLibraryError, check, lib
 __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
-    "LaunchConfig", "KernelEvents", "StepOpts", "step_stats_records", "step_scalars", "toy_chains", "gemm_tn", "gemm_tn_sghmc", "gemm_tn_sghmc_blocks", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
+    "LaunchConfig", "KernelEvents", "StepOpts", "step_stats_records", "step_scalars", "toy_chains", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
     "bnn_fused_sgld_steps", "window_gather", "tanh_rowdot", "bias_tanh", "bnn_head_last_layer_backward", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
 ]
 
@@ -306,48 +306,6 @@ def toy_chains(sampler, target, target_params, theta, mom, tau, g, v_hat, minv, 
                int(burn_in_steps), int(keep_every), _ptr(kept), _stream(theta))
     check(rc, "sgmcmc_toy_chains")
     return kept
-
-
-def gemm_tn(a, b, out, variant=0, phase_counters=None, phase_sleep=0):
-    """``out[M, N] = a[K, M]^T @ b[K, N]`` (fp32, matrix cores): the weight-gradient product of a dense layer."""
-    K, M = a.shape
-    N = b.shape[1]
-    if a.dtype != torch.float32 or b.dtype != torch.float32 or out.dtype != torch.float32:
-        raise TypeError("gemm_tn is fp32")
-    if b.shape[0] != K or tuple(out.shape) != (M, N) or a.stride(1) != 1 or b.stride(1) != 1 or out.stride(1) != 1:
-        raise ValueError("gemm_tn: shapes / strides do not match")
-    with _on(a):
-        rc = lib().sgmcmc_gemm_tn_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
-                                      int(variant), _ptr(phase_counters), int(phase_sleep), _stream(a))
-    check(rc, "sgmcmc_gemm_tn_f32")
-    return out
-
-
-def gemm_tn_sghmc(a, b, theta, V, minv, grad_tail, eps, scale_grad, mdecay, grad_decay=0.0, seed=0, step=0, step_dev=None,
-                  first_element=0, stats=None, stats_base=0, stats_total=0, grad_out=None, gemm_blocks=0,
-                  phase_counters=None, phase_sleeps=0):
-    """Weight-gradient product ``a[K, M]^T @ b[K, N]`` with the frozen SGHMC update of the layer as its epilogue
-    (``sgmcmc_gemm_tn_sghmc_f32``). ``theta`` / ``V`` / ``minv``: the layer's slice of the arena rows -- the ``M * N``
-    weights followed by ``grad_tail.numel()`` more parameters whose gradient ``grad_tail`` already holds."""
-    K, M = a.shape
-    N = b.shape[1]
-    n_tail = 0 if grad_tail is None else grad_tail.numel()
-    for t in (a, b, theta, V, minv):
-        if t.dtype != torch.float32:
-            raise TypeError("gemm_tn_sghmc is fp32")
-    if b.shape[0] != K or a.stride(1) != 1 or b.stride(1) != 1 or theta.numel() != M * N + n_tail:
-        raise ValueError("gemm_tn_sghmc: shapes / strides do not match")
-    with _on(a):
-        rc = lib().sgmcmc_gemm_tn_sghmc_f32(
-            a.data_ptr(), b.data_ptr(), M, N, K, a.stride(0), b.stride(0), _ptr(theta), _ptr(V, theta), _ptr(minv, theta),
-            _ptr(grad_tail), n_tail, _ptr(grad_out), float(eps), float(scale_grad), float(mdecay), float(grad_decay),
-            int(seed), int(step), _ctr(step_dev), int(first_element), None if stats is None else _ptr(stats.workspace),
-            int(stats_base), int(stats_total), int(gemm_blocks), _ptr(phase_counters), int(phase_sleeps), _stream(a))
-    check(rc, "sgmcmc_gemm_tn_sghmc_f32")
-
-
-def gemm_tn_sghmc_blocks(M, N, n_tail, gemm_blocks=0):
-    return int(lib().sgmcmc_gemm_tn_sghmc_blocks(int(M), int(N), int(n_tail), int(gemm_blocks)))
 
 
 def philox_normal(out, seed, step, step_dev=None, launch=None):

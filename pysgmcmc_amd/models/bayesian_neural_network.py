@@ -186,9 +186,6 @@ class BNNCost(object):
         self.fuse_tanh_rowdot = True                      # measured 228.2 vs 231.3 us per step at 10 M parameters
         # loss head folded into the single-output layer's backward launch (every dependent launch of the step costs ~5 us)
         self.fuse_head = True
-        # weight-gradient products gW = h^T delta: "blas" (rocBLAS / hipBLASLt through torch) or "mfma" (kernels.gemm_tn, the
-        # product the fused GEMM + update kernel forms: same bits as that kernel's gradient)
-        self.gw_gemm = "blas"
         # (Forking the weight-gradient GEMMs onto a second stream inside the captured graph was measured
         # on MI355X at batch 256: 291 us/step vs 275 us on one stream -- not kept.)
 
@@ -230,14 +227,13 @@ class BNNCost(object):
         return ws
 
     @torch.no_grad()
-    def cost_and_grad(self, params, grad_views, theta_sumsq=None, theta_sumsq_partials=None, weight_update=None):
+    def cost_and_grad(self, params, grad_views, theta_sumsq=None, theta_sumsq_partials=None):
         """NLL at ``params`` with d NLL/d params written into ``grad_views`` (views of the sampler's
         gradient arena): rocBLAS GEMMs + the library's loss-head and fused tanh-backward/bias-gradient
         kernels (~20 launches per step for 4 layers)."""
         if self.use_hip_kernels:
             # no silent fallback: the HIP path needs device tensors (kernels.* raises on CPU tensors)
-            return self._cost_and_grad_hip(params, grad_views, theta_sumsq, theta_sumsq_partials, weight_update)
-        assert weight_update is None, "the weight-update hook belongs to the HIP path"
+            return self._cost_and_grad_hip(params, grad_views, theta_sumsq, theta_sumsq_partials)
         return self._cost_and_grad_torch(params, grad_views, theta_sumsq)
 
     def _forward(self, params, X, hs):
@@ -254,39 +250,7 @@ class BNNCost(object):
                 torch.tanh_(hs[l])
             h = hs[l]
 
-    # layers with at least this many weights announce their finished gradient (grad_ready_points): the sampler may
-    # then update that slice of the arena on a side stream under the rest of the backward pass
-    OVERLAP_MIN_WEIGHTS = 1 << 18
-
-    def grad_ready_points(self, params):
-        """Parameter indices p, in the order the backward pass reaches them, at which the gradients of ``params[p:]``
-        are complete and their values are no longer read: after the weight-gradient GEMM of hidden layer l (p = 2 l),
-        for every layer but the first (its gradient is the last thing the pipeline computes)."""
-        n_layers = (len(params) - 1) // 2
-        L = n_layers - 1
-        single_out = params[2 * L].shape[1] == 1 and n_layers >= 2
-        top = L - 1 if single_out else L
-        return [2 * l for l in range(top, 0, -1) if params[2 * l].numel() >= self.OVERLAP_MIN_WEIGHTS]
-
-    def cost_and_grad_iter(self, params, grad_views, theta_sumsq=None, theta_sumsq_partials=None):
-        """``cost_and_grad`` as a generator: yields p at every point of ``grad_ready_points`` (in that order) and
-        returns the cost (``StopIteration.value``). HIP path only; advance it under ``torch.no_grad()`` (a generator
-        cannot hold a grad-mode context across its yields)."""
-        return self._hip_pipeline(params, grad_views, theta_sumsq, theta_sumsq_partials)
-
-    def _cost_and_grad_hip(self, params, grad_views, theta_sumsq, theta_sumsq_partials=None, weight_update=None):
-        gen = self._hip_pipeline(params, grad_views, theta_sumsq, theta_sumsq_partials, weight_update)
-        while True:
-            try:
-                next(gen)
-            except StopIteration as stop:
-                return stop.value
-
-    def _hip_pipeline(self, params, grad_views, theta_sumsq, theta_sumsq_partials=None, weight_update=None):
-        """``weight_update(l, h_in, delta_l)`` (optional): called where the weight-gradient product of hidden layer ``l``
-        would be issued -- every gradient that follows W_l in the arena up to the next layer's weights is complete and W_l is
-        no longer read. If it returns True the caller has consumed the product itself (the sampler's GEMM + update kernel,
-        ``kernels.gemm_tn_sghmc``) and ``grad_views[2 l]`` is NOT written."""
+    def _cost_and_grad_hip(self, params, grad_views, theta_sumsq, theta_sumsq_partials=None):
         from pysgmcmc_amd import kernels
         X, Y = self.x_placeholder.value, self.y_placeholder.value
         B = X.shape[0]
@@ -295,7 +259,6 @@ class BNNCost(object):
         hs, ds = ws["h"], ws["d"]
         L = n_layers - 1
         single_out = params[2 * L].shape[1] == 1 and n_layers >= 2
-        ready = set(self.grad_ready_points(params))
         # forward; a single-output last layer is a plain GEMV whose bias the loss head adds
         h = X
         fuse_top = single_out and self.fuse_tanh_rowdot
@@ -357,18 +320,12 @@ class BNNCost(object):
                                                 grad_views[2 * (l - 1) + 1], grad_views[2 * l].view(-1),
                                                 bias_prev=params[2 * (l - 1) + 1], beta=beta)
                 continue
-            # delta_{l-1} = delta_l W_l^T FIRST: it is the last reader of W_l, so once gW_l exists (next GEMM) the layer's
-            # slice of the arena may be updated while the rest of the backward pass runs
+            # delta_{l-1} = delta_l W_l^T first (the last reader of W_l), then gW_l
             if l > 0:
                 torch.mm(ds[l], W.t(), out=ds[l - 1])
             # gW_l = h_{l-1}^T delta_l written directly into the gradient arena. The weight-prior term
             # coef * theta is added by the update kernel (fold_prior) or rides in the GEMM epilogue (beta).
-            if weight_update is not None and weight_update(l, h_in, ds[l]):
-                pass                                          # product + update of this layer's slice done by the sampler's kernel
-            elif (self.gw_gemm == "mfma" and self.fold_prior and W.dtype == torch.float32 and W.shape[1] % 128 == 0
-                  and W.shape[0] % 4 == 0 and h_in.shape[0] % 16 == 0 and grad_views[2 * l].data_ptr() % 16 == 0):
-                kernels.gemm_tn(h_in, ds[l], grad_views[2 * l])   # the library's own fp32 matrix-core product (k-ordered fmaf chain)
-            elif self.fold_prior:
+            if self.fold_prior:
                 torch.mm(h_in.t(), ds[l], out=grad_views[2 * l])
             else:
                 torch.addmm(W, h_in.t(), ds[l], beta=prior_coef, alpha=1.0, out=grad_views[2 * l])
@@ -378,8 +335,6 @@ class BNNCost(object):
                     torch.mv(ds[l].t(), ws["ones"], out=grad_views[2 * l + 1])
                 else:
                     torch.addmv(b, ds[l].t(), ws["ones"], beta=prior_coef, alpha=1.0, out=grad_views[2 * l + 1])
-            if 2 * l in ready:
-                yield 2 * l                                   # gradients of params[2 l:] complete, values no longer read
             if l > 0:
                 # delta_{l-1} *= 1 - h_{l-1}^2, and gb_{l-1} = column sums of the result (+ beta * b_{l-1})
                 kernels.tanh_backward_colsum(ds[l - 1], hs[l - 1], grad_views[2 * (l - 1) + 1],

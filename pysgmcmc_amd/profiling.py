@@ -34,7 +34,7 @@ class UpdateKernelTimer(object):
         self._seen = 0
         self.bracket = bool(bracket)
         self.kevents = []          # one KernelEvents per timed launch, in launch order
-        self.tags = []             # per timed launch: None, or (step, lo, hi) for one slice of an overlapped update
+        self.tags = []             # per timed launch: None, or (step, lo, hi): the step number and the arena slice of the launch
         self.pairs = []            # (torch event, torch event) brackets, when bracket=True
         self._pool = []
         self._current = None
@@ -52,7 +52,7 @@ class UpdateKernelTimer(object):
     # -- called by the sampler around its update launch --
     def due(self, tag=None):
         """Called once per launch while enabled: is this launch one of the timed ones? With ``sample_every = k`` the launches
-        of every k-th step are (all slices of an overlapped step together: the tag's first entry is the step number)."""
+        of every k-th step are (all launches of a step together: the tag's first entry is the step number)."""
         k = max(int(self.sample_every), 1)
         if tag is not None:
             return tag[0] % k == 0
@@ -88,21 +88,27 @@ class UpdateKernelTimer(object):
         return np.array([k.elapsed_us() for k in self.kevents])
 
     def step_us(self):
-        """Time from the end of each step's LAST update launch to the end of the next step's: the device time of a
-        whole step (an overlapped update is several launches per step, tagged (step, lo, hi))."""
-        kv = self.last_launch_of_each_step()
-        return np.array([kv[j].us_until(kv[j + 1]) for j in range(len(kv) - 1)])
+        """Device time of a whole step: from the end of one timed step's LAST update launch to the end of the next timed
+        step's, divided by the number of steps in between (with ``sample_every = k`` only every k-th step carries events, so
+        consecutive entries are k steps apart; untagged launches count as consecutive steps)."""
+        kv, steps = self.last_launch_of_each_step(with_steps=True)
+        out = []
+        for j in range(len(kv) - 1):
+            gap = 1 if (steps[j] is None or steps[j + 1] is None) else max(int(steps[j + 1]) - int(steps[j]), 1)
+            out.append(kv[j].us_until(kv[j + 1]) / gap)
+        return np.array(out)
 
-    def last_launch_of_each_step(self):
-        out, prev = [], object()
+    def last_launch_of_each_step(self, with_steps=False):
+        out, steps, prev = [], [], object()
         for kev, tag in zip(self.kevents, self.tags):
             step = tag[0] if tag is not None else None
             if tag is not None and step == prev:
                 out[-1] = kev
             else:
                 out.append(kev)
+                steps.append(step)
             prev = step if tag is not None else object()
-        return out
+        return (out, steps) if with_steps else out
 
     def per_step_kernel_us(self):
         """(sum of the update launches' durations per step, bytes-weighted slices included)."""

@@ -26,7 +26,7 @@ What differs, by design:
     {sum theta^2, sum V^2, sum minv, sum minv^2} from registers (``sampler.stats``); a cost
     function that sets ``accepts_theta_sumsq`` gets sum theta^2 for free (BNN weight prior).
     ``"theta_sq"`` reduces only sum theta^2 (all a BNN pipeline consumes); ``False`` nothing.
-  * ``overlap_update`` (attribute) / ``attach_moments``: see ``_step_graph`` and ``attach_moments``.
+  * ``attach_moments``: the chain's Welford moments ride in the update launch.
   * ``sample_format`` (attribute, not a constructor keyword so that the
     ``get_sampler`` keyword reflection stays identical to the reference):
     ``"numpy"`` (default, reference behaviour: one D2H copy of theta per step),
@@ -145,22 +145,6 @@ class MCMCSampler(object):
         self._moments, self._moments_every = None, 1
         # hipGraph mode
         self.use_hip_graph = False
-        # True: update the arena slice by slice on a side stream as soon as each layer's gradient is complete (needs
-        # use_hip_graph = True and a cost function with cost_and_grad_iter, e.g. BNNCost). Bit-identical chain, but
-        # MEASURED SLOWER on MI355X (profiles/r03_overlap_probe.txt: 239-246 vs 199 us per step at 10 M parameters --
-        # cross-queue synchronisation costs ~40 us per step whatever the update's grid): off by default, kept for
-        # the measurement.
-        self.overlap_update = False
-        # SGHMC + an MLP cost function (BNNCost), frozen phase: the weight-gradient GEMM of every hidden layer carries the
-        # update of that layer's slice of the arena as its epilogue (kernels.gemm_tn_sghmc) -- no separate update launch, no
-        # gradient round trip through HBM for the weights. Needs use_hip_graph = True. The chain differs from the default
-        # path only through the summation order of the weight-gradient products (BNNCost.gw_gemm = "mfma" reproduces it
-        # bit for bit with the un-fused kernels).
-        self.fuse_update_into_gemm = False
-        self._fused_plan = None
-        self._slice_plan = None
-        self._slice_launch = None
-        self._side_stream = None
         self._scalars_dev = None
         self._scalars_value = None
         self._graphs = {}
@@ -178,8 +162,6 @@ class MCMCSampler(object):
         self.theta_t = self.arena.views("theta")
         self._graphs.clear()
         self._static_feeds.clear()
-        self._slice_plan = None
-        self._fused_plan = None
         self._stats_valid = False
         self._view_cache = None
 
@@ -348,10 +330,9 @@ class MCMCSampler(object):
             self._stats_out_valid = False     # K7 runs lazily (sampler.stats); the BNN head reads the records
 
     def _launch(self):
-        """Launch configuration of the update kernel for THIS launch: the chain's geometry (or the geometry this
-        step's slices were planned with), plus the timestamp events of an attached, enabled kernel timer (never inside
-        a graph capture)."""
-        base = self._slice_launch if self._slice_launch is not None else self.launch
+        """Launch configuration of the update kernel for THIS launch: the chain's geometry plus the timestamp events of an
+        attached, enabled kernel timer (never inside a graph capture)."""
+        base = self.launch
         t = self.kernel_timer
         if t is not None and t._current is not None:
             return t.launch_config(base)
@@ -414,6 +395,13 @@ class MCMCSampler(object):
         moments = None
         if self._moments_due() and not self._capturing:
             moments = self._moments
+        if self._SCALARS_KIND is None:
+            # a sampler whose kernel takes no step extras (SVGD): plain launch, the Welford pass on its own (K4)
+            self._timed_kernel_step(eps, xi, tag=(self.n_iterations, 0, self.arena.n))
+            if moments is not None:
+                moments.update(self.arena.row("theta"))
+            return
+        if moments is not None:
             moments.count += 1
         # (a captured launch replays its arguments and cannot carry the by-value Welford count: see _step_graph_full)
         self._timed_kernel_step(eps, xi, opts=self._update_opts(0, self.arena.n, moments=moments),
@@ -475,76 +463,35 @@ class MCMCSampler(object):
         """One step with the launch-bound part replayed from hipGraphs.
 
         ``use_hip_graph = True``: the graph holds cost + gradient into the arena; the fused update is launched
-        directly (stepsize / phase / Philox step by value, HIP events can time it). With ``overlap_update`` and a
-        cost function that reports when a layer's gradient is complete (``cost_and_grad_iter``), the pipeline is
-        captured as consecutive graph SEGMENTS and the update of the finished slice of the arena is launched on a side
-        stream between them, so the HBM-bound update runs under the remaining (matrix-core-bound) backward GEMMs; the
-        slices draw the Philox quads the single launch would draw -- the chain is bit-identical.
+        directly (stepsize / phase / Philox step by value, HIP events can time it).
         ``use_hip_graph = "full"``: ONE graph per phase (burn-in / frozen) also holds the update: the Philox step comes
         from a device counter and the stepsize-derived scalars from a device block refreshed by a tiny direct launch
         whenever the schedule moves (``StepOpts.scalars_dev``), so a SCHEDULED stepsize replays the same graph.
         Feeds are copied into static buffers first. Requirements: static feed shapes; a cost function without host
-        synchronisation."""
+        synchronisation. (Round 3's two further modes -- the update on a side stream under the backward GEMMs, and the
+        update as the epilogue of a hand-written weight-gradient GEMM -- were measured slower / no faster and live in
+        ``tools/experiments/stepping.py``.)"""
         self._feed_static(feed_dict)
         eps = self._next_stepsize()
         self._ensure_stats()
         if self.use_hip_graph == "full":
             return self._step_graph_full(eps)
-        if self.fuse_update_into_gemm and self._fused_plan is not False and not getattr(self, "_adapting", False) \
-                and not self._moments_due() and hasattr(self, "_fused_gemm_plan"):
-            done = self._step_graph_fused_gemm(eps)
-            if done is not None:
-                return done
         entry = self._graphs.get(("cost",))
         if entry is None:
             entry = self._graphs[("cost",)] = self._capture_cost()
-        segments, cost = entry
-        with torch.no_grad():
-            if len(segments) == 1:
-                segments[0][0].replay()
-                self._update(eps, None)
-            else:
-                self._replay_overlapped(segments, eps)
-        self.cost = cost
-        return self._finish_step(cost)
-
-    def _step_graph_fused_gemm(self, eps):
-        """Frozen step whose update rides in the weight-gradient GEMMs (see ``fuse_update_into_gemm``): ONE graph holds the
-        cost pipeline, the fused GEMM + update launches (Philox step from the device counter) and the counter increment.
-        Returns None when the model does not fit the fused kernel (the caller then steps the usual way)."""
-        if self._fused_plan is None:
-            self._fused_plan = self._fused_gemm_plan() or False
-            if self._fused_plan is False:
-                return None
-        plan, total = self._fused_plan
-        if self._step_ctr is None:
-            self._step_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
-        if self._ctr_value != self.n_iterations:
-            self._step_ctr.fill_(self.n_iterations)
-            self._ctr_value = self.n_iterations
-        key = ("fused_gemm", float(eps))
-        entry = self._graphs.get(key)
-        if entry is None:
-            self._warm_cost()
-            graph = torch.cuda.CUDAGraph()
-            self._fused_grad_decay = float(getattr(self.cost_fun, "grad_theta_coef", 0.0))    # set by the warm-up evaluation
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"), torch.no_grad():
-                cost = self.cost_fun.cost_and_grad(self.params, self.arena.grad_views,
-                                                   weight_update=self._fused_weight_update(plan, total, eps), **self._cost_kwargs())
-                kernels.counter_add(self._step_ctr, 1)
-            cost = cost.detach() if isinstance(cost, torch.Tensor) else torch.as_tensor(cost)
-            entry = self._graphs[key] = (graph, cost)
         graph, cost = entry
-        graph.replay()
-        self._ctr_value += 1
-        self._stats_written()
+        with torch.no_grad():
+            graph.replay()
+            self._update(eps, None)
         self.cost = cost
         return self._finish_step(cost)
 
     def _step_graph_full(self, eps):
         if self._step_ctr is None:
             self._step_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
+        if self._scalars_dev is None and self._SCALARS_KIND is not None:
             self._scalars_dev = torch.zeros(8, dtype=self._torch_dtype, device=self.device)
+            self._scalars_value = None
         if self._ctr_value != self.n_iterations:
             self._step_ctr.fill_(self.n_iterations)
             self._ctr_value = self.n_iterations
@@ -586,98 +533,15 @@ class MCMCSampler(object):
                 kw["theta_sumsq_partials"] = st.workspace
         return kw
 
-    def _plan_slices(self, ready_points):
-        """Arena slices of an overlapped step. ``ready_points`` = parameter indices p (descending): when the cost
-        pipeline reaches that point, the gradients of params[p:] are complete and their values no longer read.
-        Returns [(lo, hi, record_base)] in launch order plus the record total, or None when a boundary is not
-        quad-aligned (slices must start on a Philox quad)."""
-        a = self.arena
-        bt = self._slice_block_threads()
-        cfg = kernels.LaunchConfig(block_threads=bt,
-                                   **{k: v for k, v in (self.launch.as_dict() if self.launch is not None else {}).items()
-                                      if k != "block_threads"})
-        bounds = [a.n] + [int(a.offsets[p]) for p in ready_points] + [0]
-        if any(b % 4 for b in bounds[1:]) or sorted(set(bounds), reverse=True) != bounds:
-            return None
-        spans = [(bounds[i + 1], bounds[i]) for i in range(len(bounds) - 1)]      # launch order: high addresses first
-        blocks = [kernels.step_stats_records(hi - lo, cfg) for lo, hi in spans]
-        total = sum(blocks)
-        plan, base = [], total
-        for (lo, hi), nb in zip(spans, blocks):
-            base -= nb                                                           # records in memory order
-            plan.append((lo, hi, base))
-        return plan, total, cfg
-
-    def _slice_block_threads(self):
-        if self.launch is not None and self.launch.as_dict()["block_threads"] > 0:
-            return self.launch.as_dict()["block_threads"]
-        return 128 if self._arena_is_hbm_resident() else 256
-
     def _capture_cost(self):
-        """Capture the cost/gradient pipeline: one graph, or -- overlapped update -- one graph per segment between
-        the points where a slice of the gradient is complete. Returns ([(graph, slice or None)], cost)."""
+        """Capture the cost/gradient pipeline into one graph. Returns (graph, cost)."""
         self._warm_cost()
-        iter_fn = getattr(self.cost_fun, "cost_and_grad_iter", None) if self.overlap_update else None
-        plan = None
-        if iter_fn is not None:
-            points = list(self.cost_fun.grad_ready_points(self.params))
-            plan = self._plan_slices(points) if points else None
-        if plan is None:
-            graph = torch.cuda.CUDAGraph()
-            # thread_local: other threads (e.g. the RCCL watchdog of a multi-chain job) may keep calling
-            # HIP while this thread captures
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                cost = self._cost_and_grad()
-            return [(graph, None)], cost
-        spans, total, cfg = plan
-        self._slice_plan = (spans, total, cfg)
-        gen = iter_fn(self.params, self.arena.grad_views, **self._cost_kwargs())
-        segments, cost, pool = [], None, None
-        for k in range(len(spans)):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"), torch.no_grad():
-                try:
-                    next(gen)
-                except StopIteration as stop:
-                    cost = stop.value
-            pool = graph.pool()
-            segments.append((graph, spans[k]))
-        assert cost is not None, "cost_and_grad_iter must yield exactly once per grad_ready_points() entry"
-        self._grad_decay = float(getattr(self.cost_fun, "grad_theta_coef", 0.0))
-        cost = cost.detach() if isinstance(cost, torch.Tensor) else torch.as_tensor(cost)
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
-            self._fork_events = [torch.cuda.Event() for _ in range(len(spans))]
-            self._join_event = torch.cuda.Event()
-        return segments, cost
-
-    def _replay_overlapped(self, segments, eps):
-        """graph segment -> update of the slice whose gradient it completed, on the side stream -> next segment ...;
-        the last slice (nothing left to hide under) runs on the main stream, which then waits for the side stream."""
-        spans, total, cfg = self._slice_plan
-        moments = None
-        if self._moments_due():
-            moments = self._moments
-            moments.count += 1
-        main = torch.cuda.current_stream(self.device)
-        side = self._side_stream
-        self._slice_launch = cfg
-        try:
-            last = len(segments) - 1
-            for k, (graph, (lo, hi, base)) in enumerate(segments):
-                graph.replay()
-                opts = self._update_opts(lo, hi, base, total, moments=moments, sliced=True)
-                if k < last:
-                    self._fork_events[k].record(main)
-                    side.wait_event(self._fork_events[k])
-                    with torch.cuda.stream(side):
-                        self._timed_kernel_step(eps, None, sl=slice(lo, hi), opts=opts, tag=(self.n_iterations, lo, hi))
-                else:
-                    self._timed_kernel_step(eps, None, sl=slice(lo, hi), opts=opts, tag=(self.n_iterations, lo, hi))
-            self._join_event.record(side)
-            main.wait_event(self._join_event)
-        finally:
-            self._slice_launch = None
+        graph = torch.cuda.CUDAGraph()
+        # thread_local: other threads (e.g. the RCCL watchdog of a multi-chain job) may keep calling
+        # HIP while this thread captures
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            cost = self._cost_and_grad()
+        return graph, cost
 
     def _capture_full(self, eps):
         self._warm_cost()

@@ -53,50 +53,6 @@ class SGHMCSampler(FusedBNNStepsMixin, BurnInMCMCSampler):
             xi=xi, stats=self._step_stats(), grad_decay=self._grad_decay, launch=self._launch(), opts=opts, **self._noise_args())
         self._stats_written()
 
-    # ------------------------------------------------------------------ weight-gradient GEMM with the update as epilogue
-    def _fused_gemm_plan(self):
-        """Slices of the arena for ``fuse_update_into_gemm``: one per hidden dense layer of an MLP cost function,
-        ``[W_l | everything up to W_{l+1}]`` (the top one runs to the end of the arena), or None when the model / dtype /
-        alignment does not fit ``sgmcmc_gemm_tn_sghmc_f32`` (the sampler then steps as usual)."""
-        a, params = self.arena, self.params
-        if self._torch_dtype != torch.float32 or not hasattr(self.cost_fun, "cost_and_grad") or (len(params) - 1) % 2:
-            return None
-        n_layers = (len(params) - 1) // 2
-        L = n_layers - 1
-        if n_layers < 2 or params[2 * L].dim() != 2 or params[2 * L].shape[1] != 1:
-            return None
-        plan, offs = [], [int(a.offsets[2 * l]) for l in range(L)] + [a.n]
-        for l in range(L):
-            W = params[2 * l]
-            M, N = (int(W.shape[0]), int(W.shape[1])) if W.dim() == 2 else (0, 0)
-            lo, hi = offs[l], offs[l + 1]
-            if W.dim() != 2 or N % 128 or M % 4 or lo % 4 or lo != int(a.offsets[2 * l]) or hi - lo < M * N or (l == 0 and lo != 0):
-                return None
-            plan.append(dict(layer=l, lo=lo, hi=hi, M=M, N=N, n_tail=hi - lo - M * N,
-                             blocks=kernels.gemm_tn_sghmc_blocks(M, N, hi - lo - M * N)))
-        base = 0
-        for p in plan:
-            p["rec_base"], base = base, base + p["blocks"]
-        return plan, base
-
-    def _fused_weight_update(self, plan, total, eps):
-        """The hook handed to the cost pipeline while the fused graph is captured."""
-        a = self.arena
-        by_layer = {p["layer"]: p for p in plan}
-
-        def hook(l, h_in, delta):
-            p = by_layer.get(l)
-            if p is None or h_in.shape[0] % 16:
-                return False
-            sl = slice(p["lo"], p["hi"])
-            kernels.gemm_tn_sghmc(h_in, delta, a.row("theta")[sl], a.row("V")[sl], a.row("minv")[sl],
-                                  a.row("grad")[p["lo"] + p["M"] * p["N"]:p["hi"]] if p["n_tail"] else None,
-                                  eps, self.scale_grad, self.mdecay, grad_decay=self._fused_grad_decay, seed=self._philox_seed,
-                                  step=0, step_dev=self._step_ctr, first_element=p["lo"], stats=self._step_stats(),
-                                  stats_base=p["rec_base"], stats_total=total)
-            return True
-        return hook
-
     # ------------------------------------------------------------------ fused small-model path (see _fused_bnn.py)
     def _fused_bnn_launch(self, starts, costs, eps, n_steps, n_chains=1, chain_stride=None, bases=None):
         gen, cost, a = self.batch_generator, self.cost_fun, self.arena

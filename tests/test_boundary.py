@@ -35,7 +35,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in _declared_symbols():
         assert hasattr(handle, name), "libsgmcmc_hip.so does not export %s" % name
     lib = _lib.lib()
-    assert lib.sgmcmc_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.sgmcmc_abi_version() == _lib.ABI_VERSION == 4
     assert lib.sgmcmc_summary_workspace_bytes() >= 1024 * 32
     # the per-call launch geometry is validated on the host before anything is launched: checkable without a
     # GPU (the output pointer is a dummy that is never dereferenced because the call fails first)
@@ -46,6 +46,19 @@ def test_library_loads_and_exports_every_declared_symbol():
     rc = lib.sgmcmc_moments_update_f32(ctypes.c_void_p(4096), ctypes.c_void_p(4096), ctypes.c_void_p(4096), 8, 1,
                                        ctypes.byref(bad), None)
     assert rc == -1 and b"quads_per_thread" in lib.sgmcmc_last_error()
+
+
+def test_abi_exports_no_experiment_knobs():
+    """the ABI a maintainer binds must not carry experiment switches. v4 dropped the hand-written GEMM entry
+    points (tile-variant / timing-probe / de-phasing arguments); they are built separately by tools/experiments."""
+    from pysgmcmc_amd import _lib
+    handle = ctypes.CDLL(_lib.build())
+    header = open(HEADER).read()
+    assert not [name for name in _declared_symbols() if "gemm" in name]
+    for name in ("sgmcmc_gemm_tn_f32", "sgmcmc_gemm_tn_sghmc_f32", "sgmcmc_gemm_tn_sghmc_blocks"):
+        assert not hasattr(handle, name)
+    for word in ("phase_counters", "phase_sleep", "int variant", "probe"):
+        assert word not in header, "include/sgmcmc_hip.h mentions %r" % word
 
 
 def test_abi_holds_no_process_wide_state():

@@ -271,6 +271,8 @@ def test_bench_n2_driver_arguments_contain_one_exchange(gpu):
     d = _bench_n2(["--steps", "20", "--warmup", "5"])
     assert d["steps"] == 20 and d["warmup"] == 5 and d["config"]["rhat_every"] == 14 and d["config"]["moments_every"] == 10
     assert d["rccl"]["exchanges_timed"] == 1 and d["rccl"]["rhat_exchange_ms"]["start_to_finish"] > 0
+    assert d["rccl"]["cadence_steps_used"] == 14 and d["rccl"]["cadence_steps_config3"] == 100
+    assert d["value_ex_exchange"] >= d["value"] and d["rccl"]["exposed_ms"] > 0
     # the update launches of every 4th step carry timestamp events (20 // 5; a timed launch costs the step ~8 us)
     assert d["rhat"] is not None and d["config"]["time_every"] == 4 and d["roofline"]["launches_timed"] == 5
 
@@ -299,6 +301,12 @@ def test_bench_starts_its_own_ranks_without_a_launcher(gpu, n):
     assert d["n_gpus"] == n and d["rccl"]["ranks"] == n and d["rccl"]["exchanges_timed"] == 1 and d["value"] > 0
     assert d["config"]["chains"] == n and d["rhat"] is not None
     assert "roofline_unoverlapped" in d and "step_breakdown_us" in d      # rank 0's extra legs ran after the group was torn down
+    # the exchange's exposed time and `value` with it taken out ride next to `value`
+    rc = d["rccl"]
+    assert rc["exposed_ms"] >= rc["exposed_ms_rank0"] > 0 and 0 < rc["exposed_frac_of_timed_region"] < 1
+    assert d["value_ex_exchange"] >= d["value"] > 0
+    assert np.isclose(d["value_ex_exchange"], n * 6 / (d["ms_per_step"] * 6e-3 - rc["exposed_ms"] * 1e-3), rtol=2e-2)
+    assert rc["cadence_steps_used"] == d["config"]["rhat_every"] == 4 and rc["cadence_steps_config3"] == 100
 
 
 @pytest.mark.timeout(600)

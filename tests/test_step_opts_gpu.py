@@ -162,7 +162,7 @@ def test_device_scalars_override_the_by_value_scalars(gpu, dt, kind, adapt):
             assert torch.equal(a[k], b[k]), (kind, eps, k)
 
 
-def _bnn_chain(gpu, ctor, overlap, graph, moments_every=0, fused_moments=True, steps=14, **kw):
+def _bnn_chain(gpu, ctor, graph, moments_every=0, fused_moments=True, steps=14, **kw):
     from pysgmcmc_amd.data_batches import Placeholder, generate_batches
     from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments
     from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
@@ -173,12 +173,10 @@ def _bnn_chain(gpu, ctor, overlap, graph, moments_every=0, fused_moments=True, s
     xp, yp = Placeholder(dtype=torch.float32, device=gpu), Placeholder(dtype=torch.float32, device=gpu)
     params = init_mlp_params(16, hidden=(96, 128, 64), seed=5, dtype=torch.float32, device=gpu)
     cost = BNNCost(xp, yp, batch_size=32, n_examples=400)
-    cost.OVERLAP_MIN_WEIGHTS = 1024                        # every hidden layer announces its gradient
     s = ctor(params=params, cost_fun=cost, batch_generator=generate_batches(X, y, xp, yp, batch_size=32, seed=2),
              stepsize_schedule=ConstantStepsizeSchedule(0.01), session=gpu, dtype=torch.float32, seed=9, **kw)
     s.sample_format = "view"
     s.use_hip_graph = graph
-    s.overlap_update = overlap
     s.collect_stats = "theta_sq"
     s.kernel_timer = UpdateKernelTimer()
     s.kernel_timer.enabled = True
@@ -194,27 +192,6 @@ def _bnn_chain(gpu, ctor, overlap, graph, moments_every=0, fused_moments=True, s
     return s, m, costs
 
 
-def test_overlapped_update_gives_the_same_chain(gpu):
-    """overlap_update: the cost pipeline is replayed as graph segments and every finished slice of the arena is updated
-    on a side stream under the rest of the backward pass. Chain, costs, statistics-fed weight prior and the fused
-    Welford moments equal the single-launch sampler's bit for bit (SGHMC across the burn-in switch, SGLD, relativistic)."""
-    from pysgmcmc_amd.samplers import RelativisticSGHMCSampler, SGHMCSampler, SGLDSampler
-    for ctor, kw, rows in ((SGHMCSampler, dict(burn_in_steps=5, scale_grad=400.0), ("theta", "V", "minv", "grad")),
-                           (SGLDSampler, dict(burn_in_steps=5, scale_grad=400.0), ("theta", "minv")),
-                           (RelativisticSGHMCSampler, {}, ("theta", "p"))):
-        base, mb, cb = _bnn_chain(gpu, ctor, overlap=False, graph=True, moments_every=3, fused_moments=False, **kw)
-        over, mo, co = _bnn_chain(gpu, ctor, overlap=True, graph=True, moments_every=3, **kw)
-        eager, me, ce = _bnn_chain(gpu, ctor, overlap=False, graph=False, moments_every=3, **kw)
-        assert len(over._graphs[("cost",)][0]) == 3          # three graph segments: two announced layers + the tail
-        assert len(over.kernel_timer.kevents) == 3 * 14 and len(base.kernel_timer.kevents) == 14
-        assert over.kernel_timer.per_step_kernel_us().shape == (14,) and (over.kernel_timer.kernel_us() > 0).all()
-        for other, m, c in ((over, mo, co), (eager, me, ce)):
-            for row in rows:
-                assert torch.equal(base.arena.row(row), other.arena.row(row)), (ctor.__name__, row)
-            assert np.allclose(c, cb, rtol=1e-6, atol=0)
-            assert m.count == mb.count == 4 and torch.equal(m.mean, mb.mean) and torch.equal(m.m2, mb.m2)
-
-
 def test_burn_in_without_minv_stores_gives_the_same_chain(gpu):
     """``store_minv_every_step = False``: only the LAST burn-in step writes minv (it is the one value the frozen steps
     consume, pysgmcmc/samplers/base_classes.py:449-454). Same chain bit for bit through the switch, in every stepping
@@ -223,7 +200,7 @@ def test_burn_in_without_minv_stores_gives_the_same_chain(gpu):
     for ctor in (SGHMCSampler, SGLDSampler):
         for graph in (False, True, "full"):
             kw = dict(burn_in_steps=6, scale_grad=400.0)
-            a, _, ca = _bnn_chain(gpu, ctor, overlap=False, graph=graph, steps=11, **kw)
+            a, _, ca = _bnn_chain(gpu, ctor, graph=graph, steps=11, **kw)
             b = None
 
             def chain_b():

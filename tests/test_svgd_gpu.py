@@ -327,3 +327,26 @@ def test_svgd_randomised_shape_sweep():
                                    err_msg=str((case, n, d, ld, offset, dtype, sign)))
         if pad:
             assert np.all(got[:, d:] == 7.0), (case, n, d, ld)           # the padding is never written
+
+
+def test_svgd_sampler_with_attached_moments():
+    """``attach_moments`` on a sampler whose kernel takes no step extras (SVGD) must not raise: the Welford
+    pass runs as its own launch (K4) after the step and equals the moments of the visited states."""
+    from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments
+    from pysgmcmc_amd.sampling import Sampler
+    rng = np.random.RandomState(1)
+    x0 = rng.normal(size=(12, 3))
+    s = Sampler.get_sampler(Sampler.SVGD, particles=[torch.tensor(r, device=DEV) for r in x0],
+                            cost_fun=lambda p: 0.5 * (p ** 2).sum(), dtype=torch.float32)
+    s.sample_format = "device"
+    m = ChainMoments(s.arena.n, DEV)
+    s.attach_moments(m, every=2)
+    seen = []
+    for i in range(8):
+        next(s)
+        if (i + 1) % 2 == 0:
+            seen.append(s.arena.row("theta").double().clone())
+    assert m.count == 4
+    ref = torch.stack(seen)
+    assert torch.allclose(m.mean.double(), ref.mean(dim=0), atol=1e-5)
+    assert torch.allclose(m.m2.double(), ((ref - ref.mean(dim=0)) ** 2).sum(dim=0), atol=1e-4)

@@ -31,7 +31,7 @@
 #include <cmath>
 #include <cstdint>
 
-#include "sgmcmc_hip.h"
+#include "sgmcmc_gemm_experiments.h"
 
 #pragma clang fp contract(off)
 

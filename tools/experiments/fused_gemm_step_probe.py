@@ -1,7 +1,9 @@
 """Step time of the 10 M-parameter bench chain: cost graph + one update launch (the default) against the update fused into
 the weight-gradient GEMMs (sampler.fuse_update_into_gemm), with the library's and with the hand-written gW products."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from tools.experiments import gemm_kernels      # sets PYSGMCMC_AMD_LIB to the experiments build
+from tools.experiments.stepping import upgrade
 import torch
 import bench
 
@@ -11,6 +13,7 @@ enable_gemm_tuning(True, max_duration_ms=30, max_iterations=20)
 for label, fused, gw in (("library GEMMs + one K1 launch (default)", False, "blas"), ("hand-written gW GEMMs + one K1 launch", False, "mfma"),
                          ("update fused into the gW GEMMs", True, "blas")):
     s = bench.build_chain(dev, 0, os.environ.get("PROBE_WORKLOAD", "bnn10m-sghmc"), burn_in=8)
+    s = upgrade(s)
     s.sample_format = "view"
     s.use_hip_graph = True
     s.collect_stats = "theta_sq"

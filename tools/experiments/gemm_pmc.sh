@@ -1,7 +1,7 @@
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/gemm_pmc; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/a -o s -- python3 tools/gemm_pmc_probe.py > $O/a.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/t -o s -- python3 tools/gemm_pmc_probe.py > $O/t.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/a -o s -- python3 tools/experiments/gemm_pmc_probe.py > $O/a.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/t -o s -- python3 tools/experiments/gemm_pmc_probe.py > $O/t.log 2>&1
 python3 - <<'PY'
 import csv, collections, glob
 csv.field_size_limit(1<<30)

@@ -1,7 +1,8 @@
 """The fused weight-gradient GEMM + SGHMC update against (library GEMM, then K1 on the layer's slice): bit-exactness of
 theta', V' given the gradient the fused kernel computed, and microseconds."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from tools.experiments import gemm_kernels      # sets PYSGMCMC_AMD_LIB to the experiments build
 import torch
 from pysgmcmc_amd import kernels
 from pysgmcmc_amd.models.bayesian_neural_network import enable_gemm_tuning
@@ -21,7 +22,7 @@ for (M, N, K, n_tail, first) in ((2048, 2048, 256, 2048, 1607680), (784, 2048, 2
     th, V = theta0.clone(), V0.clone()
     gout = torch.full((M, N), float("nan"), device=dev)
     st = kernels.StepStats(n, dev)
-    kernels.gemm_tn_sghmc(a, b, th, V, minv, gtail, 0.01, 1e5, 0.05, grad_decay=1e-6, seed=11, step=5, first_element=first,
+    gemm_kernels.gemm_tn_sghmc(a, b, th, V, minv, gtail, 0.01, 1e5, 0.05, grad_decay=1e-6, seed=11, step=5, first_element=first,
                           stats=st, grad_out=gout)
     # reference: K1 on the gradient the fused kernel wrote
     th2, V2 = theta0.clone(), V0.clone()
@@ -52,7 +53,7 @@ for (M, N, K, n_tail, first) in ((2048, 2048, 256, 2048, 1607680), (784, 2048, 2
         torch.mm(a.t(), b, out=gw[:M * N].view(M, N))
         kernels.sghmc_step(th2, V2, gw, None, None, None, minv, None, 0.01, 1e5, 0.05, False, seed=11, step=5, stats=st)
     def fused(blocks):
-        kernels.gemm_tn_sghmc(a, b, th, V, minv, gtail, 0.01, 1e5, 0.05, seed=11, step=5, first_element=first, stats=st,
+        gemm_kernels.gemm_tn_sghmc(a, b, th, V, minv, gtail, 0.01, 1e5, 0.05, seed=11, step=5, first_element=first, stats=st,
                               gemm_blocks=blocks)
     print("    library GEMM + K1 slice: %.1f us" % t(separate), flush=True)
     names = {0: "no prefetch, 4 WG/CU", 1: "2 of 4 quads prefetched, 4 WG/CU", 2: "4 of 4 prefetched, 4 WG/CU (spills)",
@@ -60,7 +61,7 @@ for (M, N, K, n_tail, first) in ((2048, 2048, 256, 2048, 1607680), (784, 2048, 2
              6: "2 of 4 prefetched, 3 WG/CU"}
     for fl in range(7):
         th3, V3 = theta0.clone(), V0.clone()
-        kernels.gemm_tn_sghmc(a, b, th3, V3, minv, gtail, 0.01, 1e5, 0.05, grad_decay=1e-6, seed=11, step=5, first_element=first,
+        gemm_kernels.gemm_tn_sghmc(a, b, th3, V3, minv, gtail, 0.01, 1e5, 0.05, grad_decay=1e-6, seed=11, step=5, first_element=first,
                               gemm_blocks=1024 | (fl << 16))
         ok = torch.equal(th3, th_ref) and torch.equal(V3, V_ref)
         print("    flavour %d (%s): bit-equal %s, %s us" % (fl, names[fl], ok, " / ".join(
@@ -68,7 +69,7 @@ for (M, N, K, n_tail, first) in ((2048, 2048, 256, 2048, 1607680), (784, 2048, 2
     pc = torch.zeros(2048, dtype=torch.int32, device=dev)
     for sl in (1, 2, 3):
         def fused_dephased():
-            kernels.gemm_tn_sghmc(a, b, th, V, minv, gtail, 0.01, 1e5, 0.05, seed=11, step=5, first_element=first, stats=st,
+            gemm_kernels.gemm_tn_sghmc(a, b, th, V, minv, gtail, 0.01, 1e5, 0.05, seed=11, step=5, first_element=first, stats=st,
                                   phase_counters=pc, phase_sleeps=sl)
         print("    fused, de-phased by %d x 3.4 us: %.1f us   (CU keys seen: %d)" % (sl, t(fused_dephased), int((pc > 0).sum())), flush=True)
     th.copy_(theta0); V.copy_(V0); th2.copy_(theta0); V2.copy_(V0)

@@ -2,7 +2,9 @@
 step in one graph ("full"), and the update forked layer by layer onto a side stream (inside the graph, or between graph
 segments), with the full-occupancy update kernel and with small persistent grids that leave the CUs to the GEMMs."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from tools.experiments import gemm_kernels      # sets PYSGMCMC_AMD_LIB to the experiments build
+from tools.experiments.stepping import upgrade
 import torch
 import bench
 from pysgmcmc_amd import kernels
@@ -21,6 +23,7 @@ for label, graph, overlap, geom in cases:
     if only and only not in label:
         continue
     s = bench.build_chain(dev, 0, "bnn10m-sghmc", burn_in=8)
+    s = upgrade(s)
     s.sample_format = "view"
     s.use_hip_graph = graph
     s.overlap_update = overlap
