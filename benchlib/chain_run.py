@@ -271,7 +271,7 @@ class ChainBench(object):
             # template args: <Op<float, ADAPT, INJECT>, quads per lane, NT, STATS (2 = sum theta^2 only), LOOP, MOMENTS>, from
             # the launch configuration in effect (library defaults: 1 quad per lane, nt iff the launch streams > 640 MiB,
             # single-pass variant while the grid is uncapped)
-            "roofline": {"bound": "hbm", "kernel": legs.update_kernel_instance(op_name, not self.frozen_phase, big, sampler),
+            "roofline": {"bound": "hbm", "kernel": legs.update_kernel_instance(op_name, kind == "rsghmc" or not self.frozen_phase, big, sampler),   # (2nd template arg of RsghmcOp = POW2: m = c = 1)
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,

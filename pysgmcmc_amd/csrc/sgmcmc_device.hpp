@@ -365,7 +365,11 @@ struct SgldOp {
     }
 };
 
-template <typename T, bool ADAPT_UNUSED, bool INJECT>
+// POW2: m^2 c^2 is a power of two (the reference's default m = c = 1, relativistic_sghmc.py:24-27): x / m2c2 and
+// x * (1 / m2c2) are then the SAME correctly rounded value, so the two divisions by m2c2 of :123 / :131 become multiplications
+// -- bit-identical results, 2 of the 4 divisions per element gone. The kernel is VALU-bound, not HBM-bound (SQ counters,
+// profiles/r04_k3_counters.txt: its vector ALU is active 87-93 % of the launch), so instructions are time here.
+template <typename T, bool POW2, bool INJECT>
 struct RsghmcOp {
     typedef T real;
     T *theta, *p; const T *grad; const T *xi;
@@ -374,6 +378,7 @@ struct RsghmcOp {
     NoiseKey nk;
     double *stats_part;
     const T *scalars_dev = nullptr;       // nullable device copy of {eps, mass, D, m2c2, nscale} (see SghmcOp)
+    T inv_m2c2 = T(0);                    // POW2 only: 1 / m2c2 (exact)
     static constexpr unsigned stats_mask = 0x3u;     // {theta'^2, p'^2}
     __device__ __forceinline__ void prepare()
     {
@@ -405,6 +410,7 @@ struct RsghmcOp {
         load_part(theta, q, cnt, R.th); load_part(p, q, cnt, R.p); load_part(grad, q, cnt, R.gr);
         if (INJECT) load_part(xi, q, cnt, R.z);
     }
+    __device__ __forceinline__ T over_m2c2(T x) const { return POW2 ? x * inv_m2c2 : x / m2c2; }
     __device__ __forceinline__ void compute(size_t q, Regs &R) const
     {
         if (!INJECT) normal_quad(nk, q, R.z);
@@ -412,10 +418,10 @@ struct RsghmcOp {
         for (int j = 0; j < 4; ++j) {
             T p0 = R.p[j];
             T gl = -((grad_decay != T(0)) ? R.gr[j] + grad_decay * R.th[j] : R.gr[j]);           // :100-103
-            T pg = (eps * p0) / (mass * rsqrt_rn<T>((p0 * p0) / m2c2 + T(1)));           // :123
+            T pg = (eps * p0) / (mass * rsqrt_rn<T>(over_m2c2(p0 * p0) + T(1)));         // :123
             T nz = nscale * R.z[j];                                                      // :125
             T p1 = p0 + (((eps * gl) + nz) - (D * pg));                                  // :126-129
-            T pg1 = (eps * p1) / (mass * rsqrt_rn<T>((p1 * p1) / m2c2 + T(1)));          // :131
+            T pg1 = (eps * p1) / (mass * rsqrt_rn<T>(over_m2c2(p1 * p1) + T(1)));        // :131
             R.p[j] = p1;
             R.th[j] = R.th[j] + pg1;                                                     // :132-135
         }

@@ -36,13 +36,20 @@ int rsghmc_step(T *theta, T *p, const T *grad, size_t n, T eps, T mass, T c, T D
                   aligned16(se.ex.mom_mean) && aligned16(se.ex.mom_m2);
     bool mom_done = false;
     int rc;
-    if (xi) {
-        RsghmcOp<T, false, true> op{theta, p, grad, xi, s[0], s[1], s[2], s[3], s[4], grad_decay, nk, sp, sdev};
-        rc = launch<RsghmcOp<T, false, true>, false>(op, n, vec_ok, sizeof(T) * 6, lc, se, &mom_done, st);
-    } else {
-        RsghmcOp<T, false, false> op{theta, p, grad, xi, s[0], s[1], s[2], s[3], s[4], grad_decay, nk, sp, sdev};
-        rc = launch<RsghmcOp<T, false, false>, true>(op, n, vec_ok, sizeof(T) * 5, lc, se, &mom_done, st);
+    // m^2 c^2 a power of two (the default m = c = 1): the divisions by it are exact multiplications (RsghmcOp POW2). Not with
+    // device-resident scalars: the block may be refreshed with another mass / c after this launch was captured.
+    int e2 = 0;
+    const T inv = T(1) / s[3];
+    const bool pow2 = sdev == nullptr && s[3] > T(0) && std::isfinite(s[3]) && std::frexp(s[3], &e2) == T(0.5) &&
+                      std::isnormal(inv) && std::isnormal(s[3]);
+#define RSGHMC_GO(P2, INJ)                                                                                        \
+    {                                                                                                             \
+        RsghmcOp<T, P2, INJ> op{theta, p, grad, xi, s[0], s[1], s[2], s[3], s[4], grad_decay, nk, sp, sdev, inv};  \
+        rc = launch<RsghmcOp<T, P2, INJ>, !INJ>(op, n, vec_ok, sizeof(T) * (INJ ? 6 : 5), lc, se, &mom_done, st);  \
     }
+    if (pow2) { if (xi) RSGHMC_GO(true, true) else RSGHMC_GO(true, false) }
+    else { if (xi) RSGHMC_GO(false, true) else RSGHMC_GO(false, false) }
+#undef RSGHMC_GO
     if (rc == 0 && se.want_moments && !mom_done) {
         MomentsOp<T> mop{theta, se.ex.mom_mean, se.ex.mom_m2, se.ex.mom_inv};
         sgmcmc_launch_t lc_mom = lc ? *lc : sgmcmc_launch_t{};      // same geometry, but NOT the caller's timestamp events: they

@@ -35,6 +35,7 @@ MODES = {
     "SgldOp<float, false, false>": ("sgld_frozen", 12, 4),
     "SgldOp<float, true, false>": ("sgld_adapt", 20, 20),
     "RsghmcOp<float, false, false>": ("rsghmc", 12, 8),
+    "RsghmcOp<float, true, false>": ("rsghmc", 12, 8),       # POW2: m^2 c^2 a power of two (the default m = c = 1)
 }
 
 
