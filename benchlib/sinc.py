@@ -163,7 +163,7 @@ def run_sinc(args, dev, rank, world, dist):
                                "%d steps per launch; 1 chain per GPU" % (n, CHUNK),
                    "params": n, "batch": BATCH_SINC, "chains": world, "steps_per_launch": CHUNK},
         "modes_samples_per_s": modes,
-        "roofline": {"bound": "hbm", "kernel": "bnn_fused_steps_kernel<float, SGHMC> (ONE 1024-lane workgroup per chain)",
+        "roofline": {"bound": "hbm", "kernel": "bnn_fused_sghmc_kernel<float, 0> (ONE 1024-lane workgroup per chain)",
                      "achieved": round(alg_bytes / (us_per_step * 1e-6) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg_bytes / (us_per_step * 1e-6) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
                      "algorithmic_bytes_per_step": alg_bytes, "us_per_step": round(us_per_step, 2),
