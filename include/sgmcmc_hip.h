@@ -403,18 +403,37 @@ int sgmcmc_bias_tanh_rowdot_f64(double *a, const double *bias, const double *w, 
 int sgmcmc_bias_tanh_f32(float *a, const float *bias, size_t rows, size_t cols, sgmcmc_stream_t stream);
 int sgmcmc_bias_tanh_f64(double *a, const double *bias, size_t rows, size_t cols, sgmcmc_stream_t stream);
 
+/* A hidden layer of the BNN forward pass in ONE launch (the Dense(tanh) layers of
+ * pysgmcmc/models/bayesian_neural_network.py:30-52): fp32 matrix-core product with the activation as its epilogue,
+ *   out[m][n] = tanh( sum_k h[m][k] W[k][n] + bias[n] )
+ * replacing library GEMM + sgmcmc_bias_tanh_f32 (two launches). h [M = batch][ldh >= K], W [K][ldw >= N] (the layer's
+ * kernel as it lies in the arena), out [M][ldo >= N], all row-major.
+ *   w_next, dot_parts: both NULL, or the single output unit's weights [N] and a [N / 64][M] buffer: the launch also leaves
+ *     dot_parts[t][m] = sum over the 64 columns n of column tile t of out[m][n] * w_next[n] (fixed order) -- the Dense(1)
+ *     layer of :53-56; sgmcmc_bnn_head_last_layer_backward_* adds the N / 64 partials per row (n_mean_parts = N / 64).
+ *   stats_ws, tsq_parts: both NULL, or as in sgmcmc_tanh_rowdot_*: workgroups 0 .. 15 add up one slice each of the
+ *     sum(theta^2) records of the previous step kernel (needs M / 32 * N / 64 >= 16 workgroups).
+ * M % 32 == 0, N % 64 == 0, K % 16 == 0, K >= 64; every row 16-byte aligned (ld* % 4 == 0); operands < 2 GiB each.
+ * One workgroup per 32 x 64 output tile, ONE per CU: meant for M * N / 2048 <= the CU count (batch 256 x 2048 columns).
+ * fp32 MFMA is an exact k-ordered fmaf chain: results differ from a library GEMM in summation order only; deterministic.  */
+int sgmcmc_bnn_dense_tanh_f32(const float *h, const float *W, const float *bias, float *out, int M, int N, int K, int ldh,
+                              int ldw, int ldo, const float *w_next, float *dot_parts, const void *stats_ws, double *tsq_parts,
+                              sgmcmc_stream_t stream);
+
 /* sgmcmc_bnn_head_* and sgmcmc_bnn_last_layer_backward_* in ONE launch (every dependent launch of the step costs
- * ~5 us): `mean` [rows] is the single-output layer's pre-bias output (sgmcmc_tanh_rowdot_*), tsq_parts the slices of
- * sum(theta^2) it left; d cost/d mean is formed on the fly by every workgroup, workgroup 0 writes the head's scalar
- * outputs. Arguments as in the two separate entry points (fold_prior_grad: the same bit mask).                    */
+ * ~5 us): `mean` [n_mean_parts][rows] is the single-output layer's pre-bias output -- n_mean_parts = 1: the vector
+ * sgmcmc_tanh_rowdot_* writes; > 1: the per-column-tile partial dot products sgmcmc_bnn_dense_tanh_f32 writes, added here
+ * in order (rows <= 1024) --, tsq_parts the slices of sum(theta^2) that launch left; d cost/d mean is formed on the fly by
+ * every workgroup, workgroup 0 writes the head's scalar outputs. Arguments as in the two separate entry points
+ * (fold_prior_grad: the same bit mask).                                                                            */
 int sgmcmc_bnn_head_last_layer_backward_f32(
-    const float *mean, const float *y, const float *log_var, const double *tsq_parts, const float *last_bias, size_t rows,
+    const float *mean, size_t n_mean_parts, const float *y, const float *log_var, const double *tsq_parts, const float *last_bias, size_t rows,
     size_t cols, double batch_size, double n_examples, double n_params, double wdecay, double prior_mean, double prior_var,
     int fold_prior_grad, const float *w, const float *h, const float *bias_prev, float beta, float *cost_out,
     float *grad_log_var_out, float *grad_last_bias_out, float *mse_out, float *delta_prev, float *colsum, float *gw,
     sgmcmc_stream_t stream);
 int sgmcmc_bnn_head_last_layer_backward_f64(
-    const double *mean, const double *y, const double *log_var, const double *tsq_parts, const double *last_bias, size_t rows,
+    const double *mean, size_t n_mean_parts, const double *y, const double *log_var, const double *tsq_parts, const double *last_bias, size_t rows,
     size_t cols, double batch_size, double n_examples, double n_params, double wdecay, double prior_mean, double prior_var,
     int fold_prior_grad, const double *w, const double *h, const double *bias_prev, double beta, double *cost_out,
     double *grad_log_var_out, double *grad_last_bias_out, double *mse_out, double *delta_prev, double *colsum, double *gw,

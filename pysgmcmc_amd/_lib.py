@@ -26,7 +26,7 @@ def lib_path():
 def build(force=False):
     """Compile ``csrc/libsgmcmc_hip.so`` for gfx950 with hipcc (no GPU needed)."""
     import subprocess
-    deps = [os.path.join(_CSRC, f) for f in ("sgmcmc_kernels.hip", "sgmcmc_sghmc.hip", "sgmcmc_sgld.hip", "sgmcmc_rsghmc.hip", "sgmcmc_toy.hip", "sgmcmc_stream.hpp", "sgmcmc_bnn_fused.hip", "sgmcmc_svgd.hip", "sgmcmc_device.hpp",
+    deps = [os.path.join(_CSRC, f) for f in ("sgmcmc_kernels.hip", "sgmcmc_sghmc.hip", "sgmcmc_sgld.hip", "sgmcmc_rsghmc.hip", "sgmcmc_toy.hip", "sgmcmc_bnn_gemm.hip", "sgmcmc_stream.hpp", "sgmcmc_bnn_fused.hip", "sgmcmc_svgd.hip", "sgmcmc_device.hpp",
                                              "sgmcmc_host.hpp")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "sgmcmc_hip.h"))
     stale = (not os.path.exists(_LIB_PATH)
@@ -141,7 +141,7 @@ def _declare(lib):
         f.argtypes = [_vp, _vp, _sz, _sz, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_bnn_head_last_layer_backward_" + sfx)
-        f.argtypes = ([_vp] * 5 + [_sz, _sz] + [ctypes.c_double] * 6 + [_ci, _vp, _vp, _vp, real] + [_vp] * 7 + [_vp])
+        f.argtypes = ([_vp, _sz] + [_vp] * 4 + [_sz, _sz] + [ctypes.c_double] * 6 + [_ci, _vp, _vp, _vp, real] + [_vp] * 7 + [_vp])
         f.restype = _ci
         f = getattr(lib, "sgmcmc_window_gather_" + sfx)
         f.argtypes = [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]
@@ -159,6 +159,8 @@ def _declare(lib):
         f = getattr(lib, "sgmcmc_summary_" + sfx)
         f.argtypes = [_vp, _sz, _vp, _vp, _vp]
         f.restype = _ci
+    lib.sgmcmc_bnn_dense_tanh_f32.argtypes = [_vp] * 4 + [_ci] * 6 + [_vp] * 5
+    lib.sgmcmc_bnn_dense_tanh_f32.restype = _ci
     lib.sgmcmc_philox_bits_u32.argtypes = [_vp, _sz, _u64, _u64, _vp, _vp]
     lib.sgmcmc_counter_add_u64.argtypes = [_vp, _u64, _vp]
     lib.sgmcmc_counter_add_u64.restype = _ci

@@ -1,0 +1,314 @@
+// sgmcmc_bnn_gemm.hip -- a hidden layer of the BNN forward pass (pysgmcmc/models/bayesian_neural_network.py:30-52) as ONE launch:
+// fp32 matrix-core product with bias + tanh (and, for the last hidden layer, the single output unit's dot product) as its epilogue.
+//
+//   out[m][n] = tanh( sum_k h[m][k] W[k][n] + b[n] )            h [M = batch][K], W [K][N] row-major (the arena's layout)
+//   dot_parts[t][m] = sum_{n in column tile t} out[m][n] w_next[n]   (optional; the Dense(1) layer of :53-56, added up by the loss head)
+//
+// Replaces library GEMM + sgmcmc_bias_tanh_f32 (+ sgmcmc_bias_tanh_rowdot_f32 for the last hidden layer). In isolation it
+// only ties that pair on the 2048 x 2048 layer (19.5-20.2 vs 21.1-21.5 us; it was an experiment that missed its gate, see
+// tools/gpu/bnn_dense_tanh.hip and profiles/r04_fwd_epilogue_probe.txt for everything tried on the way), but in the sampler's
+// step two launches per layer become one and the 10 M-parameter chain goes from 195.1 to 188.6 us per step with the first two
+// hidden layers on it (tools/fwd_fused_step_probe.py).
+//
+// Decomposition for M = 256: the output is 512 MFMA tiles of 32 x 32 for 1024 SIMDs, so K must be split; a workgroup (ONE per
+// CU, 8 waves = 2 per SIMD) owns a 32 x 64 output tile = 2 MFMA tiles x 4 quarters of every 64-deep K chunk and adds the
+// quarters through LDS in a fixed order before the epilogue -- the sums are complete inside the workgroup, which is what lets
+// the activation ride in the launch (and keeps the result bit-reproducible).
+// Operands go from global memory DIRECTLY into LDS (buffer_load_dwordx4 ... lds) into a ring of NS stages (A 32 x 64, B 64 x 64
+// floats = 24 KB), NS - 2 chunks in flight across bare s_barriers with counted vmcnt waits; the fragments of chunk c + 1 are
+// read from LDS while the MFMAs of chunk c issue.
+//   * fp32 MFMA and vector-ALU instructions share the SIMD's lanes: every VALU instruction in the K loop is MFMA time. The
+//     loads are therefore BUFFER loads -- one constant 32-bit per-lane offset + a scalar chunk offset + a scalar descriptor: no
+//     per-lane address arithmetic at all (64-bit global addresses cost 3.5 us of 23.9) -- and the loop is unrolled by the ring
+//     depth, so LDS addresses are a per-lane register + an immediate and M0 a constant.
+//   * A (k contiguous in memory): LDS image [m][64 k], 16-byte quads XOR-swizzled with m & 15 -- applied to the per-lane GLOBAL
+//     offset, the LDS side of a direct load is lane-linear -- so that ds_read_b128 of 4 k values per lane is conflict-free; a
+//     lane's 8 k values feed 8 MFMAs (the k order inside a chunk is permuted, a sum over k does not care).
+//   * B (n contiguous): LDS image [k][64 n], one ds_read_b32 per MFMA, 32 consecutive lanes = 32 consecutive banks.
+//   * two accumulators per wave (alternating MFMAs, added in the epilogue): consecutive MFMAs are independent.
+// Workgroup -> tile map is XCD-aware (workgroup b runs on XCD b % 8): every XCD owns a contiguous range of column tiles, so
+// each slice of W is pulled into exactly one XCD's L2.
+//
+// fp32 MFMA is an exact fmaf chain (MI355X_MICROARCH.md): the product differs from a library GEMM in summation order only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <type_traits>
+
+#include "sgmcmc_hip.h"
+
+#pragma clang fp contract(off)
+
+#include "sgmcmc_host.hpp"
+
+using namespace sgmcmc_host;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 32, BN = 64, BK = 64;
+constexpr int KQ = 4;                                       // K quarters of a chunk = partial tiles the epilogue adds
+constexpr int TP = BN + 4;                                  // pitch of the accumulator tiles in LDS (floats)
+constexpr int TSQ_SLICES = 16;                              // as sgmcmc_kernels.hip: slices of the sum(theta^2) partials
+
+// s_waitcnt immediate on gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14; expcnt / lgkmcnt = no wait
+constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm()
+{
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(N));
+}
+
+// at most `chunks` chunks (3 direct loads per wave each) may still be in flight
+template <int MAXC>
+__device__ __forceinline__ void wait_chunks_in_flight(int chunks)
+{
+    if constexpr (MAXC == 0) {
+        wait_vm<0>();
+    } else {
+        if (chunks >= MAXC) wait_vm<3 * MAXC>();
+        else wait_chunks_in_flight<MAXC - 1>(chunks);
+    }
+}
+
+struct FwdArgs {
+    const float *h, *W, *bias;
+    float *out;
+    const float *w_next;        // nullable
+    float *dot_parts;           // [N / 64][M]
+    const double *stats_ws;     // nullable: statistics workspace of the previous step kernel ...
+    double *tsq_parts;          // ... whose sum(theta^2) records workgroups 0 .. 15 add up into 16 slices
+    int M, N, K, ldh, ldw, ldo;
+};
+
+template <int NS>
+struct __attribute__((aligned(16))) FwdLds {
+    union {
+        struct {
+            float A[NS][BM][BK];
+            float B[NS][BK][BN];
+        } ring;
+        float T[KQ][BM][TP];
+        double red[8];
+    };
+};
+
+__device__ __forceinline__ float tanh_f32(float x) { return tanhf(x); }      // the activation launch's own tanh
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// sum over the 16 lanes of a DPP row; the total arrives in the row's lane 15 (fixed order)
+__device__ __forceinline__ float row16_sum_lane15(float v)
+{
+    v += dpp_mov<0x111>(v);     // row_shr:1
+    v += dpp_mov<0x112>(v);     // row_shr:2
+    v += dpp_mov<0x114>(v);     // row_shr:4
+    v += dpp_mov<0x118>(v);     // row_shr:8
+    return v;
+}
+
+template <int NS>
+__global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
+{
+    static_assert(NS >= 4 && NS % 2 == 0, "ring: one chunk being read, one landing, one free; unrolled by NS with two fragment sets");
+    constexpr int D = NS - 1;                               // chunk kc + D is requested in iteration kc
+    __shared__ FwdLds<NS> lds;                              // ONE shared object (a second one de-pipelines the direct loads)
+    static_assert(sizeof(lds.ring) >= sizeof(lds.T), "the accumulator tiles reuse the ring");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = wave & 1, kq = wave >> 1;                // this wave's MFMA tile (columns 32 nt ...) and quarter of every chunk
+    // ---- workgroup -> tile, XCD-aware: XCD x owns tiles [x T/8, (x+1) T/8), consecutive tiles share the column tile
+    const int tiles_m = g.M / BM, tiles = tiles_m * (g.N / BN);
+    int t = blockIdx.x;
+    if (tiles % 8 == 0) t = (t & 7) * (tiles >> 3) + (t >> 3);
+    const int n0 = (t / tiles_m) * BN, m0 = (t % tiles_m) * BM;
+    const int nk = (g.K + BK - 1) / BK;                     // K % 16 == 0: the last chunk may hold 16, 32 or 48 valid k only
+    // ---- direct loads: wave w requests 4 rows of A (256 B each) and 2 x 4 rows of B per chunk
+    const int ar = 4 * wave + (lane >> 4);                  // A row of this lane's 16 bytes
+    const int aq = (lane & 15) ^ (ar & 15);                 // logical quad stored at physical slot lane & 15
+    const int br = 8 * wave + (lane >> 4);                  // B rows br, br + 4
+    const unsigned a_lane = (unsigned)(ar * g.ldh + 4 * aq) * 4u;
+    const unsigned b_lane = (unsigned)(br * g.ldw + 4 * (lane & 15)) * 4u;
+    const unsigned b_chunk = (unsigned)BK * (unsigned)g.ldw * 4u, b_rows4 = 4u * (unsigned)g.ldw * 4u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(g.h + (size_t)m0 * g.ldh), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.W + n0), 0, 0x7fffffff, 0x00020000);
+#endif
+    auto issue = [&](int kc, int st) {                      // chunks that lie wholly below K: scalar offsets only
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned sa = (unsigned)kc * (BK * 4), sb = (unsigned)kc * b_chunk;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, &lds.ring.A[st][4 * wave][0], 16, a_lane, sa, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave][0], 16, b_lane, sb, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave + 4][0], 16, b_lane, sb + b_rows4, 0, 0);
+#endif
+    };
+    auto issue_clamped = [&](int kc, int st) {              // prologue / last chunks: beyond K any valid address will do (never used)
+#if defined(__HIP_DEVICE_COMPILE__)
+        int ka = kc * BK + 4 * aq, kb0 = kc * BK + br, kb1 = kc * BK + br + 4;
+        if (ka + 4 > g.K) ka = g.K - 4;
+        if (kb0 >= g.K) kb0 = g.K - 1;
+        if (kb1 >= g.K) kb1 = g.K - 1;
+        const unsigned va = (unsigned)(ar * g.ldh + ka) * 4u, c4 = 4u * (unsigned)(lane & 15) * 4u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, &lds.ring.A[st][4 * wave][0], 16, va, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave][0], 16, (unsigned)kb0 * (unsigned)g.ldw * 4u + c4, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave + 4][0], 16, (unsigned)kb1 * (unsigned)g.ldw * 4u + c4, 0, 0, 0);
+#endif
+    };
+    // ---- fragment addresses
+    const int fm = lane & 31, kl = lane >> 5;
+    const int sw = fm & 15;
+    const int aoff0 = fm * BK + 4 * ((4 * kq + 2 * kl) ^ sw), aoff1 = fm * BK + 4 * ((4 * kq + 2 * kl + 1) ^ sw);
+    const int boff = (16 * kq + 8 * kl) * BN + 32 * nt + fm;
+    struct Frag {
+        f32x4_t a0, a1;
+        float b[8];
+    };
+    auto read_frags = [&](int st, Frag &f) {
+        const float *A = &lds.ring.A[st][0][0];
+        const float *B = &lds.ring.B[st][0][0];
+        f.a0 = *reinterpret_cast<const f32x4_t *>(A + aoff0);
+        f.a1 = *reinterpret_cast<const f32x4_t *>(A + aoff1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.b[j] = B[boff + j * BN];
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    auto mfmas = [&](const Frag &f, int j0, int j1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j >= j0 && j < j1) {
+                const float a = j < 4 ? f.a0[j & 3] : f.a1[j & 3];
+                if (!(j & 1)) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f.b[j], acc0, 0, 0, 0);
+                else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f.b[j], acc1, 0, 0, 0);
+            }
+    };
+    // ---- prologue: chunks 0 .. D - 1 requested ...
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+        if (c < nk) issue_clamped(c, c);
+    // ... and while they fly, the side job of the last hidden layer's launch: workgroups 0 .. 15 add up one contiguous slice
+    // each of the sum(theta^2) records the previous step kernel left in its statistics workspace (the loss head adds the
+    // slices in order: same arithmetic as sgmcmc_bias_tanh_rowdot_*'s side job)
+    double tsq = 0.0;
+    const unsigned n_slices = gridDim.x < (unsigned)TSQ_SLICES ? gridDim.x : (unsigned)TSQ_SLICES;
+    const bool slicer = g.stats_ws != nullptr && blockIdx.x < n_slices;
+    if (slicer) {
+        const unsigned nparts = (unsigned)reinterpret_cast<const unsigned long long *>(g.stats_ws)[0];
+        const double *__restrict__ p = g.stats_ws + 4;
+        const unsigned len = (nparts + n_slices - 1) / n_slices;
+        const unsigned lo = blockIdx.x * len, hi = (lo + len < nparts) ? lo + len : nparts;
+        for (unsigned i = lo + tid; i < hi; i += 512) tsq += p[4 * (size_t)i];      // statistic 0 of record i
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) tsq += __shfl_down(tsq, off, 64);
+    }
+    wait_chunks_in_flight<D - 1>(nk - 1);
+    __builtin_amdgcn_s_barrier();
+    Frag fa, fb;
+    read_frags(0, fa);
+    // One iteration: chunk kc + 1 is waited for and read from LDS (into the other fragment set) while the MFMAs of chunk kc
+    // issue. The steady state is unrolled by NS: ring stages are compile-time constants and the two fragment sets swap roles
+    // without register copies.
+    auto steady = [&](int kc, const Frag &cur, Frag &nxt, auto stage) {
+        constexpr int I = decltype(stage)::value;           // kc % NS
+        wait_vm<3 * (D - 2)>();                             // chunk kc + 1 landed: chunks kc + 2 .. kc + D - 1 may be in flight
+        __builtin_amdgcn_s_barrier();                       // ... for every wave; and the stage of chunk kc - 1 is free
+        mfmas(cur, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(kc + D, (I + D) % NS);
+        read_frags((I + 1) % NS, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(cur, 2, 8);
+    };
+    int kc = 0;
+    for (; kc + D + NS < nk; kc += NS) {                    // every chunk requested here (up to kc + NS - 1 + D) lies wholly below K
+        steady(kc, fa, fb, std::integral_constant<int, 0>());
+        steady(kc + 1, fb, fa, std::integral_constant<int, 1>());
+        steady(kc + 2, fa, fb, std::integral_constant<int, 2>());
+        steady(kc + 3, fb, fa, std::integral_constant<int, 3>());
+    }
+    int st_read = 1, st_issue = D % NS;                     // kc % NS == 0 here: stage of chunk kc + 1, stage of chunk kc + D
+    for (; kc + 1 < nk; ++kc) {                             // the last chunks: counted waits, the (possibly short) last chunk requested
+        wait_chunks_in_flight<D - 2>(nk - 2 - kc);
+        __builtin_amdgcn_s_barrier();
+        mfmas(fa, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kc + D < nk) issue_clamped(kc + D, st_issue);
+        read_frags(st_read, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fa, 2, 8);
+        fa = fb;
+        st_read = st_read + 1 == NS ? 0 : st_read + 1;
+        st_issue = st_issue + 1 == NS ? 0 : st_issue + 1;
+    }
+    // last chunk: only the quarters that lie below K exist
+    if ((nk - 1) * BK + 16 * kq < g.K) mfmas(fa, 0, 8);
+    // ---- epilogue: the four K quarters meet in LDS (fixed order), bias + tanh on row-major quads, 16-byte stores
+    __syncthreads();                                        // every fragment read is done: the ring is free
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds.T[kq][(r & 3) + 8 * (r >> 2) + 4 * kl][32 * nt + fm] = acc0[r] + acc1[r];
+    __syncthreads();
+    {
+        const int row = tid >> 4, c4 = (tid & 15) * 4;
+        f32x4_t s = *reinterpret_cast<const f32x4_t *>(&lds.T[0][row][c4]);
+#pragma unroll
+        for (int p = 1; p < KQ; ++p) {
+            const f32x4_t sp = *reinterpret_cast<const f32x4_t *>(&lds.T[p][row][c4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += sp[j];
+        }
+        const f32x4_t b = *reinterpret_cast<const f32x4_t *>(g.bias + n0 + c4);
+        f32x4_t v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = tanh_f32(s[j] + b[j]);
+        *reinterpret_cast<f32x4_t *>(g.out + (size_t)(m0 + row) * g.ldo + n0 + c4) = v;
+        if (g.w_next != nullptr) {
+            const f32x4_t w = *reinterpret_cast<const f32x4_t *>(g.w_next + n0 + c4);
+            float d = ((v[0] * w[0] + v[1] * w[1]) + v[2] * w[2]) + v[3] * w[3];
+            d = row16_sum_lane15(d);                        // the 16 lanes of a DPP row hold one tile row
+            if ((lane & 15) == 15) g.dot_parts[(size_t)(n0 / BN) * g.M + m0 + row] = d;
+        }
+    }
+    if (slicer) {                                           // uniform per workgroup
+        __syncthreads();                                    // T has been consumed: red (same union) may be written
+        if (lane == 0) lds.red[wave] = tsq;
+        __syncthreads();
+        if (tid == 0)
+            g.tsq_parts[blockIdx.x] = ((((((lds.red[0] + lds.red[1]) + lds.red[2]) + lds.red[3]) + lds.red[4]) + lds.red[5]) + lds.red[6]) + lds.red[7];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* see include/sgmcmc_hip.h */
+int sgmcmc_bnn_dense_tanh_f32(const float *h, const float *W, const float *bias, float *out, int M, int N, int K, int ldh,
+                              int ldw, int ldo, const float *w_next, float *dot_parts, const void *stats_ws, double *tsq_parts,
+                              sgmcmc_stream_t stream)
+{
+    if (!h || !W || !bias || !out || ((w_next != nullptr) != (dot_parts != nullptr)) || ((stats_ws != nullptr) != (tsq_parts != nullptr)))
+        return fail(SGMCMC_EINVAL, "bnn_dense_tanh: NULL argument (w_next / dot_parts and stats_ws / tsq_parts go together)");
+    if (M <= 0 || N <= 0 || K < 64 || M % BM || N % BN || K % 16 || ldh < K || ldw < N || ldo < N || ldh % 4 || ldw % 4 || ldo % 4 ||
+        ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(bias) |
+          reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(w_next)) & 15u))
+        return fail(SGMCMC_EINVAL, "bnn_dense_tanh: needs M %% 32 == 0, N %% 64 == 0, K %% 16 == 0, K >= 64, 16-byte aligned rows");
+    if ((double)K * ldw * 4.0 >= 2147483648.0 || (double)M * ldh * 4.0 >= 2147483648.0)
+        return fail(SGMCMC_EINVAL, "bnn_dense_tanh: an operand spans more than 2 GiB (32-bit buffer offsets)");
+    FwdArgs g{h, W, bias, out, w_next, dot_parts, static_cast<const double *>(stats_ws), tsq_parts, M, N, K, ldh, ldw, ldo};
+    const int tiles = (M / BM) * (N / BN);
+    hipLaunchKernelGGL((bnn_dense_tanh_kernel<4>), dim3(tiles), dim3(512), 0, static_cast<hipStream_t>(stream), g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch bnn_dense_tanh");
+}
+
+}  // extern "C"

@@ -508,9 +508,10 @@ __global__ void __launch_bounds__(1024) last_layer_backward_kernel(const T *__re
 // function of the residual and the scalar log-variance only, so every workgroup forms it on the fly; workgroup 0 also
 // reduces the residuals and writes the head's scalar outputs (cost, d cost/d log_var, mse, last bias gradient).
 // sum(theta^2) arrives as the n_tsq slices tanh_rowdot_kernel left in tsq_parts. One launch less per step.
+constexpr int HEAD_MAX_PART_ROWS = 1024;                     // batch rows when the mean arrives as partial dot products
 template <typename T>
 __global__ void __launch_bounds__(1024) head_last_layer_backward_kernel(
-    const T *__restrict__ mean, const T *__restrict__ y, const T *__restrict__ s_ptr, const double *__restrict__ tsq_parts,
+    const T *__restrict__ mean_parts, int n_mean_parts, const T *__restrict__ y, const T *__restrict__ s_ptr, const double *__restrict__ tsq_parts,
     int n_tsq, const T *__restrict__ last_bias, BnnHeadConsts k, T *__restrict__ cost_out, T *__restrict__ grad_s_out,
     T *__restrict__ grad_bias_out, T *__restrict__ mse_out, const T *__restrict__ w, const T *__restrict__ h, size_t rows,
     size_t cols, const T *__restrict__ bias_prev, T beta, T *__restrict__ delta_prev, T *__restrict__ colsum,
@@ -518,7 +519,32 @@ __global__ void __launch_bounds__(1024) head_last_layer_backward_kernel(
 {
     __shared__ T lds[2][16][CS_COLS];
     __shared__ double lds_h[2][16];
+    __shared__ T mean_lds[HEAD_MAX_PART_ROWS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the output unit's pre-bias mean: a plain vector, or n_mean_parts partial dot products per row (what
+    // sgmcmc_bnn_dense_tanh_f32 leaves: one per 64-column tile), added here in a fixed order by every workgroup
+    const T *__restrict__ mean = mean_parts;
+    if (n_mean_parts > 1) {
+        // four adjacent lanes per row, each adds a contiguous quarter of the parts (its loads issued four at a time, not one
+        // dependent round trip per part), then the quarters are added in lane order: a fixed summation order
+        const int per = (n_mean_parts + 3) / 4;
+        for (size_t i = threadIdx.x; i < 4 * rows; i += blockDim.x) {   // rows <= 1024: whole waves enter each trip
+            const size_t r = i >> 2;
+            const int q = (int)(i & 3), lo = q * per, hi = (lo + per < n_mean_parts) ? lo + per : n_mean_parts;
+            T m = T(0);
+            int p = lo;
+            for (; p + 4 <= hi; p += 4) {
+                const T v0 = mean_parts[(size_t)p * rows + r], v1 = mean_parts[(size_t)(p + 1) * rows + r];
+                const T v2 = mean_parts[(size_t)(p + 2) * rows + r], v3 = mean_parts[(size_t)(p + 3) * rows + r];
+                m = (((m + v0) + v1) + v2) + v3;
+            }
+            for (; p < hi; ++p) m += mean_parts[(size_t)p * rows + r];
+            const T m1 = __shfl_down(m, 1, 64), m2 = __shfl_down(m, 2, 64), m3 = __shfl_down(m, 3, 64);
+            if (q == 0) mean_lds[r] = ((m + m1) + m2) + m3;
+        }
+        __syncthreads();
+        mean = mean_lds;
+    }
     const double s = (double)*s_ptr;
     const double es = exp(s);
     const double inv = 1.0 / (es + 1e-16);                       // :369
@@ -703,7 +729,7 @@ int last_layer_backward_impl(const T *dvec, const T *w, const T *h, size_t rows,
 }
 
 template <typename T>
-int head_last_layer_backward_impl(const T *mean, const T *y, const T *s_ptr, const double *tsq_parts, const T *last_bias,
+int head_last_layer_backward_impl(const T *mean, size_t n_mean_parts, const T *y, const T *s_ptr, const double *tsq_parts, const T *last_bias,
                                   size_t rows, size_t cols, double batch_size, double n_examples, double n_params,
                                   double wdecay, double prior_mean, double prior_var, int flags, const T *w, const T *h,
                                   const T *bias_prev, T beta, T *cost_out, T *grad_s_out, T *grad_bias_out, T *mse_out,
@@ -712,6 +738,8 @@ int head_last_layer_backward_impl(const T *mean, const T *y, const T *s_ptr, con
     if (!mean || !y || !s_ptr || !tsq_parts || !w || !h || !cost_out || !grad_s_out || !mse_out || !delta_prev || !colsum ||
         !gw || rows == 0 || cols == 0 || (grad_bias_out && !last_bias) || (beta != T(0) && !bias_prev))
         return fail(SGMCMC_EINVAL, "bnn_head_last_layer_backward: NULL argument or empty matrix");
+    if (n_mean_parts == 0 || n_mean_parts > 4096 || (n_mean_parts > 1 && rows > (size_t)HEAD_MAX_PART_ROWS))
+        return fail(SGMCMC_EINVAL, "bnn_head_last_layer_backward: n_mean_parts must be 1 .. 4096 (and rows <= 1024 when > 1)");
     BnnHeadConsts k;
     k.batch_size = batch_size; k.n_examples = n_examples; k.wdecay = wdecay;
     k.wp_den = n_params + (2.0 * 1e-16 + 1e-16);                 /* safe_divide, n_params > 0 */
@@ -719,9 +747,11 @@ int head_last_layer_backward_impl(const T *mean, const T *y, const T *s_ptr, con
     k.ln_prior_mean = std::log(prior_mean); k.ln_prior_var = std::log(prior_var);
     k.fold_prior_grad = (flags & 1) ? 1 : 0;
     k.add_last_bias = (flags & 2) ? 1 : 0;
-    const int n_tsq = (int)(rows < (size_t)TSQ_SLICES ? rows : (size_t)TSQ_SLICES);   // what tanh_rowdot wrote (one workgroup per row)
+    // slices of sum(theta^2) the forward launch left: min(16, its workgroups) -- one workgroup per row (tanh_rowdot), or per
+    // 32 x 64 output tile (bnn_dense_tanh, which callers use only with >= 16 tiles)
+    const int n_tsq = (int)((n_mean_parts > 1 || rows >= (size_t)TSQ_SLICES) ? (size_t)TSQ_SLICES : rows);
     hipLaunchKernelGGL((head_last_layer_backward_kernel<T>), dim3((unsigned)((cols + CS_COLS - 1) / CS_COLS)), dim3(1024), 0, st,
-                       mean, y, s_ptr, tsq_parts, n_tsq, last_bias, k, cost_out, grad_s_out, grad_bias_out, mse_out, w, h,
+                       mean, (int)n_mean_parts, y, s_ptr, tsq_parts, n_tsq, last_bias, k, cost_out, grad_s_out, grad_bias_out, mse_out, w, h,
                        rows, cols, bias_prev, beta, delta_prev, colsum, gw);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch head_last_layer_backward");
@@ -939,13 +969,13 @@ SGMCMC_WINDOW_GATHER(f64, double)
         return e == hipSuccess ? 0 : hip_fail(e, "launch bias_tanh");                                                \
     }                                                                                                                \
     int sgmcmc_bnn_head_last_layer_backward_##SFX(                                                                   \
-        const T *mean, const T *y, const T *log_var, const double *tsq_parts, const T *last_bias, size_t rows,       \
-        size_t cols, double batch_size, double n_examples, double n_params, double wdecay, double prior_mean,        \
+        const T *mean, size_t n_mean_parts, const T *y, const T *log_var, const double *tsq_parts, const T *last_bias, \
+        size_t rows, size_t cols, double batch_size, double n_examples, double n_params, double wdecay, double prior_mean,        \
         double prior_var, int fold_prior_grad, const T *w, const T *h, const T *bias_prev, T beta, T *cost_out,      \
         T *grad_log_var_out, T *grad_last_bias_out, T *mse_out, T *delta_prev, T *colsum, T *gw,                     \
         sgmcmc_stream_t stream)                                                                                      \
     {                                                                                                                \
-        return head_last_layer_backward_impl<T>(mean, y, log_var, tsq_parts, last_bias, rows, cols, batch_size,      \
+        return head_last_layer_backward_impl<T>(mean, n_mean_parts, y, log_var, tsq_parts, last_bias, rows, cols, batch_size, \
                                                 n_examples, n_params, wdecay, prior_mean, prior_var, fold_prior_grad, \
                                                 w, h, bias_prev, beta, cost_out, grad_log_var_out,                   \
                                                 grad_last_bias_out, mse_out, delta_prev, colsum, gw,                 \

@@ -16,7 +16,7 @@ __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
     "LaunchConfig", "KernelEvents", "StepOpts", "step_stats_records", "step_scalars", "toy_chains", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
-    "bnn_fused_sgld_steps", "window_gather", "tanh_rowdot", "bias_tanh", "bnn_head_last_layer_backward", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
+    "bnn_fused_sgld_steps", "window_gather", "tanh_rowdot", "bias_tanh", "bnn_dense_tanh", "bnn_dense_tanh_fits", "bnn_head_last_layer_backward", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
 ]
 
 _SFX = {torch.float32: "f32", torch.float64: "f64"}
@@ -498,6 +498,44 @@ def bias_tanh(a, bias):
     return a
 
 
+def bnn_dense_tanh_fits(h, W, out):
+    """Can :func:`bnn_dense_tanh` take this layer? f32 device tensors, batch a multiple of 32, fan-out a multiple of 64, fan-in a
+    multiple of 16 and >= 64, 16-byte aligned rows -- and at most one 32 x 64 output tile per compute unit (the kernel is built for
+    ONE wave of workgroups: batch 256 x 2048 columns; larger grids run the library product)."""
+    if not (h.is_cuda and h.dtype == W.dtype == out.dtype == torch.float32 and h.dim() == W.dim() == out.dim() == 2):
+        return False
+    M, K, N = int(h.shape[0]), int(h.shape[1]), int(W.shape[1])
+    if W.shape[0] != K or tuple(out.shape) != (M, N) or M % 32 or N % 64 or K % 16 or K < 64:
+        return False
+    if (M // 32) * (N // 64) > torch.cuda.get_device_properties(h.device).multi_processor_count:
+        return False
+    for t in (h, W, out):
+        if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+            return False
+    return True
+
+
+def bnn_dense_tanh(h, W, bias, out, w_next=None, dot_parts=None, stats_workspace=None, tsq_parts=None):
+    """``out = tanh(h @ W + bias)`` in ONE launch on the fp32 matrix cores (``sgmcmc_bnn_dense_tanh_f32``; shapes as
+    :func:`bnn_dense_tanh_fits` demands). With ``w_next [N]`` and ``dot_parts [N // 64, M]`` the launch also leaves the
+    per-column-tile partial dot products of ``out`` with ``w_next`` (the single output unit); with ``stats_workspace`` and
+    ``tsq_parts`` it adds up the sum(theta^2) records like :func:`tanh_rowdot`."""
+    M, K = int(h.shape[0]), int(h.shape[1])
+    N = int(W.shape[1])
+    if not bnn_dense_tanh_fits(h, W, out) or bias.numel() != N or bias.dtype != h.dtype:
+        raise ValueError("pysgmcmc_amd: bnn_dense_tanh: shapes / dtypes / alignment do not fit the kernel (see bnn_dense_tanh_fits)")
+    if dot_parts is not None and (w_next is None or w_next.numel() != N or dot_parts.numel() != (N // 64) * M):
+        raise ValueError("pysgmcmc_amd: bnn_dense_tanh needs w_next [N] and dot_parts [N // 64, M]")
+    if tsq_parts is not None and (tsq_parts.dtype != torch.float64 or tsq_parts.numel() < 16 or (M // 32) * (N // 64) < 16):
+        raise ValueError("pysgmcmc_amd: bnn_dense_tanh: tsq_parts must be float64[16] and the launch needs >= 16 output tiles")
+    with torch.cuda.device(h.device):                          # (h may be a pitched view: rows are what must be contiguous)
+        rc = lib().sgmcmc_bnn_dense_tanh_f32(h.data_ptr(), W.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, h.stride(0),
+                                             W.stride(0), out.stride(0), _ptr(w_next), _ptr(dot_parts), _ptr(stats_workspace),
+                                             _ptr(tsq_parts), _stream(h))
+    check(rc, "sgmcmc_bnn_dense_tanh_f32")
+    return out
+
+
 def tanh_rowdot(a, w, out, stats_workspace=None, tsq_parts=None, bias=None):
     """``a = tanh(a [+ bias])`` in place (``[rows, cols]``) and ``out[r] = a[r] . w`` in one launch. With ``stats_workspace``
     (a ``StepStats.workspace``) and ``tsq_parts`` (float64[16] device tensor) the launch also adds up the
@@ -518,11 +556,15 @@ def bnn_head_last_layer_backward(mean, y, log_var, tsq_parts, last_bias, batch_s
                                  grad_last_bias_out, mse_out, delta_prev, colsum, gw, fold_prior_grad=False,
                                  add_last_bias=True):
     """Loss head + backward of the single-output last layer (+ tanh backward and bias gradient of the layer below) in
-    ONE launch; see ``include/sgmcmc_hip.h``. ``mean`` = the pre-bias outputs of :func:`tanh_rowdot`."""
+    ONE launch; see ``include/sgmcmc_hip.h``. ``mean`` = the pre-bias outputs of :func:`tanh_rowdot` (``[rows]``), or the
+    per-column-tile partial dot products of :func:`bnn_dense_tanh` (``[n_parts, rows]``, added in the launch)."""
     f = getattr(lib(), "sgmcmc_bnn_head_last_layer_backward_" + _sfx(h))
     rows, cols = h.shape
+    n_parts = mean.numel() // rows
+    if n_parts * rows != mean.numel() or y.numel() != rows:
+        raise ValueError("pysgmcmc_amd: bnn_head_last_layer_backward: mean must hold n_parts x rows elements")
     with _on(h):
-        rc = f(_ptr(mean), _ptr(y, mean), _ptr(log_var), _ptr(tsq_parts), _ptr(last_bias), rows, cols, float(batch_size),
+        rc = f(_ptr(mean), n_parts, _ptr(y), _ptr(log_var), _ptr(tsq_parts), _ptr(last_bias), rows, cols, float(batch_size),
                float(n_examples), float(n_params), float(wdecay), float(prior_mean), float(prior_var),
                int(bool(fold_prior_grad)) | (2 if add_last_bias else 0), _ptr(w), _ptr(h), _ptr(bias_prev), float(beta),
                _ptr(cost_out), _ptr(grad_log_var_out), _ptr(grad_last_bias_out), _ptr(mse_out), _ptr(delta_prev, h),

@@ -186,6 +186,12 @@ class BNNCost(object):
         self.fuse_tanh_rowdot = True                      # measured 228.2 vs 231.3 us per step at 10 M parameters
         # loss head folded into the single-output layer's backward launch (every dependent launch of the step costs ~5 us)
         self.fuse_head = True
+        # hidden layers whose shapes fit (f32, batch % 32 == 0, width % 64 == 0, at most one 32 x 64 output tile per CU -- the
+        # 10 M-parameter net at batch 256) run as ONE launch each: fp32 matrix-core product with bias + tanh (and, for the last
+        # hidden layer, the output unit's dot product) as its epilogue, kernels.bnn_dense_tanh, instead of library GEMM +
+        # activation launch: 195.1 -> 188.6 us per step with the first two layers on it (tools/fwd_fused_step_probe.py). Other
+        # shapes (the reference's 3 x 50 net, batch 20) keep the library products.
+        self.fused_dense = True
         # (Forking the weight-gradient GEMMs onto a second stream inside the captured graph was measured
         # on MI355X at batch 256: 291 us/step vs 275 us on one stream -- not kept.)
 
@@ -221,6 +227,8 @@ class BNNCost(object):
             mk = lambda w: torch.empty(B, w, dtype=dt, device=dev)
             ws = {"h": [mk(w) for w in widths], "d": [mk(w) for w in widths],
                   "ones": torch.ones(B, dtype=dt, device=dev),
+                  # per-column-tile partial dot products of the last hidden layer with the output unit's weights (bnn_dense_tanh)
+                  "dot_parts": torch.zeros(max(widths[-2] // 64, 1) if n_layers >= 2 else 1, B, dtype=dt, device=dev),
                   "tsq_parts": torch.zeros(16, dtype=torch.float64, device=dev),
                   "cost": torch.zeros(1, dtype=dt, device=dev), "mse": torch.zeros(1, dtype=dt, device=dev)}
             self._ws = {key: ws}
@@ -265,8 +273,22 @@ class BNNCost(object):
         # loss head folded into the last layer's backward (one launch less): needs the sum(theta^2) records of the
         # previous step kernel, which the rowdot launch reduces to 16 slices on the side
         fuse_head = fuse_top and self.fuse_head and theta_sumsq_partials is not None
+        mean = hs[L].view(-1)                                     # the output unit's pre-bias mean, as the loss head reads it
         for l in range(n_layers):
             W, b = params[2 * l], params[2 * l + 1]
+            top = l == L - 1 and fuse_top
+            if (l < L and self.fused_dense and kernels.bnn_dense_tanh_fits(h, W, hs[l])
+                    and (not top or (fuse_head and (h.shape[0] // 32) * (W.shape[1] // 64) >= 16 and h.shape[0] <= 1024))):
+                # product + bias + tanh in ONE launch; for the last hidden layer also the output unit's partial dot products
+                # (added up by the loss head) and the 16 slices of the previous step kernel's sum(theta^2) records
+                if top:
+                    kernels.bnn_dense_tanh(h, W, b.view(-1), hs[l], w_next=params[2 * L].view(-1), dot_parts=ws["dot_parts"],
+                                           stats_workspace=theta_sumsq_partials, tsq_parts=ws["tsq_parts"])
+                    mean = ws["dot_parts"]
+                else:
+                    kernels.bnn_dense_tanh(h, W, b.view(-1), hs[l])
+                h = hs[l]
+                continue
             if l == L and single_out:
                 if not fuse_top:
                     torch.mv(h, W.view(-1), out=hs[l].view(-1))
@@ -276,7 +298,7 @@ class BNNCost(object):
                 torch.mm(h, W, out=hs[l])
             else:
                 torch.addmm(b, h, W, out=hs[l])
-            if l == L - 1 and fuse_top:
+            if top:
                 # bias + tanh of the last hidden layer and the output unit's dot product in one launch
                 kernels.tanh_rowdot(hs[l], params[2 * L].view(-1), hs[L].view(-1),
                                     stats_workspace=theta_sumsq_partials if fuse_head else None,
@@ -295,7 +317,7 @@ class BNNCost(object):
         if fuse_head:
             # loss head + gW_L + delta_{L-1} (incl. tanh') + gb_{L-1} + gb_L + d/d log_var in ONE launch
             kernels.bnn_head_last_layer_backward(
-                hs[L].view(-1), Y.reshape(-1), params[-1], ws["tsq_parts"], params[2 * L + 1], self.batch_size,
+                mean, Y.reshape(-1), params[-1], ws["tsq_parts"], params[2 * L + 1], self.batch_size,
                 self.n_examples, n_params, self.wdecay, self.prior_mean, self.prior_var, params[2 * L].view(-1), hs[L - 1],
                 params[2 * (L - 1) + 1], beta, ws["cost"], grad_views[-1], grad_views[2 * L + 1], ws["mse"], ds[L - 1],
                 grad_views[2 * (L - 1) + 1], grad_views[2 * L].view(-1), fold_prior_grad=self.fold_prior, add_last_bias=True)

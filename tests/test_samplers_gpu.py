@@ -372,6 +372,7 @@ def test_fused_head_launch_equals_separate_kernels(gpu, dt):
             for fuse in (False, True):
                 c = BNNCost(xp, yp, batch_size=20, n_examples=1000, fold_prior=fold)
                 c.fuse_head = fuse
+                c.fused_dense = False        # (its last-layer form needs the fused head: it would change the products between the two)
                 gv = [torch.full_like(p, float("nan")) for p in params]
                 cost = c.cost_and_grad(params, gv, theta_sumsq_partials=st.workspace)
                 outs.append((float(cost), float(c.last_mse), [g.clone() for g in gv]))

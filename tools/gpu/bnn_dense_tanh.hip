@@ -120,7 +120,11 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
     static_assert(NS >= 4 && NS % 2 == 0, "ring: one chunk being read, one landing, one free; unrolled by NS with two fragment sets");
     constexpr int D = NS - 1;                               // chunk kc + D is requested in iteration kc
     constexpr bool NO_MFMA = PROBE & 1, NO_LOAD = PROBE & 2, REGSTAGE = PROBE & 8;
-    __shared__ FwdLds<NS> lds;
+    // probes of the load / MFMA interaction: PRELOAD = every ring stage is filled with real data once and the loop requests nothing;
+    // SINK_LDS = on top of that the loop streams its chunks into an extra LDS stage nobody reads; SINK_VGPR = into registers
+    constexpr bool PRELOAD = PROBE & 16, SINK_LDS = PROBE & 32, SINK_VGPR = PROBE & 64;
+    constexpr bool BUFFER = PROBE & 128;   // buffer_load ... lds: 32-bit per-lane offset + scalar chunk offset, no 64-bit address VGPRs
+    __shared__ FwdLds<NS + (SINK_LDS ? 1 : 0)> lds;
     static_assert(sizeof(lds.ring) >= sizeof(lds.T), "the accumulator tiles reuse the ring");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,11 +147,35 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
     const char *a_base = reinterpret_cast<const char *>(g.h + (size_t)m0 * g.ldh);
     const char *b_base = reinterpret_cast<const char *>(g.W + n0);
     const size_t b_chunk = (size_t)BK * g.ldw * 4, b_rows4 = (size_t)4 * g.ldw * 4;
+    f32x4_t sink = {0.f, 0.f, 0.f, 0.f};
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a_base), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b_base), 0, 0x7fffffff, 0x00020000);
+#endif
     auto issue = [&](int kc, int st) {                      // chunks that lie wholly below K
 #if defined(__HIP_DEVICE_COMPILE__)
         if (NO_LOAD) return;
         const char *pa = a_base + (size_t)kc * (BK * 4);
         const char *pb = b_base + (size_t)kc * b_chunk;
+        if (BUFFER) {
+            const int stb = (PRELOAD && SINK_LDS) ? NS : st;
+            if (PRELOAD && !SINK_LDS) return;
+            const unsigned sa = (unsigned)kc * (BK * 4), sb = (unsigned)((size_t)kc * b_chunk);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, &lds.ring.A[stb][4 * wave][0], 16, a_lane, sa, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[stb][8 * wave][0], 16, b_lane, sb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[stb][8 * wave + 4][0], 16, b_lane, sb + (unsigned)b_rows4, 0, 0);
+            return;
+        }
+        if (PRELOAD) {
+            if (SINK_LDS) st = NS;
+            else if (SINK_VGPR) {
+                const f32x4_t x = *reinterpret_cast<const f32x4_t *>(pa + a_lane);
+                const f32x4_t y = *reinterpret_cast<const f32x4_t *>(pb + b_lane);
+                const f32x4_t z = *reinterpret_cast<const f32x4_t *>(pb + b_rows4 + b_lane);
+                sink += x + y + z;
+                return;
+            } else return;
+        }
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(pa + a_lane), &lds.ring.A[st][4 * wave][0], 16, 0, 0);
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(pb + b_lane), &lds.ring.B[st][8 * wave][0], 16, 0, 0);
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(pb + b_rows4 + b_lane), &lds.ring.B[st][8 * wave + 4][0], 16, 0, 0);
@@ -263,9 +291,10 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
     } else {
     // ---- prologue: chunks 0 .. D - 1 requested, chunk 0 landed and read
 #pragma unroll
-    for (int c = 0; c < D; ++c)
+    for (int c = 0; c < (PRELOAD ? NS : D); ++c)
         if (c < nk) issue_clamped(c, c);
-    if (!NO_LOAD) wait_chunks_in_flight<D - 1>(nk - 1);
+    if (PRELOAD) wait_vm<0>();
+    else if (!NO_LOAD) wait_chunks_in_flight<D - 1>(nk - 1);
     __builtin_amdgcn_s_barrier();
     read_frags(0, fa);
     // One iteration: chunk kc + 1 is waited for and read from LDS (into the other fragment set) while the MFMAs of chunk kc
@@ -273,7 +302,7 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
     // + an immediate, M0 = a constant) and the two fragment sets swap roles without register copies.
     auto steady = [&](int kc, const Frag &cur, Frag &nxt, auto stage) {
         constexpr int I = decltype(stage)::value;           // kc % NS
-        if (!NO_LOAD) wait_vm<3 * (D - 2)>();               // chunk kc + 1 landed: chunks kc + 2 .. kc + D - 1 may be in flight
+        if (!NO_LOAD && !(PRELOAD && !SINK_LDS)) wait_vm<3 * (D - 2)>();   // chunk kc + 1 landed: chunks kc + 2 .. kc + D - 1 may be in flight
         __builtin_amdgcn_s_barrier();                       // ... for every wave; and the stage of chunk kc - 1 is free
         mfmas(cur, 0, 2);
         __builtin_amdgcn_sched_barrier(0);
@@ -299,7 +328,7 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
         __builtin_amdgcn_s_barrier();
         mfmas(fa, 0, 2);
         __builtin_amdgcn_sched_barrier(0);
-        if (kc + D < nk) issue_clamped(kc + D, st_issue);
+        if (kc + D < nk && !PRELOAD) issue_clamped(kc + D, st_issue);
         read_frags(st_read, fb);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(fa, 2, 8);
@@ -310,6 +339,7 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
     }
     // last chunk: only the quarters that lie below K exist
     if ((nk - 1) * BK + 16 * kq < g.K) mfmas(fa, 0, 8);
+    if (SINK_VGPR && sink[0] == 123.456f && g.M < 0) g.out[0] = sink[1] + sink[2] + sink[3];
     // ---- epilogue: the four K quarters meet in LDS (fixed order), bias + tanh on row-major quads, 16-byte stores
     __syncthreads();                                        // every fragment read is done: the ring is free
 #pragma unroll
@@ -369,6 +399,12 @@ int bnn_dense_tanh_probe_f32(const float *h, const float *W, const float *bias, 
         case 2: return launch_fwd<4, 2>(g, st);
         case 3: return launch_fwd<4, 3>(g, st);
         case 10: return launch_fwd<6, 0>(g, st);
+        case 16: return launch_fwd<4, 16>(g, st);
+        case 128: return launch_fwd<4, 128>(g, st);
+        case 176: return launch_fwd<4, 176>(g, st);
+        case 138: return launch_fwd<6, 128>(g, st);
+        case 48: return launch_fwd<4, 48>(g, st);
+        case 80: return launch_fwd<4, 80>(g, st);
         case 8: return launch_fwd<4, 8>(g, st);
         case 9: return launch_fwd<4, 9>(g, st);
         default: break;
