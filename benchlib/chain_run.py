@@ -389,7 +389,7 @@ class ChainBench(object):
                 "launches_timed": int(u_us.size), "step_ms_median": round(serial_step_us * 1e-3, 4),
                 "note": "the same chain, %d steps after the timed region with the timer on EVERY update launch and no moments "
                         "steps: the kernel alone in the pipeline, as rounds 1-2 reported `roofline`" % n_legs}
-            g_us, g_flops = legs.gemm_only_us(sampler)
+            g_us, g_flops, n_fused = legs.gemm_only_us(sampler)
             c_us = legs.cost_pipeline_us(sampler)
             meas_us = float(np.median(self.step_ms)) * 1e3 if self.step_ms is not None else None
             line["step_breakdown_us"] = {
@@ -398,12 +398,15 @@ class ChainBench(object):
                 "timed_region_step_median": None if meas_us is None else round(meas_us, 1),
                 "gemm_tflops": round(g_flops / (g_us * 1e-6) / 1e12, 1),
                 "gemm_frac_of_fp32_mfma_peak": round(g_flops / (g_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3),
-                "gemm_flop_per_step": int(g_flops),
-                "note": "gemm = the step's eight fp32 library GEMMs replayed alone from a hipGraph; small_launches = the captured "
-                        "cost pipeline alone minus gemm (bias + tanh, tanh-backward + bias gradient, loss head ...); "
+                "gemm_flop_per_step": int(g_flops), "forward_layers_on_the_fused_launch": n_fused,
+                "note": "gemm = the step's eight fp32 products replayed alone from a hipGraph: five library GEMMs (backward) + the "
+                        "three forward layers as the pipeline runs them (%d of them as ONE launch each with bias + tanh as the "
+                        "product's epilogue, sgmcmc_bnn_dense_tanh_f32: their activation is then inside `gemm`); small_launches = the "
+                        "captured cost pipeline alone minus gemm (window gather aside: tanh-backward + bias gradient, loss head, and the "
+                        "activation launches of forward layers on the library product); " % n_fused +
                         "update = the fused update launched once after the backward pass. Differences of graph replays: rocprofv3's "
-                        "per-kernel durations of the same step (profiles/r03_bench10m_kernel_stats.csv: GEMMs 136, seven small "
-                        "launches 37, update 35 us) carry ~1.5 us of profiler overhead per kernel. The fp32 MFMA peak is quoted at "
+                        "per-kernel durations of the same step (profiles/r04_bench10m_kernel_stats.csv) carry ~1.5 us of profiler "
+                        "overhead per kernel. The fp32 MFMA peak is quoted at "
                         "2.4 GHz; under this load the chip sustains ~2.0 GHz (profiles/r04_fwd_epilogue_probe.txt)"}
         if not args.no_update_only and self.kind == "sghmc":
             if sampler.use_hip_graph and self.K == 1:

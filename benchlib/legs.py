@@ -125,18 +125,26 @@ def hbm_resident_roofline(dev, n=N_HBM_RESIDENT, iters=40):
 
 @torch.no_grad()
 def gemm_only_us(sampler, iters=60):
-    """The eight fp32 GEMMs of one step (three forward, five backward; same operands, shapes and output buffers as the
-    cost pipeline) replayed back to back from their own hipGraph: microseconds per step and their FLOP count."""
+    """The eight fp32 products of one step (three forward, five backward; same operands, shapes and output buffers as the cost
+    pipeline) replayed back to back from their own hipGraph: microseconds per step and their FLOP count. The forward ones are
+    what the pipeline runs: the fused product + bias + tanh launch (kernels.bnn_dense_tanh) where BNNCost.fused_dense takes the
+    layer, else the library GEMM. Returns (us, flops, number of forward layers on the fused launch)."""
+    from pysgmcmc_amd import kernels
     cost, params, gv = sampler.cost_fun, sampler.params, sampler.arena.grad_views
     X = cost.x_placeholder.value
     ws = cost._buffers(params, X.shape[0])
     hs, ds = ws["h"], ws["d"]
     L = (len(params) - 1) // 2 - 1                              # index of the single-output layer
+    n_fused = [0]
 
     def gemms():
-        h, flops = X, 0
+        h, flops, n_fused[0] = X, 0, 0
         for l in range(L):
-            torch.mm(h, params[2 * l], out=hs[l])                  # the bias rides in the activation launch
+            if getattr(cost, "fused_dense", False) and kernels.bnn_dense_tanh_fits(h, params[2 * l], hs[l]):
+                kernels.bnn_dense_tanh(h, params[2 * l], params[2 * l + 1].view(-1), hs[l])
+                n_fused[0] += 1
+            else:
+                torch.mm(h, params[2 * l], out=hs[l])              # the bias rides in the activation launch
             flops += 2 * h.shape[0] * h.shape[1] * params[2 * l].shape[1]
             h = hs[l]
         for l in range(L - 1, -1, -1):
@@ -163,7 +171,7 @@ def gemm_only_us(sampler, iters=60):
         graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3, flops
+    return e0.elapsed_time(e1) / iters * 1e3, flops, n_fused[0]
 
 
 def cost_pipeline_us(sampler, iters=60):

@@ -1,9 +1,11 @@
 // bnn_dense_tanh.hip -- EXPERIMENT (round 4), not part of libsgmcmc_hip.so: one hidden layer of the BNN
 // forward pass (pysgmcmc/models/bayesian_neural_network.py:30-52) as a hand-written fp32 matrix-core product with bias + tanh
 // (and optionally the single output unit's dot product) as its epilogue, against library GEMM + sgmcmc_bias_tanh_f32.
-// Result (profiles/r04_fwd_epilogue_probe.txt): correct to fp32 rounding, but at M = 256, K = N = 2048 it only TIES
-// library GEMM + bias_tanh (21.4 vs 21.1 us), +2.0 us on the K = 784 layer, +3.3 us over the whole forward pass -- below the
-// gate of 3 us per product, so the cost path keeps the library products. Build: make -C tools/gpu; run: tools/fwd_fused_probe.py.
+// Result (profiles/r04_fwd_epilogue_probe.txt): correct to fp32 rounding; with 64-bit global addresses it only TIED library GEMM +
+// bias_tanh at M = 256, K = N = 2048 (21.4 vs 21.1 us; gate of 3 us not met); with BUFFER loads (probe 128: no per-lane address
+// arithmetic at all) 19.5-20.2 us, and in the sampler's step the three hidden layers on it take 8.9 us off 196.2 -- that variant
+// became the product kernel pysgmcmc_amd/csrc/sgmcmc_bnn_gemm.hip (sgmcmc_bnn_dense_tanh_f32). This file stays as the measurement
+// harness with every probe variant. Build: make -C tools/gpu; run: tools/fwd_fused_probe.py, tools/fwd_probe_timing.py.
 //
 //   forward:   out[m][n] = tanh( sum_k h[m][k] W[k][n] + b[n] )            h [M = batch][K], W [K][N] row-major
 //              (+ optionally dot_parts[t][m] = sum_{n in column tile t} out[m][n] w_next[n], the single output unit)
@@ -28,7 +30,10 @@
 //     compile-time constants: 21.4-23.8 depending on the operand DATA (the chip clocks to its power budget);
 //   * operands staged through registers (global_load_dwordx4 four chunks ahead + ds_write_b128) instead of direct loads: 23.6,
 //     the same; the K loop with no loads at all (MFMAs on whatever LDS holds): 17.1; the loads alone: 9.8;
-//   * library product alone: 17.9-18.9; + bias_tanh: 21.1-21.6.
+//   * library product alone: 17.9-18.9; + bias_tanh: 21.1-21.6;
+//   * probes of the load / MFMA interaction (tools/fwd_probe_timing.py): ring preloaded with real data and no loads in the loop 18.2-18.5;
+//     the same with the loop's chunks streamed into an LDS stage nobody reads 21.6 (global_load_lds, 64-bit addresses) / 19.8
+//     (buffer_load ... lds); the kernel itself 23.5-23.9 / 20.2: the loads cost MFMA time by being ISSUED, not by being waited for.
 //
 // fp32 MFMA is an exact fmaf chain (MI355X_MICROARCH.md): the product differs from a library GEMM in summation order only.
 #include <hip/hip_runtime.h>
