@@ -7,7 +7,7 @@
 // Replaces library GEMM + sgmcmc_bias_tanh_f32 (+ sgmcmc_bias_tanh_rowdot_f32 for the last hidden layer). In isolation it
 // only ties that pair on the 2048 x 2048 layer (19.5-20.2 vs 21.1-21.5 us; it was an experiment that missed its gate, see
 // tools/gpu/bnn_dense_tanh.hip and profiles/r04_fwd_epilogue_probe.txt for everything tried on the way), but in the sampler's
-// step two launches per layer become one and the 10 M-parameter chain goes from 195.1 to 188.6 us per step with the first two
+// step two launches per layer become one and the 10 M-parameter chain goes from 196.2 to 186.0 us per step with its three
 // hidden layers on it (tools/fwd_fused_step_probe.py).
 //
 // Decomposition for M = 256: the output is 512 MFMA tiles of 32 x 32 for 1024 SIMDs, so K must be split; a workgroup (ONE per
@@ -222,12 +222,18 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
         constexpr int I = decltype(stage)::value;           // kc % NS
         wait_vm<3 * (D - 2)>();                             // chunk kc + 1 landed: chunks kc + 2 .. kc + D - 1 may be in flight
         __builtin_amdgcn_s_barrier();                       // ... for every wave; and the stage of chunk kc - 1 is free
+        // order inside an iteration (tools/fwd_fused_step_probe.py, 10 M-parameter chain, us per step): the fragment reads right
+        // after the second MFMA and the loads after the fourth 186.0; loads + reads bunched after the second 187.0; one load per
+        // MFMA gap 186.0; s_setprio 1 for the later-dispatched wave of each SIMD 187.7
         mfmas(cur, 0, 2);
         __builtin_amdgcn_sched_barrier(0);
-        issue(kc + D, (I + D) % NS);
         read_frags((I + 1) % NS, nxt);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(cur, 2, 8);
+        mfmas(cur, 2, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(kc + D, (I + D) % NS);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(cur, 4, 8);
     };
     int kc = 0;
     for (; kc + D + NS < nk; kc += NS) {                    // every chunk requested here (up to kc + NS - 1 + D) lies wholly below K
@@ -242,8 +248,8 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
         __builtin_amdgcn_s_barrier();
         mfmas(fa, 0, 2);
         __builtin_amdgcn_sched_barrier(0);
-        if (kc + D < nk) issue_clamped(kc + D, st_issue);
         read_frags(st_read, fb);
+        if (kc + D < nk) issue_clamped(kc + D, st_issue);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(fa, 2, 8);
         fa = fb;
