@@ -498,6 +498,16 @@ def bias_tanh(a, bias):
     return a
 
 
+_CU_COUNT = {}
+
+
+def _cu_count(device):
+    n = _CU_COUNT.get(device)
+    if n is None:
+        n = _CU_COUNT[device] = int(torch.cuda.get_device_properties(device).multi_processor_count)
+    return n
+
+
 def bnn_dense_tanh_fits(h, W, out):
     """Can :func:`bnn_dense_tanh` take this layer? f32 device tensors, batch a multiple of 32, fan-out a multiple of 64, fan-in a
     multiple of 16 and >= 64, 16-byte aligned rows -- and at most one 32 x 64 output tile per compute unit (the kernel is built for
@@ -507,7 +517,7 @@ def bnn_dense_tanh_fits(h, W, out):
     M, K, N = int(h.shape[0]), int(h.shape[1]), int(W.shape[1])
     if W.shape[0] != K or tuple(out.shape) != (M, N) or M % 32 or N % 64 or K % 16 or K < 64:
         return False
-    if (M // 32) * (N // 64) > torch.cuda.get_device_properties(h.device).multi_processor_count:
+    if (M // 32) * (N // 64) > _cu_count(h.device):
         return False
     for t in (h, W, out):
         if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
