@@ -1,12 +1,10 @@
 """CPU baselines of the bench workloads: the oracle (kind "port") timed on the GPU box's host cores. The only place besides
 tests/ and smoke() that may touch ``oracle/`` -- as the thing timed NEXT to the product, never inside its timed region."""
-import os
-import sys
 import time
 
 import numpy as np
 
-from benchlib.common import BATCH, N_DATA, ROOT, usable_cores
+from benchlib.common import BATCH, N_DATA, usable_cores
 from benchlib.workloads import WORKLOADS
 
 

@@ -5,7 +5,7 @@ import time
 import numpy as np
 import torch
 
-from benchlib.common import BYTES_PER_PARAM, FP32_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS, N_DATA, N_HBM_RESIDENT, PRIME_BURN_IN, pmc_traffic
+from benchlib.common import BYTES_PER_PARAM, HBM_PEAK_GBS, N_DATA, N_HBM_RESIDENT, PRIME_BURN_IN, pmc_traffic
 from benchlib.workloads import build_chain
 
 
