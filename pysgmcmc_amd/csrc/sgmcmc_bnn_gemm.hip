@@ -135,9 +135,9 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
     const int ar = 4 * wave + (lane >> 4);                  // A row of this lane's 16 bytes
     const int aq = (lane & 15) ^ (ar & 15);                 // logical quad stored at physical slot lane & 15
     const int br = 8 * wave + (lane >> 4);                  // B rows br, br + 4
-    const unsigned a_lane = (unsigned)(ar * g.ldh + 4 * aq) * 4u;
-    const unsigned b_lane = (unsigned)(br * g.ldw + 4 * (lane & 15)) * 4u;
-    const unsigned b_chunk = (unsigned)BK * (unsigned)g.ldw * 4u, b_rows4 = 4u * (unsigned)g.ldw * 4u;
+    [[maybe_unused]] const unsigned a_lane = (unsigned)(ar * g.ldh + 4 * aq) * 4u;
+    [[maybe_unused]] const unsigned b_lane = (unsigned)(br * g.ldw + 4 * (lane & 15)) * 4u;
+    [[maybe_unused]] const unsigned b_chunk = (unsigned)BK * (unsigned)g.ldw * 4u, b_rows4 = 4u * (unsigned)g.ldw * 4u;
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(g.h + (size_t)m0 * g.ldh), 0, 0x7fffffff, 0x00020000);
