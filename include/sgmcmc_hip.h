@@ -420,6 +420,29 @@ int sgmcmc_bnn_dense_tanh_f32(const float *h, const float *W, const float *bias,
                               int ldw, int ldo, const float *w_next, float *dot_parts, const void *stats_ws, double *tsq_parts,
                               sgmcmc_stream_t stream);
 
+/* Backward step through a hidden tanh layer of the same network in ONE launch (the reference's graph differentiates
+ * bayesian_neural_network.py:30-52 through tf.gradients, samplers/base_classes.py:121-122): replaces library GEMM
+ * delta W^T + sgmcmc_tanh_backward_colsum_f32.
+ *   out[m][n] = ( sum_k delta[m][k] W[n][k] ) * (1 - act[m][n]^2)     delta [M][K] = d cost / d pre-activation of the layer above,
+ *                                                                      W [N][K] that layer's weights, act [M][N] this layer's tanh outputs
+ *   colsum_parts[t][n] = sum of out[m][n] over row tile t (rows 32 t .. 32 t + 31)      (optional; [M / 32][N])
+ * i.e. out = d cost / d pre-activation of this layer; its column sums are this layer's bias gradient. Same pipeline and shape
+ * limits as sgmcmc_bnn_dense_tanh_f32 (M % 32, N % 64, K % 16, K >= 64, 16-byte aligned rows, operands < 2 GiB); W is read along
+ * its rows, no transpose is formed. A workgroup owns 32 rows, so the sums over ALL rows need a second pass over what other
+ * workgroups wrote: inside one launch that costs more than the launch it saves (measured), so the row-tile
+ * sums are left in colsum_parts and added up -- in row-tile order: bit-reproducible, no atomics --
+ *   * by the NEXT launch of this function on the stream, on the side (fin_*: fin_colsum[c] = sum_r fin_parts[r][c]
+ *     (+ fin_beta * fin_bias[c]), r < fin_rows, c < fin_n; fin_parts must not be the colsum_parts the same launch writes), or
+ *   * by sgmcmc_colsum_finish_f32 (a small launch), or
+ *   * not at all (colsum_parts NULL) when the caller gets the bias gradient elsewhere -- BNNCost takes the first layer's from
+ *     the weight-gradient product itself, [x | 1]^T delta.                                                                   */
+int sgmcmc_bnn_dense_tanh_backward_f32(const float *delta, const float *W, const float *act, float *out, float *colsum_parts,
+                                       int M, int N, int K, int ldd, int ldw, int lda, int ldo, const float *fin_parts,
+                                       int fin_rows, int fin_n, const float *fin_bias, float fin_beta, float *fin_colsum,
+                                       sgmcmc_stream_t stream);
+int sgmcmc_colsum_finish_f32(const float *parts, int rows, int n, const float *bias, float beta, float *colsum,
+                             sgmcmc_stream_t stream);
+
 /* sgmcmc_bnn_head_* and sgmcmc_bnn_last_layer_backward_* in ONE launch (every dependent launch of the step costs
  * ~5 us): `mean` [n_mean_parts][rows] is the single-output layer's pre-bias output -- n_mean_parts = 1: the vector
  * sgmcmc_tanh_rowdot_* writes; > 1: the per-column-tile partial dot products sgmcmc_bnn_dense_tanh_f32 writes, added here
@@ -440,11 +463,13 @@ int sgmcmc_bnn_head_last_layer_backward_f64(
     sgmcmc_stream_t stream);
 
 /* Minibatch window [start, start + batch) of the device-resident dataset copied into the (static) feed buffers with
- * ONE launch: x_out[batch][dim] = X[start ..][:], y_out[batch] = y[start ..] (pysgmcmc/data_batches.py:118-123).   */
+ * ONE launch: x_out[batch][dim] = X[start ..][:], y_out[batch] = y[start ..] (pysgmcmc/data_batches.py:118-123).
+ * x_out_ld >= dim is the row pitch of x_out in elements (dim: dense); columns beyond dim are left alone -- BNNCost keeps a
+ * column of ones there, so that the first layer's weight-gradient product [x | 1]^T delta also yields its bias gradient. */
 int sgmcmc_window_gather_f32(const float *X, const float *y, size_t n_data, size_t start, size_t batch, size_t dim,
-                             float *x_out, float *y_out, sgmcmc_stream_t stream);
+                             float *x_out, size_t x_out_ld, float *y_out, sgmcmc_stream_t stream);
 int sgmcmc_window_gather_f64(const double *X, const double *y, size_t n_data, size_t start, size_t batch, size_t dim,
-                             double *x_out, double *y_out, sgmcmc_stream_t stream);
+                             double *x_out, size_t x_out_ld, double *y_out, sgmcmc_stream_t stream);
 
 /* ---- Stein variational gradient descent: pysgmcmc/samplers/svgd.py:118-181 -----------------------
  * The n particles are the rows of a [n_particles x ld] device matrix (row pitch ld >= dim elements; with

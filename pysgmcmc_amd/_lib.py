@@ -144,7 +144,7 @@ def _declare(lib):
         f.argtypes = ([_vp, _sz] + [_vp] * 4 + [_sz, _sz] + [ctypes.c_double] * 6 + [_ci, _vp, _vp, _vp, real] + [_vp] * 7 + [_vp])
         f.restype = _ci
         f = getattr(lib, "sgmcmc_window_gather_" + sfx)
-        f.argtypes = [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]
+        f.argtypes = [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _sz, _vp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_bnn_fused_sgld_steps_" + sfx)
         f.argtypes = ([_vp] * 6 + [_sz, _sz, _ci, ctypes.POINTER(_ci), _ci, _vp, _vp, _sz, _vp, _ci]
@@ -161,6 +161,10 @@ def _declare(lib):
         f.restype = _ci
     lib.sgmcmc_bnn_dense_tanh_f32.argtypes = [_vp] * 4 + [_ci] * 6 + [_vp] * 5
     lib.sgmcmc_bnn_dense_tanh_f32.restype = _ci
+    lib.sgmcmc_bnn_dense_tanh_backward_f32.argtypes = [_vp] * 5 + [_ci] * 7 + [_vp, _ci, _ci, _vp, ctypes.c_float, _vp, _vp]
+    lib.sgmcmc_bnn_dense_tanh_backward_f32.restype = _ci
+    lib.sgmcmc_colsum_finish_f32.argtypes = [_vp, _ci, _ci, _vp, ctypes.c_float, _vp, _vp]
+    lib.sgmcmc_colsum_finish_f32.restype = _ci
     lib.sgmcmc_philox_bits_u32.argtypes = [_vp, _sz, _u64, _u64, _vp, _vp]
     lib.sgmcmc_counter_add_u64.argtypes = [_vp, _u64, _vp]
     lib.sgmcmc_counter_add_u64.restype = _ci

@@ -76,13 +76,23 @@ __device__ __forceinline__ void wait_chunks_in_flight(int chunks)
 }
 
 struct FwdArgs {
-    const float *h, *W, *bias;
+    const float *h, *W, *bias;  // BWD: h = delta of the layer above [M][K], W [N][K] (the layer's weights, read along their rows)
     float *out;
     const float *w_next;        // nullable
     float *dot_parts;           // [N / 64][M]
     const double *stats_ws;     // nullable: statistics workspace of the previous step kernel ...
     double *tsq_parts;          // ... whose sum(theta^2) records workgroups 0 .. 15 add up into 16 slices
     int M, N, K, ldh, ldw, ldo;
+    // BWD only
+    const float *act;           // [M][N] the layer's tanh outputs (pitch lda)
+    float *colsum_parts;        // nullable: [M / 32][N] column sums of out over each row tile
+    int lda;
+    // BWD side job: the column sums an EARLIER launch left in parts are added up (row-tile order) into fin_colsum
+    const float *fin_parts;     // nullable: [fin_rows][fin_n]
+    const float *fin_bias;      // nullable with fin_beta == 0
+    float *fin_colsum;          // [fin_n] = sum_r fin_parts[r][:] (+ fin_beta * fin_bias)
+    float fin_beta;
+    int fin_rows, fin_n;
 };
 
 template <int NS>
@@ -94,6 +104,10 @@ struct __attribute__((aligned(16))) FwdLds {
         } ring;
         float T[KQ][BM][TP];
         double red[8];
+        struct {
+            float T_[KQ][BM][TP];
+            float cs[8][BN];    // BWD: column sums of the 8 waves' rows
+        } epi;
     };
 };
 
@@ -115,7 +129,11 @@ __device__ __forceinline__ float row16_sum_lane15(float v)
     return v;
 }
 
-template <int NS>
+// BWD = false: the forward layer above. BWD = true: the layer's backward step,
+//   out[m][n] = ( sum_k delta[m][k] W[n][k] ) * (1 - act[m][n]^2),  colsum[n] = sum_m out[m][n] (+ beta bias[n])
+// -- the same pipeline with B read along the rows of W (contraction-contiguous like A: same swizzled LDS image, two
+// ds_read_b128 per chunk instead of eight ds_read_b32).
+template <int NS, bool BWD>
 __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
 {
     static_assert(NS >= 4 && NS % 2 == 0, "ring: one chunk being read, one landing, one free; unrolled by NS with two fragment sets");
@@ -136,38 +154,60 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
     const int aq = (lane & 15) ^ (ar & 15);                 // logical quad stored at physical slot lane & 15
     const int br = 8 * wave + (lane >> 4);                  // B rows br, br + 4
     [[maybe_unused]] const unsigned a_lane = (unsigned)(ar * g.ldh + 4 * aq) * 4u;
-    [[maybe_unused]] const unsigned b_lane = (unsigned)(br * g.ldw + 4 * (lane & 15)) * 4u;
+    // B forward: rows k of W (n contiguous), lane & 15 = quad of the 64 tile columns. B backward: tile column n = row n0 + br of W
+    // (k contiguous): quads swizzled like A's (rows br and br + 4 differ in bit 2 of the swizzle: two lane offsets)
+    const int bq0 = (lane & 15) ^ (br & 15), bq1 = (lane & 15) ^ ((br + 4) & 15);
+    [[maybe_unused]] const unsigned b_lane = BWD ? (unsigned)(br * g.ldw + 4 * bq0) * 4u : (unsigned)(br * g.ldw + 4 * (lane & 15)) * 4u;
+    [[maybe_unused]] const unsigned b_lane1 = (unsigned)((br + 4) * g.ldw + 4 * bq1) * 4u;
     [[maybe_unused]] const unsigned b_chunk = (unsigned)BK * (unsigned)g.ldw * 4u, b_rows4 = 4u * (unsigned)g.ldw * 4u;
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(g.h + (size_t)m0 * g.ldh), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.W + n0), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(BWD ? g.W + (size_t)n0 * g.ldw : g.W + n0), 0, 0x7fffffff, 0x00020000);
 #endif
     auto issue = [&](int kc, int st) {                      // chunks that lie wholly below K: scalar offsets only
 #if defined(__HIP_DEVICE_COMPILE__)
-        const unsigned sa = (unsigned)kc * (BK * 4), sb = (unsigned)kc * b_chunk;
+        const unsigned sa = (unsigned)kc * (BK * 4);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, &lds.ring.A[st][4 * wave][0], 16, a_lane, sa, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave][0], 16, b_lane, sb, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave + 4][0], 16, b_lane, sb + b_rows4, 0, 0);
+        if constexpr (BWD) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave][0], 16, b_lane, sa, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave + 4][0], 16, b_lane1, sa, 0, 0);
+        } else {
+            const unsigned sb = (unsigned)kc * b_chunk;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave][0], 16, b_lane, sb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave + 4][0], 16, b_lane, sb + b_rows4, 0, 0);
+        }
 #endif
     };
     auto issue_clamped = [&](int kc, int st) {              // prologue / last chunks: beyond K any valid address will do (never used)
 #if defined(__HIP_DEVICE_COMPILE__)
-        int ka = kc * BK + 4 * aq, kb0 = kc * BK + br, kb1 = kc * BK + br + 4;
+        int ka = kc * BK + 4 * aq;
         if (ka + 4 > g.K) ka = g.K - 4;
-        if (kb0 >= g.K) kb0 = g.K - 1;
-        if (kb1 >= g.K) kb1 = g.K - 1;
-        const unsigned va = (unsigned)(ar * g.ldh + ka) * 4u, c4 = 4u * (unsigned)(lane & 15) * 4u;
+        const unsigned va = (unsigned)(ar * g.ldh + ka) * 4u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, &lds.ring.A[st][4 * wave][0], 16, va, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave][0], 16, (unsigned)kb0 * (unsigned)g.ldw * 4u + c4, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave + 4][0], 16, (unsigned)kb1 * (unsigned)g.ldw * 4u + c4, 0, 0, 0);
+        if constexpr (BWD) {
+            int k0 = kc * BK + 4 * bq0, k1 = kc * BK + 4 * bq1;
+            if (k0 + 4 > g.K) k0 = g.K - 4;
+            if (k1 + 4 > g.K) k1 = g.K - 4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave][0], 16, (unsigned)(br * g.ldw + k0) * 4u, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave + 4][0], 16, (unsigned)((br + 4) * g.ldw + k1) * 4u, 0, 0, 0);
+        } else {
+            int kb0 = kc * BK + br, kb1 = kc * BK + br + 4;
+            if (kb0 >= g.K) kb0 = g.K - 1;
+            if (kb1 >= g.K) kb1 = g.K - 1;
+            const unsigned c4 = 4u * (unsigned)(lane & 15) * 4u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave][0], 16, (unsigned)kb0 * (unsigned)g.ldw * 4u + c4, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave + 4][0], 16, (unsigned)kb1 * (unsigned)g.ldw * 4u + c4, 0, 0, 0);
+        }
 #endif
     };
     // ---- fragment addresses
     const int fm = lane & 31, kl = lane >> 5;
     const int sw = fm & 15;
     const int aoff0 = fm * BK + 4 * ((4 * kq + 2 * kl) ^ sw), aoff1 = fm * BK + 4 * ((4 * kq + 2 * kl + 1) ^ sw);
-    const int boff = (16 * kq + 8 * kl) * BN + 32 * nt + fm;
+    const int boff = BWD ? 32 * nt * BK + aoff0 : (16 * kq + 8 * kl) * BN + 32 * nt + fm;      // BWD: row 32 nt + fm, same quads as A
+    const int boff1 = 32 * nt * BK + aoff1;
     struct Frag {
         f32x4_t a0, a1;
         float b[8];
@@ -177,8 +217,14 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
         const float *B = &lds.ring.B[st][0][0];
         f.a0 = *reinterpret_cast<const f32x4_t *>(A + aoff0);
         f.a1 = *reinterpret_cast<const f32x4_t *>(A + aoff1);
+        if constexpr (BWD) {
+            const f32x4_t b0 = *reinterpret_cast<const f32x4_t *>(B + boff), b1 = *reinterpret_cast<const f32x4_t *>(B + boff1);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f.b[j] = B[boff + j * BN];
+            for (int j = 0; j < 4; ++j) { f.b[j] = b0[j]; f.b[4 + j] = b1[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f.b[j] = B[boff + j * BN];
+        }
     };
     f32x16 acc0, acc1;
 #pragma unroll
@@ -192,16 +238,47 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
                 else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f.b[j], acc1, 0, 0, 0);
             }
     };
-    // ---- prologue: chunks 0 .. D - 1 requested ...
+    // ---- prologue: (BWD) this lane's quad of the activations for the epilogue, then chunks 0 .. D - 1 requested ...
+    f32x4_t actv = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BWD) actv = *reinterpret_cast<const f32x4_t *>(g.act + (size_t)(m0 + (tid >> 4)) * g.lda + n0 + (tid & 15) * 4);
+    // (BWD) side job of wave 0: the bias gradient of the layer ABOVE -- the per-row-tile column sums the previous launch left are
+    // added up in row-tile order (deterministic; the launch boundary is what makes them visible). Loads first, the sums after
+    // the chunk requests: older vector-memory operations only make the counted waits below stronger.
+    constexpr int FIN_PRE = 8;                              // row tiles requested ahead (batch 256); any further ones afterwards
+    float finv[BWD ? FIN_PRE : 1];
+    const int fin_c = (int)blockIdx.x * BN + tid;
+    const bool finisher = BWD && g.fin_parts != nullptr && tid < BN && fin_c < g.fin_n;
+    if constexpr (BWD) {
+        if (finisher) {
+#pragma unroll
+            for (int r = 0; r < FIN_PRE; ++r)
+                if (r < g.fin_rows) finv[r] = g.fin_parts[(size_t)r * g.fin_n + fin_c];
+        }
+    }
 #pragma unroll
     for (int c = 0; c < D; ++c)
         if (c < nk) issue_clamped(c, c);
+    if constexpr (BWD) {
+        if (finisher) {
+            float tot = finv[0];
+#pragma unroll
+            for (int r = 1; r < FIN_PRE; ++r)
+                if (r < g.fin_rows) tot += finv[r];
+            for (int r = FIN_PRE; r < g.fin_rows; ++r) tot += g.fin_parts[(size_t)r * g.fin_n + fin_c];
+            g.fin_colsum[fin_c] = (g.fin_beta != 0.f) ? tot + g.fin_beta * g.fin_bias[fin_c] : tot;
+            for (int c = fin_c + (int)gridDim.x * BN; c < g.fin_n; c += (int)gridDim.x * BN) {      // more columns than 64 per workgroup
+                float t2 = g.fin_parts[c];
+                for (int r = 1; r < g.fin_rows; ++r) t2 += g.fin_parts[(size_t)r * g.fin_n + c];
+                g.fin_colsum[c] = (g.fin_beta != 0.f) ? t2 + g.fin_beta * g.fin_bias[c] : t2;
+            }
+        }
+    }
     // ... and while they fly, the side job of the last hidden layer's launch: workgroups 0 .. 15 add up one contiguous slice
     // each of the sum(theta^2) records the previous step kernel left in its statistics workspace (the loss head adds the
     // slices in order: same arithmetic as sgmcmc_bias_tanh_rowdot_*'s side job)
     double tsq = 0.0;
     const unsigned n_slices = gridDim.x < (unsigned)TSQ_SLICES ? gridDim.x : (unsigned)TSQ_SLICES;
-    const bool slicer = g.stats_ws != nullptr && blockIdx.x < n_slices;
+    const bool slicer = !BWD && g.stats_ws != nullptr && blockIdx.x < n_slices;
     if (slicer) {
         const unsigned nparts = (unsigned)reinterpret_cast<const unsigned long long *>(g.stats_ws)[0];
         const double *__restrict__ p = g.stats_ws + 4;
@@ -272,6 +349,33 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
 #pragma unroll
             for (int j = 0; j < 4; ++j) s[j] += sp[j];
         }
+        if constexpr (BWD) {
+            // tanh' of the layer below as the epilogue (sgmcmc_tanh_backward_colsum_*'s arithmetic) ...
+            f32x4_t v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = s[j] * (1.f - actv[j] * actv[j]);
+            *reinterpret_cast<f32x4_t *>(g.out + (size_t)(m0 + row) * g.ldo + n0 + c4) = v;
+            // ... and the bias gradient: column sums over the tile's 32 rows (4 rows of a wave by shuffles, the 8 waves in order).
+            // The row tiles of a column are NOT added here: that takes a second pass over what other workgroups wrote, and in
+            // one launch it costs more than it saves (arrival counter + agent-scope fences: +12 us; relaxed write-through
+            // atomics: +2.5 us, the step got slower -- tools/bwd_fused_probe.py). The partial rows are left
+            // for the NEXT launch to add up on the side (fin_* above), or for sgmcmc_colsum_finish_f32.
+            if (g.colsum_parts == nullptr) return;          // (the first layer's bias gradient comes from the [x | 1]^T delta product)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] += __shfl_xor(v[j], 16, 64);
+                v[j] += __shfl_xor(v[j], 32, 64);
+            }
+            if (lane < 16) *reinterpret_cast<f32x4_t *>(&lds.epi.cs[wave][c4]) = v;
+            __syncthreads();
+            if (tid < BN) {
+                float tot = lds.epi.cs[0][tid];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) tot += lds.epi.cs[w][tid];
+                g.colsum_parts[(size_t)(m0 / BM) * g.N + n0 + tid] = tot;
+            }
+            return;
+        }
         const f32x4_t b = *reinterpret_cast<const f32x4_t *>(g.bias + n0 + c4);
         f32x4_t v;
 #pragma unroll
@@ -293,6 +397,17 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
     }
 }
 
+// colsum[c] = sum_r parts[r][c] (+ beta bias[c]) in row order: what a following backward launch does on the side, as a launch
+__global__ void __launch_bounds__(256) colsum_finish_kernel(const float *__restrict__ parts, int rows, int n, const float *__restrict__ bias,
+                                                            float beta, float *__restrict__ colsum)
+{
+    const int c = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (c >= n) return;
+    float tot = parts[c];
+    for (int r = 1; r < rows; ++r) tot += parts[(size_t)r * n + c];
+    colsum[c] = (beta != 0.f) ? tot + beta * bias[c] : tot;
+}
+
 }  // namespace
 
 extern "C" {
@@ -310,11 +425,50 @@ int sgmcmc_bnn_dense_tanh_f32(const float *h, const float *W, const float *bias,
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh: needs M %% 32 == 0, N %% 64 == 0, K %% 16 == 0, K >= 64, 16-byte aligned rows");
     if ((double)K * ldw * 4.0 >= 2147483648.0 || (double)M * ldh * 4.0 >= 2147483648.0)
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh: an operand spans more than 2 GiB (32-bit buffer offsets)");
-    FwdArgs g{h, W, bias, out, w_next, dot_parts, static_cast<const double *>(stats_ws), tsq_parts, M, N, K, ldh, ldw, ldo};
+    FwdArgs g{h, W, bias, out, w_next, dot_parts, static_cast<const double *>(stats_ws), tsq_parts, M, N, K, ldh, ldw, ldo,
+              nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f, 0, 0};
     const int tiles = (M / BM) * (N / BN);
-    hipLaunchKernelGGL((bnn_dense_tanh_kernel<4>), dim3(tiles), dim3(512), 0, static_cast<hipStream_t>(stream), g);
+    hipLaunchKernelGGL((bnn_dense_tanh_kernel<4, false>), dim3(tiles), dim3(512), 0, static_cast<hipStream_t>(stream), g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "launch bnn_dense_tanh");
+}
+
+/* see include/sgmcmc_hip.h */
+int sgmcmc_bnn_dense_tanh_backward_f32(const float *delta, const float *W, const float *act, float *out, float *colsum_parts,
+                                       int M, int N, int K, int ldd, int ldw, int lda, int ldo, const float *fin_parts,
+                                       int fin_rows, int fin_n, const float *fin_bias, float fin_beta, float *fin_colsum,
+                                       sgmcmc_stream_t stream)
+{
+    if (!delta || !W || !act || !out)
+        return fail(SGMCMC_EINVAL, "bnn_dense_tanh_backward: NULL argument");
+    if (M <= 0 || N <= 0 || K < 64 || M % BM || N % BN || K % 16 || ldd < K || ldw < K || lda < N || ldo < N || ldd % 4 || ldw % 4 ||
+        lda % 4 || ldo % 4 ||
+        ((reinterpret_cast<uintptr_t>(delta) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(act) |
+          reinterpret_cast<uintptr_t>(out)) & 15u))
+        return fail(SGMCMC_EINVAL, "bnn_dense_tanh_backward: needs M %% 32 == 0, N %% 64 == 0, K %% 16 == 0, K >= 64, 16-byte aligned rows");
+    if ((double)N * ldw * 4.0 >= 2147483648.0 || (double)M * ldd * 4.0 >= 2147483648.0)
+        return fail(SGMCMC_EINVAL, "bnn_dense_tanh_backward: an operand spans more than 2 GiB (32-bit buffer offsets)");
+    const int tiles = (M / BM) * (N / BN);
+    if (fin_parts != nullptr &&
+        (!fin_colsum || fin_rows <= 0 || fin_n <= 0 || (fin_beta != 0.f && !fin_bias) || fin_parts == colsum_parts))
+        return fail(SGMCMC_EINVAL, "bnn_dense_tanh_backward: the side job needs fin_colsum, fin_rows > 0, fin_n > 0, fin_bias with "
+                                   "fin_beta != 0 and partial sums other than the ones this launch writes");
+    FwdArgs g{delta, W, nullptr, out, nullptr, nullptr, nullptr, nullptr, M, N, K, ldd, ldw, ldo, act, colsum_parts, lda,
+              fin_parts, fin_bias, fin_colsum, fin_beta, fin_rows, fin_n};
+    hipLaunchKernelGGL((bnn_dense_tanh_kernel<4, true>), dim3(tiles), dim3(512), 0, static_cast<hipStream_t>(stream), g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch bnn_dense_tanh_backward");
+}
+
+/* see include/sgmcmc_hip.h */
+int sgmcmc_colsum_finish_f32(const float *parts, int rows, int n, const float *bias, float beta, float *colsum, sgmcmc_stream_t stream)
+{
+    if (n <= 0) return 0;
+    if (!parts || !colsum || rows <= 0 || (beta != 0.f && !bias)) return fail(SGMCMC_EINVAL, "colsum_finish: NULL argument or no rows");
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), parts,
+                       rows, n, bias, beta, colsum);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch colsum_finish");
 }
 
 }  // extern "C"

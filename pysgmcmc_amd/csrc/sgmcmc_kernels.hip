@@ -655,7 +655,7 @@ __global__ void counter_add_kernel(uint64_t *ctr, uint64_t inc) { *ctr += inc; }
 // (pysgmcmc/data_batches.py:118-123): x rows are contiguous, so the window is ONE contiguous range of X
 template <typename T>
 __global__ void window_gather_kernel(const T *__restrict__ X, const T *__restrict__ y, size_t start, size_t B, size_t D,
-                                     T *__restrict__ xb, T *__restrict__ yb)
+                                     T *__restrict__ xb, size_t ldx, T *__restrict__ yb)
 {
     const size_t nx = B * D;
     const T *__restrict__ src = X + start * D;
@@ -663,10 +663,28 @@ __global__ void window_gather_kernel(const T *__restrict__ X, const T *__restric
     // 16-byte copies when source window and destination are 16-byte aligned (4 elements of f32, 2 of f64 per access)
     constexpr size_t V = 16 / sizeof(T);
     struct alignas(16) Q { T v[V]; };
-    const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(xb)) & 15u) == 0;
-    const size_t nq = vec ? nx / V : 0;
-    for (size_t q = gid; q < nq; q += G) reinterpret_cast<Q *>(xb)[q] = reinterpret_cast<const Q *>(src)[q];
-    for (size_t i = nq * V + gid; i < nx; i += G) xb[i] = src[i];
+    if (ldx == D) {
+        const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(xb)) & 15u) == 0;
+        const size_t nq = vec ? nx / V : 0;
+        for (size_t q = gid; q < nq; q += G) reinterpret_cast<Q *>(xb)[q] = reinterpret_cast<const Q *>(src)[q];
+        for (size_t i = nq * V + gid; i < nx; i += G) xb[i] = src[i];
+    } else {
+        // pitched destination (row stride ldx > D; the columns beyond D are the caller's): row by row
+        const bool vec = D % V == 0 && ldx % V == 0 &&
+                         ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(xb)) & 15u) == 0;
+        if (vec) {
+            const size_t qpr = D / V, lq = ldx / V;
+            for (size_t q = gid; q < B * qpr; q += G) {
+                const size_t r = q / qpr, c = q - r * qpr;
+                reinterpret_cast<Q *>(xb)[r * lq + c] = reinterpret_cast<const Q *>(src)[q];
+            }
+        } else {
+            for (size_t i = gid; i < nx; i += G) {
+                const size_t r = i / D, c = i - r * D;
+                xb[r * ldx + c] = src[i];
+            }
+        }
+    }
     for (size_t i = gid; i < B; i += G) yb[i] = y[start + i];
 }
 
@@ -923,14 +941,15 @@ int sgmcmc_counter_add_u64(uint64_t *counter, uint64_t inc, sgmcmc_stream_t stre
 
 #define SGMCMC_WINDOW_GATHER(SFX, T)                                                                                  \
     int sgmcmc_window_gather_##SFX(const T *X, const T *y, size_t n_data, size_t start, size_t batch, size_t dim,   \
-                                   T *x_out, T *y_out, sgmcmc_stream_t stream)                                       \
+                                   T *x_out, size_t x_out_ld, T *y_out, sgmcmc_stream_t stream)                      \
     {                                                                                                                \
         if (!X || !y || !x_out || !y_out) return fail(SGMCMC_EINVAL, "window_gather: NULL argument");               \
         if (batch == 0 || start + batch > n_data) return fail(SGMCMC_EINVAL, "window_gather: window outside the data"); \
+        if (x_out_ld < dim) return fail(SGMCMC_EINVAL, "window_gather: x_out_ld < dim");                             \
         const size_t total = (batch * dim) / (16 / sizeof(T)) + batch;    /* 16-byte copies: see the kernel */            \
         const size_t blocks = (total + 255) / 256;                                                                   \
         hipLaunchKernelGGL((window_gather_kernel<T>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, \
-                           static_cast<hipStream_t>(stream), X, y, start, batch, dim, x_out, y_out);                 \
+                           static_cast<hipStream_t>(stream), X, y, start, batch, dim, x_out, x_out_ld, y_out);       \
         hipError_t e = hipGetLastError();                                                                            \
         return e == hipSuccess ? 0 : hip_fail(e, "launch window_gather");                                            \
     }

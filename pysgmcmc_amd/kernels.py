@@ -15,7 +15,7 @@ from pysgmcmc_amd._lib import SgmcmcLibraryError, check, lib
 __all__ = [
     "sghmc_step", "sgld_step", "rsghmc_step", "philox_normal", "philox_bits",
     "moments_update", "rhat_pack", "rhat_finish", "summary",
-    "LaunchConfig", "KernelEvents", "StepOpts", "step_stats_records", "step_scalars", "toy_chains", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
+    "LaunchConfig", "KernelEvents", "StepOpts", "step_stats_records", "step_scalars", "toy_chains", "set_launch_config", "get_launch_config", "summary_workspace", "counter_add", "StepStats", "bnn_head", "bnn_dense_tanh_backward", "bnn_dense_tanh_backward_fits", "colsum_finish", "tanh_backward", "tanh_backward_colsum", "bnn_last_layer_backward", "bnn_fused_sghmc_steps", "step_stats_finish",
     "bnn_fused_sgld_steps", "window_gather", "tanh_rowdot", "bias_tanh", "bnn_dense_tanh", "bnn_dense_tanh_fits", "bnn_head_last_layer_backward", "svgd_workspace", "svgd_step", "svgd_kernel", "svgd_max_particles",
 ]
 
@@ -546,6 +546,73 @@ def bnn_dense_tanh(h, W, bias, out, w_next=None, dot_parts=None, stats_workspace
     return out
 
 
+def bnn_dense_tanh_backward_fits(delta, W, act, out):
+    """Can :func:`bnn_dense_tanh_backward` take this layer? ``delta [M, K]``, ``W [N, K]`` (the weights of the layer above, fan-in
+    N), ``act`` / ``out [M, N]``: the limits of :func:`bnn_dense_tanh_fits` with the roles of W's two axes swapped."""
+    if not (delta.is_cuda and delta.dtype == W.dtype == act.dtype == out.dtype == torch.float32
+            and delta.dim() == W.dim() == act.dim() == out.dim() == 2):
+        return False
+    M, K, N = int(delta.shape[0]), int(delta.shape[1]), int(W.shape[0])
+    if W.shape[1] != K or tuple(out.shape) != (M, N) or tuple(act.shape) != (M, N) or M % 32 or N % 64 or K % 16 or K < 64:
+        return False
+    if (M // 32) * (N // 64) > _cu_count(delta.device):
+        return False
+    for t in (delta, W, act, out):
+        if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+            return False
+    return True
+
+
+def bnn_dense_tanh_backward(delta, W, act, out, colsum_parts=None, finish=None):
+    """``out = (delta @ W.T) * (1 - act ** 2)`` in ONE launch on the fp32 matrix cores (``sgmcmc_bnn_dense_tanh_backward_f32``):
+    the backward step through a hidden tanh layer, d cost / d pre-activation of the layer below from the one above.
+    ``colsum_parts [M // 32, N]`` (optional) receives the column sums of ``out`` per 32-row tile -- the bias gradient once its
+    rows are added up, which the NEXT launch does on the side when handed ``finish = (parts, colsum, bias, beta)``
+    (``colsum[:] = parts.sum(0) + beta * bias``, rows added in order), or :func:`colsum_finish`. Deterministic."""
+    M, K = int(delta.shape[0]), int(delta.shape[1])
+    N = int(W.shape[0])
+    if not bnn_dense_tanh_backward_fits(delta, W, act, out):
+        raise ValueError("pysgmcmc_amd: bnn_dense_tanh_backward: shapes / dtypes / alignment do not fit the kernel "
+                         "(see bnn_dense_tanh_backward_fits)")
+    if colsum_parts is not None and (colsum_parts.dtype != delta.dtype or colsum_parts.numel() != (M // 32) * N
+                                     or not colsum_parts.is_contiguous() or colsum_parts.device != delta.device):
+        raise ValueError("pysgmcmc_amd: bnn_dense_tanh_backward: colsum_parts must be a contiguous [M // 32, N] tensor")
+    fin = _colsum_finish_args(finish, delta)
+    if fin[0] is not None and colsum_parts is not None and fin[0] == colsum_parts.data_ptr():
+        raise ValueError("pysgmcmc_amd: bnn_dense_tanh_backward: the finish job needs partial sums other than this launch's own")
+    with torch.cuda.device(delta.device):
+        rc = lib().sgmcmc_bnn_dense_tanh_backward_f32(
+            delta.data_ptr(), W.data_ptr(), act.data_ptr(), out.data_ptr(), _ptr(colsum_parts), M, N, K, delta.stride(0),
+            W.stride(0), act.stride(0), out.stride(0), *fin, _stream(delta))
+    check(rc, "sgmcmc_bnn_dense_tanh_backward_f32")
+    return out
+
+
+def _colsum_finish_args(finish, like):
+    """(parts ptr, rows, n, bias ptr, beta, colsum ptr) of a ``finish = (parts [rows, n], colsum [n], bias [n] | None, beta)`` job."""
+    if finish is None:
+        return (None, 0, 0, None, 0.0, None)
+    parts, colsum, bias, beta = finish
+    n = int(colsum.numel())
+    if (parts.dim() != 2 or parts.shape[1] != n or not parts.is_contiguous() or not colsum.is_contiguous()
+            or parts.dtype != like.dtype or colsum.dtype != like.dtype or parts.device != like.device or colsum.device != like.device
+            or (beta != 0.0 and (bias is None or bias.numel() != n or bias.dtype != like.dtype or not bias.is_contiguous()))):
+        raise ValueError("pysgmcmc_amd: column-sum finish job: parts [rows, n], colsum [n] (and bias [n] with beta != 0) of the launch's dtype / device")
+    return (parts.data_ptr(), int(parts.shape[0]), n, bias.data_ptr() if beta != 0.0 else None, float(beta), colsum.data_ptr())
+
+
+def colsum_finish(parts, colsum, bias=None, beta=0.0):
+    """``colsum[:] = parts.sum(0) (+ beta * bias)``, the rows of ``parts`` added in order: the second half of
+    :func:`bnn_dense_tanh_backward`'s bias gradient as a launch of its own (``sgmcmc_colsum_finish_f32``)."""
+    if parts.dtype != torch.float32 or not parts.is_cuda:
+        raise TypeError("pysgmcmc_amd: colsum_finish takes float32 device tensors")
+    fin = _colsum_finish_args((parts, colsum, bias, beta), parts)
+    with torch.cuda.device(parts.device):
+        rc = lib().sgmcmc_colsum_finish_f32(*fin, _stream(parts))
+    check(rc, "sgmcmc_colsum_finish_f32")
+    return colsum
+
+
 def tanh_rowdot(a, w, out, stats_workspace=None, tsq_parts=None, bias=None):
     """``a = tanh(a [+ bias])`` in place (``[rows, cols]``) and ``out[r] = a[r] . w`` in one launch. With ``stats_workspace``
     (a ``StepStats.workspace``) and ``tsq_parts`` (float64[16] device tensor) the launch also adds up the
@@ -583,14 +650,17 @@ def bnn_head_last_layer_backward(mean, y, log_var, tsq_parts, last_bias, batch_s
 
 
 def window_gather(X, y, start, x_out, y_out):
-    """``x_out[:] = X[start:start + B]``, ``y_out[:] = y[start:start + B]`` in one launch (B = rows of x_out)."""
+    """``x_out[:] = X[start:start + B]``, ``y_out[:] = y[start:start + B]`` in one launch (B = rows of x_out; ``x_out`` may be a
+    pitched view -- rows contiguous, any row stride)."""
     f = getattr(lib(), "sgmcmc_window_gather_" + _sfx(X))
     batch = int(x_out.shape[0])
     dim = int(X.numel() // X.shape[0])
-    if x_out.numel() != batch * dim or y_out.numel() != batch:
+    if x_out.numel() != batch * dim or y_out.numel() != batch or x_out.dim() != 2 or x_out.stride(1) != 1 or x_out.stride(0) < dim:
         raise ValueError("pysgmcmc_amd: window_gather output shapes do not match the window")
-    with _on(X):
-        rc = f(_ptr(X), _ptr(y), int(X.shape[0]), int(start), batch, dim, _ptr(x_out), _ptr(y_out), _stream(X))
+    if x_out.dtype != X.dtype or y_out.dtype != X.dtype or x_out.device != X.device or not y_out.is_contiguous():
+        raise TypeError("pysgmcmc_amd: window_gather outputs must have the dataset's dtype and device")
+    with torch.cuda.device(X.device):
+        rc = f(_ptr(X), _ptr(y), int(X.shape[0]), int(start), batch, dim, x_out.data_ptr(), int(x_out.stride(0)), _ptr(y_out), _stream(X))
     check(rc, "sgmcmc_window_gather")
 
 

@@ -192,6 +192,14 @@ class BNNCost(object):
         # activation launch: 195.1 -> 188.6 us per step with the first two layers on it (tools/fwd_fused_step_probe.py). Other
         # shapes (the reference's 3 x 50 net, batch 20) keep the library products.
         self.fused_dense = True
+        # the backward step through a hidden layer the same way: delta W^T with tanh' of the layer below and its bias gradient as
+        # the epilogue (kernels.bnn_dense_tanh_backward) instead of library GEMM + tanh_backward_colsum
+        self.fused_dense_backward = True
+        # the first layer's bias gradient as the extra row of its weight-gradient product, [x | 1]^T delta = [gW_0 ; gb_0] (785 rows
+        # cost the library what 784 do; on the 2048-wide layers the 2049th row costs 4 us: tools/gw_ones_row_probe.py): the
+        # sampler's static feed buffer for x comes from static_feed_buffer() below, pitched, with the ones behind the data
+        self.bias_gradient_from_product = True
+        self._x_ext = None
         # (Forking the weight-gradient GEMMs onto a second stream inside the captured graph was measured
         # on MI355X at batch 256: 291 us/step vs 275 us on one stream -- not kept.)
 
@@ -217,6 +225,24 @@ class BNNCost(object):
         return -log_like, torch.mean(mse)
 
     # -- fused analytic path (MLP): gradients land in the arena --
+    @property
+    def wants_static_feeds(self):
+        """The sampler should feed this cost function through static buffers (see :meth:`static_feed_buffer`) in every stepping
+        mode, so that eager and hipGraph stepping run the same arithmetic."""
+        return bool(self.use_hip_kernels and self.bias_gradient_from_product)
+
+    def static_feed_buffer(self, placeholder, value):
+        """Buffer the sampler's hipGraph modes should keep feeding ``placeholder`` through (``None``: no preference). For x on
+        the HIP path: a ``[batch, dim]`` view of a ``[batch, dim + 4]`` buffer whose column ``dim`` holds ones, so that
+        ``[x | 1]^T delta`` is the first layer's weight AND bias gradient in one product."""
+        if (placeholder is not self.x_placeholder or not self.use_hip_kernels or not self.bias_gradient_from_product
+                or not value.is_cuda or value.dtype != torch.float32 or value.dim() != 2 or value.shape[1] % 4):
+            return None
+        ext = torch.zeros(value.shape[0], value.shape[1] + 4, dtype=value.dtype, device=value.device)
+        ext[:, value.shape[1]] = 1.0
+        self._x_ext = ext
+        return ext[:, :value.shape[1]]
+
     def _buffers(self, params, B):
         key = (B, params[0].dtype, params[0].device)
         ws = self._ws.get(key)
@@ -331,6 +357,19 @@ class BNNCost(object):
                              grad_last_bias_out=grad_views[2 * L + 1] if single_out else None,
                              add_last_bias=single_out)
         self.last_mse = ws["mse"]
+        # first layer's bias gradient from its weight-gradient product: X is the cost function's own pitched feed buffer with a
+        # column of ones behind the data (static_feed_buffer), and [W_0 ; b_0] is one contiguous matrix in both arenas
+        D_in = int(X.shape[1])
+        ext = self._x_ext
+        ones_row = (self.bias_gradient_from_product and ext is not None and L >= 2 and X.data_ptr() == ext.data_ptr()
+                    and X.shape[0] == ext.shape[0] and X.stride(0) == ext.stride(0) and ext.shape[1] > D_in
+                    and all(t[0].is_contiguous() and t[1].is_contiguous()
+                            and t[1].data_ptr() == t[0].data_ptr() + t[0].numel() * t[0].element_size()
+                            for t in ((grad_views[0], grad_views[1]),) + (() if self.fold_prior else ((params[0], params[1]),))))
+        pending, parts_turn = None, 0                         # column sums a fused backward launch left to be added up
+        if self.fused_dense_backward and "colsum_parts" not in ws and X.is_cuda and X.dtype == torch.float32 and B % 32 == 0:
+            widest = max(int(p.shape[0]) for p in params[0:-1:2])
+            ws["colsum_parts"] = [torch.zeros((B // 32) * widest, dtype=X.dtype, device=X.device) for _ in range(2)]
         for l in range(L, -1, -1):
             h_in = X if l == 0 else hs[l - 1]
             W, b = params[2 * l], params[2 * l + 1]
@@ -343,11 +382,36 @@ class BNNCost(object):
                                                 bias_prev=params[2 * (l - 1) + 1], beta=beta)
                 continue
             # delta_{l-1} = delta_l W_l^T first (the last reader of W_l), then gW_l
+            fused_back = False
+            # the first layer's bias gradient comes out of its weight-gradient product (below): no column sums for it here
+            below_from_product = l == 1 and ones_row
             if l > 0:
-                torch.mm(ds[l], W.t(), out=ds[l - 1])
+                fused_back = self.fused_dense_backward and kernels.bnn_dense_tanh_backward_fits(ds[l], W, hs[l - 1], ds[l - 1])
+                if fused_back:
+                    # product and tanh' of the layer below in ONE launch; the bias gradient of the layer below as column sums
+                    # per 32-row tile, added up on the side by the NEXT such launch (or by a small launch after the loop) --
+                    # which is also how this launch finishes the sums of the one before it
+                    parts = None
+                    if not below_from_product:
+                        n_tiles, width = B // 32, int(W.shape[0])
+                        parts = ws["colsum_parts"][parts_turn][:n_tiles * width].view(n_tiles, width)
+                        parts_turn ^= 1
+                    kernels.bnn_dense_tanh_backward(ds[l], W, hs[l - 1], ds[l - 1], colsum_parts=parts, finish=pending)
+                    pending = None if parts is None else (parts, grad_views[2 * (l - 1) + 1], params[2 * (l - 1) + 1].view(-1), beta)
+                else:
+                    torch.mm(ds[l], W.t(), out=ds[l - 1])
             # gW_l = h_{l-1}^T delta_l written directly into the gradient arena. The weight-prior term
             # coef * theta is added by the update kernel (fold_prior) or rides in the GEMM epilogue (beta).
-            if self.fold_prior:
+            if l == 0 and ones_row:
+                # [x | 1]^T delta = [gW_0 ; gb_0] onto the arena's [W_0 ; b_0] slice: 785 rows cost the library what 784 do
+                x1 = self._x_ext[:, :D_in + 1]
+                width = int(W.shape[1])
+                gWb = torch.as_strided(grad_views[0], (D_in + 1, width), (width, 1))
+                if self.fold_prior:
+                    torch.mm(x1.t(), ds[0], out=gWb)
+                else:
+                    torch.addmm(torch.as_strided(W, (D_in + 1, width), (width, 1)), x1.t(), ds[0], beta=prior_coef, alpha=1.0, out=gWb)
+            elif self.fold_prior:
                 torch.mm(h_in.t(), ds[l], out=grad_views[2 * l])
             else:
                 torch.addmm(W, h_in.t(), ds[l], beta=prior_coef, alpha=1.0, out=grad_views[2 * l])
@@ -357,10 +421,18 @@ class BNNCost(object):
                     torch.mv(ds[l].t(), ws["ones"], out=grad_views[2 * l + 1])
                 else:
                     torch.addmv(b, ds[l].t(), ws["ones"], beta=prior_coef, alpha=1.0, out=grad_views[2 * l + 1])
-            if l > 0:
-                # delta_{l-1} *= 1 - h_{l-1}^2, and gb_{l-1} = column sums of the result (+ beta * b_{l-1})
-                kernels.tanh_backward_colsum(ds[l - 1], hs[l - 1], grad_views[2 * (l - 1) + 1],
-                                             bias=params[2 * (l - 1) + 1], beta=beta)
+            if l > 0 and not fused_back:
+                if pending is not None:
+                    kernels.colsum_finish(*pending)
+                    pending = None
+                if below_from_product:
+                    kernels.tanh_backward(ds[l - 1], hs[l - 1])
+                else:
+                    # delta_{l-1} *= 1 - h_{l-1}^2, and gb_{l-1} = column sums of the result (+ beta * b_{l-1})
+                    kernels.tanh_backward_colsum(ds[l - 1], hs[l - 1], grad_views[2 * (l - 1) + 1],
+                                                 bias=params[2 * (l - 1) + 1], beta=beta)
+        if pending is not None:
+            kernels.colsum_finish(*pending)
         return ws["cost"].reshape(())
 
     def _cost_and_grad_torch(self, params, grad_views, theta_sumsq):

@@ -413,9 +413,16 @@ class MCMCSampler(object):
             feed_dict = dict()
         if self.use_hip_graph and self.noise_source is None and self.device.type == "cuda":
             return self._step_graph(feed_dict)
-        feed_dict.update(self._next_batch())
-        eps = self._next_stepsize()
-        self._feed(feed_dict)
+        eps = None
+        if self.device.type == "cuda" and getattr(self.cost_fun, "wants_static_feeds", False):
+            # a cost function whose arithmetic depends on being fed through its own buffers (BNNCost: the first layer's bias
+            # gradient from the [x | 1]^T delta product) gets them in eager stepping too: eager == hipGraph stepping, bit for bit
+            self._feed_static(feed_dict)
+            eps = self._next_stepsize()
+        else:
+            feed_dict.update(self._next_batch())
+            eps = self._next_stepsize()
+            self._feed(feed_dict)
         cost = self._cost_and_grad()          # U(theta_{t-1}) and its gradient
         self.cost = cost
         with torch.no_grad():
@@ -452,7 +459,13 @@ class MCMCSampler(object):
             value = placeholder.feed(value).value
             buf = self._static_feeds.get(placeholder)
             if buf is None or buf.shape != value.shape or buf.dtype != value.dtype:
-                buf = value.clone()
+                # the cost function may bring its own buffer (BNNCost: x pitched, with a column of ones behind the data)
+                make = getattr(self.cost_fun, "static_feed_buffer", None)
+                buf = make(placeholder, value) if make is not None else None
+                if buf is None:
+                    buf = value.clone()
+                else:
+                    buf.copy_(value)
                 self._static_feeds[placeholder] = buf
                 self._graphs.clear()
             else:

@@ -1,6 +1,8 @@
 """``sgmcmc_bnn_dense_tanh_f32``: a hidden layer of the BNN forward pass (``pysgmcmc/models/bayesian_neural_network.py:30-56``)
-as ONE launch -- fp32 matrix-core product with bias + tanh (and the output unit's partial dot products) as its epilogue -- against
-an fp64 product, against the library path of ``BNNCost`` (GEMM + activation launch), and in the sampler's chain."""
+as ONE launch -- fp32 matrix-core product with bias + tanh (and the output unit's partial dot products) as its epilogue -- and
+``sgmcmc_bnn_dense_tanh_backward_f32``, the backward step through such a layer (delta W^T with tanh' and the bias gradient as the
+epilogue), against fp64 products, against the library path of ``BNNCost`` (GEMM + activation / tanh' launches), and in the
+sampler's chain."""
 import numpy as np
 import pytest
 import torch
@@ -53,37 +55,131 @@ def test_dense_tanh_refuses_what_it_cannot_take(gpu):
                                tsq_parts=torch.zeros(16, dtype=torch.float64, device=gpu))
 
 
-def _cost(gpu, fused, batch, hidden, n_in=64, seed=3):
+@pytest.mark.parametrize("M,K,N", [(256, 2048, 2048), (256, 2048, 784 + 48), (32, 64, 64), (64, 80, 128), (96, 272, 192), (32, 1040, 64),
+                                   (160, 64, 320)])
+def test_dense_tanh_backward_equals_an_fp64_product(gpu, M, K, N):
+    """out = (delta W^T) (1 - act^2) and its column sums per 32-row tile: every K tail, one and several row tiles, XCD map on and
+    off, pitched operands. The row tiles are added up -- in order -- by a small launch or by the NEXT backward launch on the
+    side: same bits either way, and from launch to launch."""
+    from pysgmcmc_amd import kernels
+    g = torch.Generator(device=gpu).manual_seed(M + 3 * K + N)
+    dbuf = torch.randn(M, K + 4, device=gpu, generator=g)
+    delta = dbuf[:, :K]
+    Wbuf = torch.randn(N, K + 12, device=gpu, generator=g) / K ** 0.5
+    W = Wbuf[:, :K]                                              # [fan-in N of the layer above][its fan-out K], pitched
+    act = torch.tanh(torch.randn(M, N, device=gpu, generator=g))
+    bias = torch.randn(N, device=gpu, generator=g)
+    out = torch.full((M + 1, N), -7.0, device=gpu)
+    parts = torch.full((M // 32 + 1, N), -3.0, device=gpu)
+    assert kernels.bnn_dense_tanh_backward_fits(delta, W, act, out[:M])
+    kernels.bnn_dense_tanh_backward(delta, W, act, out[:M], colsum_parts=parts[:M // 32])
+    ref = (delta.double() @ W.double().t()) * (1.0 - act.double() ** 2)
+    scale = max(float(ref.abs().max()), 1.0)
+    assert float((out[:M].double() - ref).abs().max()) < 4e-6 * scale and torch.all(out[M] == -7.0)
+    tiles = out[:M].double().view(M // 32, 32, N).sum(1)         # the partial rows are sums of the fp32 outputs
+    assert torch.allclose(parts[:M // 32].double(), tiles, rtol=0, atol=1e-4 * scale) and torch.all(parts[M // 32] == -3.0)
+    colsum = torch.full((N + 4,), -5.0, device=gpu)
+    kernels.colsum_finish(parts[:M // 32], colsum[:N])
+    assert torch.allclose(colsum[:N].double(), ref.sum(0), rtol=0, atol=2e-5 * M ** 0.5 * scale) and torch.all(colsum[N:] == -5.0)
+    c_beta = torch.empty(N, device=gpu)
+    kernels.colsum_finish(parts[:M // 32], c_beta, bias=bias, beta=0.25)
+    assert torch.allclose(c_beta, colsum[:N] + 0.25 * bias, rtol=1e-6, atol=1e-6 * scale)
+    # the same sums as the side job of a following launch (which leaves its own partial rows elsewhere), bit for bit
+    for beta, want in ((0.0, colsum[:N]), (0.25, c_beta)):
+        o2, p2, c2 = torch.empty(M, N, device=gpu), torch.empty(M // 32, N, device=gpu), torch.full((N,), 9.0, device=gpu)
+        kernels.bnn_dense_tanh_backward(delta, W, act, o2, colsum_parts=p2, finish=(parts[:M // 32], c2, bias, beta))
+        assert torch.equal(o2, out[:M]) and torch.equal(p2, parts[:M // 32]) and torch.equal(c2, want)
+    # a finish job wider than 64 columns per workgroup of the launch that carries it
+    wide = torch.randn(3, 64 * (M // 32) * (N // 64) + 200, device=gpu, generator=g)
+    cw = torch.empty(wide.shape[1], device=gpu)
+    kernels.bnn_dense_tanh_backward(delta, W, act, torch.empty(M, N, device=gpu), finish=(wide, cw, None, 0.0))
+    assert torch.equal(cw, (wide[0] + wide[1]) + wide[2])
+    # without column sums: same outputs
+    o3 = torch.empty(M, N, device=gpu)
+    kernels.bnn_dense_tanh_backward(delta, W, act, o3)
+    assert torch.equal(o3, out[:M])
+
+
+def test_dense_tanh_backward_refuses_what_it_cannot_take(gpu):
+    from pysgmcmc_amd import kernels
+    d, W = torch.randn(256, 2048, device=gpu), torch.randn(2048, 2048, device=gpu)
+    act, out = torch.zeros(256, 2048, device=gpu), torch.empty(256, 2048, device=gpu)
+    parts = torch.zeros(8, 2048, device=gpu)
+    assert kernels.bnn_dense_tanh_backward_fits(d, W, act, out)
+    assert not kernels.bnn_dense_tanh_backward_fits(d[:20], W, act[:20], out[:20])
+    assert not kernels.bnn_dense_tanh_backward_fits(d.double(), W.double(), act.double(), out.double())
+    assert not kernels.bnn_dense_tanh_backward_fits(d[:, :48].contiguous(), W[:, :48].contiguous(), act, out)      # K < 64
+    assert not kernels.bnn_dense_tanh_backward_fits(d, W[:50], act[:, :50].contiguous(), out[:, :50].contiguous())  # N % 64
+    with pytest.raises(ValueError, match="bnn_dense_tanh_backward"):
+        kernels.bnn_dense_tanh_backward(d[:20], W, act[:20], out[:20])
+    with pytest.raises(ValueError, match="colsum_parts"):
+        kernels.bnn_dense_tanh_backward(d, W, act, out, colsum_parts=torch.zeros(4, 2048, device=gpu))
+    with pytest.raises(ValueError, match="other than this launch's own"):
+        kernels.bnn_dense_tanh_backward(d, W, act, out, colsum_parts=parts, finish=(parts, torch.empty(2048, device=gpu), None, 0.0))
+    with pytest.raises(ValueError, match="finish job"):
+        kernels.bnn_dense_tanh_backward(d, W, act, out, finish=(torch.zeros(8, 2048, device=gpu), torch.empty(2048, device=gpu), None, 0.5))
+    with pytest.raises(ValueError, match="finish job"):
+        kernels.colsum_finish(torch.zeros(8, 100, device=gpu), torch.empty(64, device=gpu))
+
+
+def test_window_gather_into_a_pitched_buffer(gpu):
+    """The static feed buffer of BNNCost is pitched (a column of ones behind the data): the gather fills the data columns only."""
+    from pysgmcmc_amd import kernels
+    for dt, dim in ((torch.float32, 784), (torch.float32, 13), (torch.float64, 6)):
+        X = torch.randn(500, dim, device=gpu, dtype=dt)
+        y = torch.randn(500, device=gpu, dtype=dt)
+        ext = torch.full((64, dim + 4), 7.0, device=gpu, dtype=dt)
+        yb = torch.empty(64, device=gpu, dtype=dt)
+        kernels.window_gather(X, y, 101, ext[:, :dim], yb)
+        assert torch.equal(ext[:, :dim], X[101:165]) and torch.all(ext[:, dim:] == 7.0) and torch.equal(yb, y[101:165])
+
+
+def _cost(gpu, fused, batch, hidden, n_in=64, seed=3, own_feed_buffer=False):
     from pysgmcmc_amd.data_batches import Placeholder
     from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
     xp, yp = Placeholder(dtype=torch.float32, device=gpu), Placeholder(dtype=torch.float32, device=gpu)
     g = torch.Generator(device=gpu).manual_seed(seed)
-    xp.feed(torch.randn(batch, n_in, device=gpu, generator=g))
+    x = torch.randn(batch, n_in, device=gpu, generator=g)
     yp.feed(torch.randn(batch, 1, device=gpu, generator=g))
     params = init_mlp_params(n_in, hidden=hidden, seed=seed, dtype=torch.float32, device=gpu)
     for p in params[1:-1:2]:
         p.normal_(0.0, 0.2, generator=g)                         # non-zero biases
     cost = BNNCost(xp, yp, batch_size=batch, n_examples=1000)
-    cost.fused_dense = fused
+    cost.fused_dense = cost.fused_dense_backward = cost.bias_gradient_from_product = fused
+    if own_feed_buffer:                                          # as the sampler's hipGraph modes feed x: pitched, ones behind the data
+        buf = cost.static_feed_buffer(xp, x)
+        assert buf is not None and buf.stride(0) == n_in + 4
+        buf.copy_(x)
+        xp.value = buf
+    else:
+        xp.feed(x)
     return cost, params
 
 
-@pytest.mark.parametrize("batch,hidden", [(256, (128, 128, 128)), (64, (128, 64)), (32, (64, 64, 64))])
-def test_cost_path_with_fused_dense_layers_equals_the_library_path(gpu, batch, hidden):
-    """BNNCost.fused_dense: same cost, mse and gradients as GEMM + activation launches to matrix-product rounding -- with the
-    output unit's dot product and the sum(theta^2) slices riding in the last hidden layer's launch (256 x 128: 16 tiles) and
-    without (fewer tiles: that layer keeps the library product + rowdot launch)."""
+@pytest.mark.parametrize("fold_prior", [True, False])
+@pytest.mark.parametrize("batch,hidden,own_feed_buffer", [(256, (128, 128, 128), False), (256, (128, 128, 128), True), (64, (128, 64), True),
+                                                          (32, (64, 64, 64), False), (32, (64, 64, 64), True)])
+def test_cost_path_with_fused_dense_layers_equals_the_library_path(gpu, batch, hidden, own_feed_buffer, fold_prior):
+    """BNNCost.fused_dense / fused_dense_backward: same cost, mse and gradients as GEMM + activation / tanh' launches to
+    matrix-product rounding -- with the output unit's dot product and the sum(theta^2) slices riding in the last hidden layer's
+    launch (256 x 128: 16 tiles) and without (fewer tiles: that layer keeps the library product + rowdot launch); with the first
+    layer's bias gradient from the [x | 1]^T delta product (the cost function's own pitched feed buffer, gradients in one arena)
+    and from the column sums a last small launch adds up; weight prior folded into the update or in the gradients."""
     from pysgmcmc_amd import kernels
     res = []
     for fused in (False, True):
-        cost, params = _cost(gpu, fused, batch, hidden)
+        cost, params = _cost(gpu, fused, batch, hidden, own_feed_buffer=own_feed_buffer and fused)
+        cost.fold_prior = fold_prior
         n = sum(p.numel() for p in params)
-        st = kernels.StepStats(n, gpu)                           # sum(theta^2) records as a step kernel leaves them
         flat = torch.cat([p.reshape(-1) for p in params])
+        offs = np.cumsum([0] + [p.numel() for p in params])
+        params = [flat[offs[k]:offs[k + 1]].view(p.shape) for k, p in enumerate(params)]      # one arena, as in the sampler
+        st = kernels.StepStats(n, gpu)                           # sum(theta^2) records as a step kernel leaves them
         kernels.sghmc_step(flat.clone(), torch.zeros(n, device=gpu), torch.zeros(n, device=gpu), None, None, None,
                            torch.ones(n, device=gpu), None, 0.0, 1.0, 0.0, False, xi=torch.zeros(n, device=gpu), stats=st,
                            opts=dict(theta_sq_only=True))
-        grads = [torch.full_like(p, float("nan")) for p in params]
+        gflat = torch.full((n,), float("nan"), device=gpu)
+        grads = [gflat[offs[k]:offs[k + 1]].view(p.shape) for k, p in enumerate(params)]
         c = cost.cost_and_grad(params, grads, theta_sumsq_partials=st.workspace)
         res.append((float(c), float(cost.last_mse), [g.clone() for g in grads]))
     (c0, m0, g0), (c1, m1, g1) = res
@@ -107,7 +203,7 @@ def test_chain_with_fused_dense_layers_tracks_the_library_chain(gpu):
         xp, yp = Placeholder(dtype=torch.float32, device=gpu), Placeholder(dtype=torch.float32, device=gpu)
         params = init_mlp_params(64, hidden=(128, 128, 128), seed=5, dtype=torch.float32, device=gpu)
         cost = BNNCost(xp, yp, batch_size=256, n_examples=2000)
-        cost.fused_dense = fused
+        cost.fused_dense = cost.fused_dense_backward = cost.bias_gradient_from_product = fused
         s = SGHMCSampler(params=params, cost_fun=cost, batch_generator=generate_batches(X, y, xp, yp, batch_size=256, seed=2),
                          stepsize_schedule=ConstantStepsizeSchedule(0.01), burn_in_steps=5, scale_grad=2000.0, session=gpu,
                          dtype=torch.float32, seed=9)
