@@ -389,7 +389,7 @@ class ChainBench(object):
                 "launches_timed": int(u_us.size), "step_ms_median": round(serial_step_us * 1e-3, 4),
                 "note": "the same chain, %d steps after the timed region with the timer on EVERY update launch and no moments "
                         "steps: the kernel alone in the pipeline, as rounds 1-2 reported `roofline`" % n_legs}
-            g_us, g_flops, n_fused = legs.gemm_only_us(sampler)
+            g_us, g_flops, n_fused, n_fused_back = legs.gemm_only_us(sampler)
             c_us = legs.cost_pipeline_us(sampler)
             meas_us = float(np.median(self.step_ms)) * 1e3 if self.step_ms is not None else None
             line["step_breakdown_us"] = {
@@ -399,11 +399,15 @@ class ChainBench(object):
                 "gemm_tflops": round(g_flops / (g_us * 1e-6) / 1e12, 1),
                 "gemm_frac_of_fp32_mfma_peak": round(g_flops / (g_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3),
                 "gemm_flop_per_step": int(g_flops), "forward_layers_on_the_fused_launch": n_fused,
-                "note": "gemm = the step's eight fp32 products replayed alone from a hipGraph: five library GEMMs (backward) + the "
-                        "three forward layers as the pipeline runs them (%d of them as ONE launch each with bias + tanh as the "
-                        "product's epilogue, sgmcmc_bnn_dense_tanh_f32: their activation is then inside `gemm`); small_launches = the "
-                        "captured cost pipeline alone minus gemm (window gather aside: tanh-backward + bias gradient, loss head, and the "
-                        "activation launches of forward layers on the library product); " % n_fused +
+                "backward_products_on_the_fused_launch": n_fused_back,
+                "note": "gemm = the step's eight fp32 products replayed alone from a hipGraph, each as the pipeline runs it: "
+                        "the three forward layers (%d of them as ONE launch each with bias + tanh as the product's epilogue, "
+                        "sgmcmc_bnn_dense_tanh_f32), the two delta W^T products (%d of them with tanh' of the layer below as the "
+                        "epilogue, sgmcmc_bnn_dense_tanh_backward_f32) and three library weight-gradient GEMMs (the first layer's "
+                        "with its bias gradient as a 785th row) -- activations and tanh' are then inside `gemm`; small_launches = the "
+                        "captured cost pipeline alone minus gemm (window gather aside: the loss head, the per-row-tile column sums in "
+                        "the backward launches' epilogues, and the activation / tanh' launches of layers on library products); "
+                        % (n_fused, n_fused_back) +
                         "update = the fused update launched once after the backward pass. Differences of graph replays: rocprofv3's "
                         "per-kernel durations of the same step (profiles/r04_bench10m_kernel_stats.csv) carry ~1.5 us of profiler "
                         "overhead per kernel. The fp32 MFMA peak is quoted at "
