@@ -25,6 +25,10 @@ class HookedBNNCost(BNNCost):
         # weight-gradient products gW = h^T delta: "blas" (rocBLAS / hipBLASLt through torch) or "mfma" (gemm_kernels.gemm_tn,
         # the product the fused GEMM + update kernel forms: same bits as that kernel's gradient)
         self.gw_gemm = "blas"
+        # the round-3 pipeline as it was measured: library / experiment products on dense operands (no pitched feed buffer with
+        # the bias gradient's column of ones, no fused backward products -- both came after these experiments)
+        self.bias_gradient_from_product = False
+        self.fused_dense_backward = False
 
     @torch.no_grad()
     def cost_and_grad(self, params, grad_views, theta_sumsq=None, theta_sumsq_partials=None, weight_update=None):
