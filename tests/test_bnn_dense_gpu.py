@@ -191,7 +191,8 @@ def test_cost_path_with_fused_dense_layers_equals_the_library_path(gpu, batch, h
 def test_chain_with_fused_dense_layers_tracks_the_library_chain(gpu):
     """A 14-step SGHMC chain (burn-in switch inside) on a net whose layers all take the fused launch agrees with the chain on
     the library products to accumulated matrix-product rounding (f32 2e-4, the bar of the fused small-model kernel), in eager
-    and hipGraph stepping; the fused chain is bit-reproducible."""
+    and both hipGraph stepping modes -- which give the SAME bits as each other (eager steps are fed through the cost function's pitched
+    buffer too); the fused chain is bit-reproducible."""
     from pysgmcmc_amd.data_batches import Placeholder, generate_batches
     from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
     from pysgmcmc_amd.samplers import SGHMCSampler
@@ -211,9 +212,11 @@ def test_chain_with_fused_dense_layers_tracks_the_library_chain(gpu):
         costs = [float(next(s)[1]) for _ in range(14)]
         return s.arena.row("theta").clone(), costs
     ref, cref = chain(False, False)
-    for graph in (False, True):
-        th, c = chain(True, graph)
-        assert torch.allclose(th, ref, rtol=2e-4, atol=2e-5) and np.allclose(c, cref, rtol=2e-5)
-    a, _ = chain(True, True)
+    got = {}
+    for graph in (False, True, "full"):
+        got[graph], c = chain(True, graph)
+        assert torch.allclose(got[graph], ref, rtol=2e-4, atol=2e-5) and np.allclose(c, cref, rtol=2e-5)
+    # eager stepping feeds the cost function through the same pitched buffer as the graph modes: same arithmetic, same bits
+    assert torch.equal(got[False], got[True]) and torch.equal(got[True], got["full"])
     b, _ = chain(True, True)
-    assert torch.equal(a, b)
+    assert torch.equal(got[True], b)
