@@ -158,7 +158,8 @@ def _cost(gpu, fused, batch, hidden, n_in=64, seed=3, own_feed_buffer=False):
 
 @pytest.mark.parametrize("fold_prior", [True, False])
 @pytest.mark.parametrize("batch,hidden,own_feed_buffer", [(256, (128, 128, 128), False), (256, (128, 128, 128), True), (64, (128, 64), True),
-                                                          (32, (64, 64, 64), False), (32, (64, 64, 64), True)])
+                                                          (32, (64, 64, 64), False), (32, (64, 64, 64), True),
+                                                          (20, (48, 40, 24), True)])     # nothing fits the fused launches: library products, bias row still there
 def test_cost_path_with_fused_dense_layers_equals_the_library_path(gpu, batch, hidden, own_feed_buffer, fold_prior):
     """BNNCost.fused_dense / fused_dense_backward: same cost, mse and gradients as GEMM + activation / tanh' launches to
     matrix-product rounding -- with the output unit's dot product and the sum(theta^2) slices riding in the last hidden layer's
