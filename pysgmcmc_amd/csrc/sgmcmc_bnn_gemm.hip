@@ -1,8 +1,12 @@
-// sgmcmc_bnn_gemm.hip -- a hidden layer of the BNN forward pass (pysgmcmc/models/bayesian_neural_network.py:30-52) as ONE launch:
-// fp32 matrix-core product with bias + tanh (and, for the last hidden layer, the single output unit's dot product) as its epilogue.
+// sgmcmc_bnn_gemm.hip -- a hidden layer of the BNN (pysgmcmc/models/bayesian_neural_network.py:30-52) as ONE launch per direction:
+// fp32 matrix-core products with the layer's elementwise work as their epilogue.
 //
+// forward (sgmcmc_bnn_dense_tanh_f32): bias + tanh, and for the last hidden layer the single output unit's dot product
 //   out[m][n] = tanh( sum_k h[m][k] W[k][n] + b[n] )            h [M = batch][K], W [K][N] row-major (the arena's layout)
 //   dot_parts[t][m] = sum_{n in column tile t} out[m][n] w_next[n]   (optional; the Dense(1) layer of :53-56, added up by the loss head)
+// backward (sgmcmc_bnn_dense_tanh_backward_f32; what tf.gradients builds for the same lines): tanh' and the bias gradient's column sums
+//   out[m][n] = ( sum_k delta[m][k] W[n][k] ) (1 - act[m][n]^2)  delta [M][K], W [N][K]: the same W, read along its rows
+//   colsum_parts[t][n] = sum of out[m][n] over row tile t        (optional; row tiles added up by the next launch, see the kernel)
 //
 // Replaces library GEMM + sgmcmc_bias_tanh_f32 (+ sgmcmc_bias_tanh_rowdot_f32 for the last hidden layer). In isolation it
 // only ties that pair on the 2048 x 2048 layer (19.5-20.2 vs 21.1-21.5 us; it was an experiment that missed its gate, see
