@@ -56,6 +56,28 @@ def test_bnn_cost_matches_oracle_and_fused_path(oracle):
         assert np.allclose(a.numpy(), b, rtol=1e-10, atol=1e-14)
 
 
+def test_fused_layer_launches_are_device_only():
+    """The one-launch layer kernels (forward / backward) and the pitched feed buffer belong to the HIP path: on host tensors the
+    shape checks say no, the launches refuse loudly, and the cost function offers no buffer -- nothing falls back silently."""
+    from pysgmcmc_amd import kernels
+    from pysgmcmc_amd._lib import SgmcmcLibraryError
+    h, W, out = torch.zeros(32, 64), torch.zeros(64, 64), torch.zeros(32, 64)
+    assert not kernels.bnn_dense_tanh_fits(h, W, out)
+    assert not kernels.bnn_dense_tanh_backward_fits(h, W, out, torch.zeros(32, 64))
+    with pytest.raises((ValueError, SgmcmcLibraryError)):
+        kernels.bnn_dense_tanh(h, W, torch.zeros(64), out)
+    with pytest.raises((ValueError, SgmcmcLibraryError)):
+        kernels.bnn_dense_tanh_backward(h, W, out, torch.zeros(32, 64))
+    with pytest.raises((TypeError, SgmcmcLibraryError)):
+        kernels.colsum_finish(torch.zeros(2, 64), torch.zeros(64))
+    xp, yp = Placeholder().feed(torch.zeros(32, 64)), Placeholder().feed(torch.zeros(32, 1))
+    c = BNNCost(xp, yp, batch_size=32, n_examples=100)
+    assert c.wants_static_feeds                                  # HIP path (the default): feed me through my own buffers
+    assert c.static_feed_buffer(xp, xp.value) is None            # ... which exist on the device only
+    c.use_hip_kernels = False
+    assert not c.wants_static_feeds
+
+
 def test_init_seeding_and_shapes():
     """tests/bayesian_neural_network/test_seeding.py: same seed => identical initial weights."""
     a, b, c = init_mlp_params(1, seed=7), init_mlp_params(1, seed=7), init_mlp_params(1, seed=8)
