@@ -447,7 +447,7 @@ int sgmcmc_colsum_finish_f32(const float *parts, int rows, int n, const float *b
  * ~5 us): `mean` [n_mean_parts][rows] is the single-output layer's pre-bias output -- n_mean_parts = 1: the vector
  * sgmcmc_tanh_rowdot_* writes; > 1: the per-column-tile partial dot products sgmcmc_bnn_dense_tanh_f32 writes, added here
  * in order (rows <= 1024) --, tsq_parts the slices of sum(theta^2) that launch left; d cost/d mean is formed on the fly by
- * every workgroup, workgroup 0 writes the head's scalar outputs. Arguments as in the two separate entry points
+ * every workgroup, one extra workgroup writes the head's scalar outputs. Arguments as in the two separate entry points
  * (fold_prior_grad: the same bit mask).                                                                            */
 int sgmcmc_bnn_head_last_layer_backward_f32(
     const float *mean, size_t n_mean_parts, const float *y, const float *log_var, const double *tsq_parts, const float *last_bias, size_t rows,

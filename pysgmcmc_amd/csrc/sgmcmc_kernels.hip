@@ -505,8 +505,9 @@ __global__ void __launch_bounds__(1024) last_layer_backward_kernel(const T *__re
 }
 
 // The loss head (bnn_head_kernel) folded into the backward of a single-output last layer: dvec[r] = d cost / d mean_r is a
-// function of the residual and the scalar log-variance only, so every workgroup forms it on the fly; workgroup 0 also
-// reduces the residuals and writes the head's scalar outputs (cost, d cost/d log_var, mse, last bias gradient).
+// function of the residual and the scalar log-variance only, so every workgroup forms it on the fly; one extra
+// workgroup (the last of the grid, no columns of its own) reduces the residuals and writes the head's scalar outputs (cost,
+// d cost/d log_var, mse, last bias gradient).
 // sum(theta^2) arrives as the n_tsq slices tanh_rowdot_kernel left in tsq_parts. One launch less per step.
 constexpr int HEAD_MAX_PART_ROWS = 1024;                     // batch rows when the mean arrives as partial dot products
 template <typename T>
@@ -521,43 +522,92 @@ __global__ void __launch_bounds__(1024) head_last_layer_backward_kernel(
     __shared__ double lds_h[2][16];
     __shared__ T mean_lds[HEAD_MAX_PART_ROWS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // the output unit's pre-bias mean: a plain vector, or n_mean_parts partial dot products per row (what
-    // sgmcmc_bnn_dense_tanh_f32 leaves: one per 64-column tile), added here in a fixed order by every workgroup
+    const int cl = lane & (CS_COLS - 1);
+    // The LAST workgroup of the grid owns no columns: it does the head's own reductions and the scalar outputs (one thread's
+    // ~1.5 us of dependent double-precision divisions at the end) next to the column workgroups instead of at the tail of one
+    // of them (tools/head_probe.py at 256 x 2048).
+    const bool head_wg = blockIdx.x == gridDim.x - 1;
+    const size_t c = head_wg ? cols : (size_t)blockIdx.x * CS_COLS + cl;
+    const size_t rl = (size_t)wave * 4 + (lane >> 4);
+    // Everything this lane will want from memory is requested FIRST -- its partial dot products, the activations and targets of
+    // its first four rows, the scalars -- and the double-precision scalar chain (exp, reciprocal: ~1 us of dependent
+    // instructions that used to start after the barrier) runs while those loads fly (tools/head_probe.py).
+    // -- the output unit's pre-bias mean: a plain vector, or n_mean_parts partial dot products per row (what
+    // sgmcmc_bnn_dense_tanh_f32 leaves: one per 64-column tile), added here in a fixed order by every workgroup: four adjacent
+    // lanes per row, each adds a contiguous quarter of the parts (its loads issued together, not one dependent round trip per
+    // part), then the quarters are added in lane order
+    constexpr int PRE = 8;                                       // parts per lane requested ahead (32 parts: all of them)
+    const int per = (n_mean_parts + 3) / 4;
+    const size_t pr = threadIdx.x >> 2;                          // first trip: row and quarter of this lane
+    const int pq = (int)(threadIdx.x & 3), plo = pq * per, phi = (plo + per < n_mean_parts) ? plo + per : n_mean_parts;
+    const bool pre_parts = n_mean_parts > 1 && threadIdx.x < 4 * rows && per <= PRE;
+    T pv[PRE];
+    if (pre_parts) {
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) pv[u] = (plo + u < phi) ? mean_parts[(size_t)(plo + u) * rows + pr] : T(0);
+    }
+    const bool pre_rows = c < cols && rl + 192 < rows;           // the first trip of the main loop
+    T hv0[4], yv0[4];
+    if (pre_rows) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { hv0[u] = h[(rl + 64 * u) * cols + c]; yv0[u] = y[rl + 64 * u]; }
+    }
+    const T wc = (c < cols) ? w[c] : T(0);
+    const double s = (double)*s_ptr;
+    const double bias_add = (k.add_last_bias && last_bias != nullptr) ? (double)*last_bias : 0.0;
+    const double es = exp(s);
+    const double inv = 1.0 / (es + 1e-16);                       // :369
+    const double dscale = -(inv / k.batch_size);
+    // (head workgroup, thread 0) whatever of the scalar outputs does not depend on the residuals: before the barriers, not after
+    double tq = 0.0, lvp = 0.0, dlv = 0.0, prior_coef = 0.0;
+    if (head_wg && threadIdx.x == 0) {
+        for (int j = 0; j < n_tsq; ++j) tq += tsq_parts[j];
+        dlv = s - k.ln_prior_mean;
+        lvp = -(dlv * dlv) / k.lvp_den - 0.5 * k.ln_prior_var;                              // :102-107
+        prior_coef = k.fold_prior_grad ? 0.0 : k.wdecay / (k.wp_den * k.n_examples);
+    }
     const T *__restrict__ mean = mean_parts;
     if (n_mean_parts > 1) {
-        // four adjacent lanes per row, each adds a contiguous quarter of the parts (its loads issued four at a time, not one
-        // dependent round trip per part), then the quarters are added in lane order: a fixed summation order
-        const int per = (n_mean_parts + 3) / 4;
         for (size_t i = threadIdx.x; i < 4 * rows; i += blockDim.x) {   // rows <= 1024: whole waves enter each trip
             const size_t r = i >> 2;
             const int q = (int)(i & 3), lo = q * per, hi = (lo + per < n_mean_parts) ? lo + per : n_mean_parts;
             T m = T(0);
             int p = lo;
-            for (; p + 4 <= hi; p += 4) {
-                const T v0 = mean_parts[(size_t)p * rows + r], v1 = mean_parts[(size_t)(p + 1) * rows + r];
-                const T v2 = mean_parts[(size_t)(p + 2) * rows + r], v3 = mean_parts[(size_t)(p + 3) * rows + r];
-                m = (((m + v0) + v1) + v2) + v3;
+            if (pre_parts && i == threadIdx.x) {
+                // the same left-to-right sum as the loop below
+#pragma unroll
+                for (int u = 0; u < PRE; ++u)
+                    if (lo + u < hi) m += pv[u];
+            } else {
+                for (; p + 4 <= hi; p += 4) {
+                    const T v0 = mean_parts[(size_t)p * rows + r], v1 = mean_parts[(size_t)(p + 1) * rows + r];
+                    const T v2 = mean_parts[(size_t)(p + 2) * rows + r], v3 = mean_parts[(size_t)(p + 3) * rows + r];
+                    m = (((m + v0) + v1) + v2) + v3;
+                }
+                for (; p < hi; ++p) m += mean_parts[(size_t)p * rows + r];
             }
-            for (; p < hi; ++p) m += mean_parts[(size_t)p * rows + r];
             const T m1 = __shfl_down(m, 1, 64), m2 = __shfl_down(m, 2, 64), m3 = __shfl_down(m, 3, 64);
             if (q == 0) mean_lds[r] = ((m + m1) + m2) + m3;
         }
         __syncthreads();
         mean = mean_lds;
     }
-    const double s = (double)*s_ptr;
-    const double es = exp(s);
-    const double inv = 1.0 / (es + 1e-16);                       // :369
-    const double dscale = -(inv / k.batch_size);
-    const double bias_add = (k.add_last_bias && last_bias != nullptr) ? (double)*last_bias : 0.0;
-    auto dvec = [&](size_t r) -> T { return (T)(((double)y[r] - ((double)mean[r] + bias_add)) * dscale); };
-    const int cl = lane & (CS_COLS - 1);
-    const size_t c = (size_t)blockIdx.x * CS_COLS + cl;
-    const size_t rl = (size_t)wave * 4 + (lane >> 4);
+    auto dvec_y = [&](T yr, size_t r) -> T { return (T)(((double)yr - ((double)mean[r] + bias_add)) * dscale); };
+    auto dvec = [&](size_t r) -> T { return dvec_y(y[r], r); };
     T acc_b = T(0), acc_w = T(0);
     if (c < cols) {
-        const T wc = w[c];
         size_t r = rl;
+        if (pre_rows) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T dr = dvec_y(yv0[u], r + 64 * u);
+                const T d = (dr * wc) * (T(1) - hv0[u] * hv0[u]);
+                delta_prev[(r + 64 * u) * cols + c] = d;
+                acc_b += d;
+                acc_w += hv0[u] * dr;
+            }
+            r += 256;
+        }
         for (; r + 192 < rows; r += 256) {
             T hv[4], dr[4];
 #pragma unroll
@@ -582,9 +632,9 @@ __global__ void __launch_bounds__(1024) head_last_layer_backward_kernel(
     acc_b += __shfl_xor(acc_b, 16, 64); acc_b += __shfl_xor(acc_b, 32, 64);
     acc_w += __shfl_xor(acc_w, 16, 64); acc_w += __shfl_xor(acc_w, 32, 64);
     if (lane < CS_COLS) { lds[0][wave][lane] = acc_b; lds[1][wave][lane] = acc_w; }
-    // the head's reductions, workgroup 0 only (same arithmetic as bnn_head_kernel)
+    // the head's reductions (same arithmetic as bnn_head_kernel)
     double sse = 0.0, sumr = 0.0;
-    if (blockIdx.x == 0) {
+    if (head_wg) {
         for (size_t i = threadIdx.x; i < rows; i += blockDim.x) {
             double r = (double)y[i] - ((double)mean[i] + bias_add);
             sse += r * r;                                            // :370
@@ -602,19 +652,15 @@ __global__ void __launch_bounds__(1024) head_last_layer_backward_kernel(
         colsum[c] = (beta != T(0)) ? tb + beta * bias_prev[c] : tb;
         gw[c] = (beta != T(0)) ? tw + beta * w[c] : tw;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double tot = 0.0, rs = 0.0, tq = 0.0;
+    if (head_wg && threadIdx.x == 0) {
+        double tot = 0.0, rs = 0.0;
         for (int wv = 0; wv < 16; ++wv) { tot += lds_h[0][wv]; rs += lds_h[1][wv]; }
-        for (int j = 0; j < n_tsq; ++j) tq += tsq_parts[j];
         const double Bd = (double)rows;
         double log_like = (-(tot * (0.5 * inv)) - 0.5 * s * Bd) / k.batch_size;            // :371-377
-        double d = s - k.ln_prior_mean;
-        double lvp = -(d * d) / k.lvp_den - 0.5 * k.ln_prior_var;                           // :102-107
         double wp = (-0.5 * k.wdecay) * tq / k.wp_den;                                      // :131-141
         double cost = -(log_like + lvp / k.n_examples + wp / k.n_examples);                 // :380-388
-        double prior_coef = k.fold_prior_grad ? 0.0 : k.wdecay / (k.wp_den * k.n_examples);
         double ds = -((tot * (0.5 * es * inv * inv) - 0.5 * Bd) / k.batch_size
-                      + (-2.0 * d / k.lvp_den) / k.n_examples) + prior_coef * s;
+                      + (-2.0 * dlv / k.lvp_den) / k.n_examples) + prior_coef * s;
         *cost_out = (T)cost;
         *grad_s_out = (T)ds;
         *mse_out = (T)(tot / Bd);
@@ -768,7 +814,7 @@ int head_last_layer_backward_impl(const T *mean, size_t n_mean_parts, const T *y
     // slices of sum(theta^2) the forward launch left: min(16, its workgroups) -- one workgroup per row (tanh_rowdot), or per
     // 32 x 64 output tile (bnn_dense_tanh, which callers use only with >= 16 tiles)
     const int n_tsq = (int)((n_mean_parts > 1 || rows >= (size_t)TSQ_SLICES) ? (size_t)TSQ_SLICES : rows);
-    hipLaunchKernelGGL((head_last_layer_backward_kernel<T>), dim3((unsigned)((cols + CS_COLS - 1) / CS_COLS)), dim3(1024), 0, st,
+    hipLaunchKernelGGL((head_last_layer_backward_kernel<T>), dim3((unsigned)((cols + CS_COLS - 1) / CS_COLS) + 1u), dim3(1024), 0, st,
                        mean, (int)n_mean_parts, y, s_ptr, tsq_parts, n_tsq, last_bias, k, cost_out, grad_s_out, grad_bias_out, mse_out, w, h,
                        rows, cols, bias_prev, beta, delta_prev, colsum, gw);
     hipError_t e = hipGetLastError();
