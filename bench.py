@@ -43,6 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import pysgmcmc_amd  # noqa: E402,F401  (first: it sets the HIP-runtime defaults the stepping modes want, before any HIP call)
 import torch  # noqa: E402
 
 from benchlib.common import kernel_source_hash, pmc_traffic, usable_cores  # noqa: E402,F401  (tools/ import these from here)

@@ -9,6 +9,7 @@ import sys
 import time
 
 import numpy as np
+import pysgmcmc_amd
 import torch
 
 from benchlib import legs
@@ -267,7 +268,8 @@ class ChainBench(object):
                        "hip_graph": bool(sampler.use_hip_graph), "gemm_tuning": not args.no_gemm_tuning,
                        "prime_steps": {"burn_in": PRIME_BURN_IN, "frozen": PRIME_FROZEN + PRIME_STEADY},
                        "max_queue_depth": args.max_queue_depth, "time_every": self.time_every,
-                       "launch": kernels.get_launch_config(), "kernel_source_hash": kernel_source_hash()},
+                       "launch": kernels.get_launch_config(), "kernel_source_hash": kernel_source_hash(),
+                       "hip_runtime_env": pysgmcmc_amd.runtime_env()},
             # template args: <Op<float, ADAPT, INJECT>, quads per lane, NT, STATS (2 = sum theta^2 only), LOOP, MOMENTS>, from
             # the launch configuration in effect (library defaults: 1 quad per lane, nt iff the launch streams > 640 MiB,
             # single-pass variant while the grid is uncapped)

@@ -1,5 +1,7 @@
 # Round-4 evidence on the final kernels (ABI v4). Run through gpurun from the repo root: bash tools/gpu/r04_profiles.sh
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+# what `import pysgmcmc_amd` asks the HIP runtime for -- exported here because under rocprofv3 the runtime initialises before python runs
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 O=gpurun_out/r04p; rm -rf $O; mkdir -p $O
 # (b) FIRST the PMC passes (cold launches of every update kernel at both sizes) so that the bench lines below can read the
 # traffic table of THIS build: kernel stats + the two PMC passes
