@@ -43,8 +43,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import pysgmcmc_amd  # noqa: E402,F401  (first: it sets the HIP-runtime defaults the stepping modes want, before any HIP call)
 import torch  # noqa: E402
+
+import pysgmcmc_amd  # noqa: E402
 
 from benchlib.common import kernel_source_hash, pmc_traffic, usable_cores  # noqa: E402,F401  (tools/ import these from here)
 from benchlib.launcher import self_launch  # noqa: E402,F401
@@ -86,6 +87,10 @@ def parse():
 
 def main():
     args = parse()
+    if WORKLOADS[args.workload]["sampler"] in ("sghmc", "sgld", "rsghmc") and not args.eager:
+        # device-bound hipGraph steps (10 M / 49.8 M parameters): the runtime's plain graph launch path, before any HIP call here
+        # or in the ranks spawned below (they inherit the environment); the line reports it (config.hip_runtime_env)
+        pysgmcmc_amd.prefer_plain_graph_launch()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: spawn the ranks from here, BEFORE anything in this process touches the GPU
         sys.exit(self_launch(args))

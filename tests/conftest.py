@@ -21,7 +21,6 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def gpu():
-    import pysgmcmc_amd  # noqa: F401  (before the first HIP call: the package sets its HIP-runtime defaults at import)
     import torch
     if not torch.cuda.is_available():
         pytest.fail("this test is marked gpu but no HIP device is visible")

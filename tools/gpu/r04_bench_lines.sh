@@ -1,6 +1,7 @@
 # the four headline bench lines again (after a change that touches only the post-run legs / labels)
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-# what `import pysgmcmc_amd` asks the HIP runtime for -- exported here because under rocprofv3 the runtime initialises before python runs
+# what bench.py asks the HIP runtime for on this workload (pysgmcmc_amd.prefer_plain_graph_launch) -- exported here because under
+# rocprofv3 the runtime initialises before python runs
 export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 O=gpurun_out/r04p; mkdir -p $O
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd_a.json 2> $O/bench.err

@@ -1,7 +1,5 @@
 # Round-4 evidence on the final kernels (ABI v4). Run through gpurun from the repo root: bash tools/gpu/r04_profiles.sh
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-# what `import pysgmcmc_amd` asks the HIP runtime for -- exported here because under rocprofv3 the runtime initialises before python runs
-export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 O=gpurun_out/r04p; rm -rf $O; mkdir -p $O
 # (b) FIRST the PMC passes (cold launches of every update kernel at both sizes) so that the bench lines below can read the
 # traffic table of THIS build: kernel stats + the two PMC passes
@@ -26,8 +24,11 @@ python3 bench.py --workload sinc-bnn --steps 3000 --warmup 100 > $O/bench_sinc_b
 python3 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --all-ranks-on-gpu0 --no-update-only > $O/bench_selflaunch_n2_gloo.json 2>> $O/bench.err
 python3 bench.py --gpus 8 --steps 20 --warmup 5 --backend gloo --all-ranks-on-gpu0 --no-update-only > $O/bench_selflaunch_n8_gloo.json 2>> $O/bench.err
 # (a) kernel-trace stats of the bench commands (program directly after --)
+# (what bench.py asks the HIP runtime for on the BNN workloads -- exported because under rocprofv3 the runtime initialises before python runs)
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench10m -o b -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/prof_bench10m.json 2> $O/prof_bench10m.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench50m_rsghmc -o b -- python3 bench.py --workload bnn50m-rsghmc --steps 100 --warmup 10 --no-cpu-baseline > $O/prof_bench50m_rsghmc.json 2> $O/prof_bench50m_rsghmc.err
+unset DEBUG_CLR_GRAPH_PACKET_CAPTURE
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sinc -o b -- python3 bench.py --workload sinc-bnn --steps 3000 --warmup 100 --no-cpu-baseline > $O/prof_sinc.json 2> $O/prof_sinc.err
 # keep only the small summaries (the per-dispatch traces are MBs)
 find $O -name "*kernel_trace.csv" -delete

@@ -1,6 +1,7 @@
 # Per-dispatch timeline of the 10 M-parameter chain's step (where the gaps between the 11 launches are). Through gpurun: bash tools/gpu/step_trace.sh
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-# what `import pysgmcmc_amd` asks the HIP runtime for -- exported here because under rocprofv3 the runtime initialises before python runs
+# what bench.py asks the HIP runtime for on this workload (pysgmcmc_amd.prefer_plain_graph_launch) -- exported here because under
+# rocprofv3 the runtime initialises before python runs
 export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 O=gpurun_out/steptrace; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --output-format csv -d $O/t -o t -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-update-only > $O/line.json 2> $O/err.txt
