@@ -112,3 +112,18 @@ def test_cpu_tensor_is_refused():
     with pytest.raises(SgmcmcLibraryError):
         kernels.sghmc_step(t, t.clone(), t.clone(), t.clone(), t.clone(), t.clone(), t.clone(), None,
                            0.01, 1.0, 0.05, True)
+
+
+def test_plain_graph_launch_is_a_call_not_a_default(monkeypatch):
+    """The HIP-runtime setting that helps device-bound chains and hurts host-bound ones is never set by importing the package."""
+    import pysgmcmc_amd
+    monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
+    assert pysgmcmc_amd.runtime_env() == {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": None}
+    import importlib
+    importlib.reload(pysgmcmc_amd)
+    assert pysgmcmc_amd.runtime_env() == {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": None}
+    in_time = pysgmcmc_amd.prefer_plain_graph_launch()
+    assert pysgmcmc_amd.runtime_env() == {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "0"}
+    import torch
+    assert in_time == (not torch.cuda.is_initialized())
+    monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
