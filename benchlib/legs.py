@@ -127,9 +127,8 @@ def hbm_resident_roofline(dev, n=N_HBM_RESIDENT, iters=40):
 def gemm_only_us(sampler, iters=60):
     """The eight fp32 products of one step (three forward, five backward; same operands, shapes and output buffers as the cost
     pipeline) replayed back to back from their own hipGraph: microseconds per step and their FLOP count. Each is what the
-    pipeline runs: the forward layers as the fused product + bias + tanh launch (kernels.bnn_dense_tanh) where BNNCost.fused_dense
-    takes them, the delta W^T products as the fused product + tanh' launch (kernels.bnn_dense_tanh_backward) where
-    fused_dense_backward does, else the library GEMM; the first layer's weight gradient with its extra bias row when the pipeline
+    pipeline runs: the forward layers as the fused product + bias + tanh launch (kernels.bnn_dense_tanh) and the delta W^T products
+    as the fused product + tanh' launch (kernels.bnn_dense_tanh_backward) where BNNCost's plan puts them there, else the library GEMM; the first layer's weight gradient with its extra bias row when the pipeline
     forms it that way. Returns (us, flops, forward layers on the fused launch, backward products on the fused launch)."""
     from pysgmcmc_amd import kernels
     cost, params, gv = sampler.cost_fun, sampler.params, sampler.arena.grad_views
@@ -138,14 +137,12 @@ def gemm_only_us(sampler, iters=60):
     hs, ds = ws["h"], ws["d"]
     L = (len(params) - 1) // 2 - 1                              # index of the single-output layer
     n_fused = [0, 0]
-    ext = getattr(cost, "_x_ext", None)
-    ones_row = (getattr(cost, "bias_gradient_from_product", False) and ext is not None and L >= 2 and X.data_ptr() == ext.data_ptr()
-                and X.stride(0) == ext.stride(0))
+    plan = cost._plan(params, gv, X, ws, True)                  # the plan the sampler's steps walk (statistics partials at hand)
 
     def gemms():
         h, flops, n_fused[0], n_fused[1] = X, 0, 0, 0
         for l in range(L):
-            if getattr(cost, "fused_dense", False) and kernels.bnn_dense_tanh_fits(h, params[2 * l], hs[l]):
+            if plan.forward[l].startswith("dense_tanh"):
                 kernels.bnn_dense_tanh(h, params[2 * l], params[2 * l + 1].view(-1), hs[l])
                 n_fused[0] += 1
             else:
@@ -155,15 +152,15 @@ def gemm_only_us(sampler, iters=60):
         for l in range(L - 1, -1, -1):
             h_in = X if l == 0 else hs[l - 1]
             if l > 0:
-                if getattr(cost, "fused_dense_backward", False) and kernels.bnn_dense_tanh_backward_fits(ds[l], params[2 * l], hs[l - 1], ds[l - 1]):
+                if plan.backward[l] == "dense_tanh_backward":
                     kernels.bnn_dense_tanh_backward(ds[l], params[2 * l], hs[l - 1], ds[l - 1])
                     n_fused[1] += 1
                 else:
                     torch.mm(ds[l], params[2 * l].t(), out=ds[l - 1])
                 flops += 2 * ds[l].shape[0] * ds[l].shape[1] * params[2 * l].shape[0]
-            if l == 0 and ones_row:
+            if l == 0 and plan.ones_row:
                 d_in, width = int(X.shape[1]), int(params[0].shape[1])
-                torch.mm(ext[:, :d_in + 1].t(), ds[0], out=torch.as_strided(gv[0], (d_in + 1, width), (width, 1)))
+                torch.mm(plan.x_ones.t(), ds[0], out=torch.as_strided(gv[0], (d_in + 1, width), (width, 1)))
             else:
                 torch.mm(h_in.t(), ds[l], out=gv[2 * l])
             flops += 2 * h_in.shape[1] * h_in.shape[0] * ds[l].shape[1]

@@ -429,6 +429,8 @@ int sgmcmc_bnn_dense_tanh_f32(const float *h, const float *W, const float *bias,
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh: needs M %% 32 == 0, N %% 64 == 0, K %% 16 == 0, K >= 64, 16-byte aligned rows");
     if ((double)K * ldw * 4.0 >= 2147483648.0 || (double)M * ldh * 4.0 >= 2147483648.0)
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh: an operand spans more than 2 GiB (32-bit buffer offsets)");
+    if (stats_ws != nullptr && (M / BM) * (N / BN) < TSQ_SLICES)
+        return fail(SGMCMC_EINVAL, "bnn_dense_tanh: the sum(theta^2) side job needs at least 16 output tiles (the loss head adds 16 slices)");
     FwdArgs g{h, W, bias, out, w_next, dot_parts, static_cast<const double *>(stats_ws), tsq_parts, M, N, K, ldh, ldw, ldo,
               nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f, 0, 0};
     const int tiles = (M / BM) * (N / BN);

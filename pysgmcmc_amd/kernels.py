@@ -638,8 +638,11 @@ def bnn_head_last_layer_backward(mean, y, log_var, tsq_parts, last_bias, batch_s
     f = getattr(lib(), "sgmcmc_bnn_head_last_layer_backward_" + _sfx(h))
     rows, cols = h.shape
     n_parts = mean.numel() // rows
-    if n_parts * rows != mean.numel() or y.numel() != rows:
-        raise ValueError("pysgmcmc_amd: bnn_head_last_layer_backward: mean must hold n_parts x rows elements")
+    if (n_parts * rows != mean.numel() or y.numel() != rows or not mean.is_contiguous()
+            or not (mean.dim() == 1 or (mean.dim() == 2 and mean.shape[1] == rows))):
+        raise ValueError("pysgmcmc_amd: bnn_head_last_layer_backward: mean must be a contiguous [rows] or [n_parts, rows] tensor, y [rows]")
+    if y.dtype != h.dtype or y.device != h.device or mean.dtype != h.dtype or mean.device != h.device:
+        raise TypeError("pysgmcmc_amd: bnn_head_last_layer_backward: mean and y must have the dtype and device of h")
     with _on(h):
         rc = f(_ptr(mean), n_parts, _ptr(y), _ptr(log_var), _ptr(tsq_parts), _ptr(last_bias), rows, cols, float(batch_size),
                float(n_examples), float(n_params), float(wdecay), float(prior_mean), float(prior_var),

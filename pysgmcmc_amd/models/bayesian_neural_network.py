@@ -150,6 +150,19 @@ def weight_prior_log_like(parameters, wdecay=1.0, dtype=torch.float64):
 
 # ------------------------------------------------------------------ cost path
 
+class _CostPlan(object):
+    """The launch sequence one configuration of the MLP cost path runs (built by ``BNNCost._plan``, walked by every step)."""
+    __slots__ = ("forward", "head", "backward", "ones_row", "x_ones", "single_out")
+
+    def __init__(self, forward, head, backward, ones_row, x_ones, single_out):
+        self.forward, self.head, self.backward = tuple(forward), head, dict(backward)
+        self.ones_row, self.x_ones, self.single_out = ones_row, x_ones, single_out
+
+    def as_dict(self):
+        return {"forward": list(self.forward), "head": self.head, "backward": dict(self.backward),
+                "first_layer_bias_gradient": "from the [x | 1]^T delta product" if self.ones_row else "column sums"}
+
+
 class BNNCost(object):
     """Negative log likelihood of the MLP BNN as a sampler ``cost_fun``.
 
@@ -182,24 +195,15 @@ class BNNCost(object):
         # otherwise). False: the same algebra in device-agnostic torch ops -- an explicit opt-in used
         # to cross-check the kernels, never selected automatically.
         self.use_hip_kernels = True
-        # tanh of the last hidden layer fused with the single output unit's dot product (one launch instead of two)
-        self.fuse_tanh_rowdot = True                      # measured 228.2 vs 231.3 us per step at 10 M parameters
-        # loss head folded into the single-output layer's backward launch (every dependent launch of the step costs ~5 us)
-        self.fuse_head = True
-        # hidden layers whose shapes fit (f32, batch % 32 == 0, width % 64 == 0, at most one 32 x 64 output tile per CU -- the
-        # 10 M-parameter net at batch 256) run as ONE launch each: fp32 matrix-core product with bias + tanh (and, for the last
-        # hidden layer, the output unit's dot product) as its epilogue, kernels.bnn_dense_tanh, instead of library GEMM +
-        # activation launch: 195.1 -> 188.6 us per step with the first two layers on it (tools/fwd_fused_step_probe.py). Other
-        # shapes (the reference's 3 x 50 net, batch 20) keep the library products.
-        self.fused_dense = True
-        # the backward step through a hidden layer the same way: delta W^T with tanh' of the layer below and its bias gradient as
-        # the epilogue (kernels.bnn_dense_tanh_backward) instead of library GEMM + tanh_backward_colsum
-        self.fused_dense_backward = True
-        # the first layer's bias gradient as the extra row of its weight-gradient product, [x | 1]^T delta = [gW_0 ; gb_0] (785 rows
-        # cost the library what 784 do; on the 2048-wide layers the 2049th row costs 4 us: tools/gw_ones_row_probe.py): the
-        # sampler's static feed buffer for x comes from static_feed_buffer() below, pitched, with the ones behind the data
-        self.bias_gradient_from_product = True
-        self._x_ext = None
+        # True: every hidden layer whose shapes fit (f32, batch % 32 == 0, widths % 64 == 0, fan-in % 16 == 0) runs as ONE launch
+        # per direction -- fp32 matrix-core product with bias + tanh (forward; for the last hidden layer also the output unit's dot
+        # product) or tanh' + bias-gradient column sums (backward) as its epilogue, csrc/sgmcmc_bnn_gemm.hip -- and the first
+        # layer's bias gradient comes out of its weight-gradient product as the extra row of [x | 1]^T delta. False: library
+        # products + the small activation / tanh' launches for every layer. Which launches a configuration gets is decided once,
+        # in _plan(); the steps only walk the plan (see plan_summary()).
+        self.fused_layers = True
+        self._x_ext = {}                                          # pitched feed buffers handed out by static_feed_buffer()
+        self._plans = {}
         # (Forking the weight-gradient GEMMs onto a second stream inside the captured graph was measured
         # on MI355X at batch 256: 291 us/step vs 275 us on one stream -- not kept.)
 
@@ -228,27 +232,29 @@ class BNNCost(object):
     @property
     def wants_static_feeds(self):
         """The sampler should feed this cost function through static buffers (see :meth:`static_feed_buffer`) in every stepping
-        mode, so that eager and hipGraph stepping run the same arithmetic."""
-        return bool(self.use_hip_kernels and self.bias_gradient_from_product)
+        mode, so that eager and hipGraph stepping run the same arithmetic. Eager steps then COPY the caller's feeds into those
+        buffers and rebind ``placeholder.value`` to them (the reference's ``feed_dict`` semantics: the fed value is read, not kept)."""
+        return bool(self.use_hip_kernels and self.fused_layers)
 
     def static_feed_buffer(self, placeholder, value):
         """Buffer the sampler's hipGraph modes should keep feeding ``placeholder`` through (``None``: no preference). For x on
         the HIP path: a ``[batch, dim]`` view of a ``[batch, dim + 4]`` buffer whose column ``dim`` holds ones, so that
-        ``[x | 1]^T delta`` is the first layer's weight AND bias gradient in one product."""
-        if (placeholder is not self.x_placeholder or not self.use_hip_kernels or not self.bias_gradient_from_product
+        ``[x | 1]^T delta`` is the first layer's weight AND bias gradient in one product. Every buffer handed out stays known
+        (keyed by its address): a second sampler or another batch shape does not take the product path away from the first."""
+        if (placeholder is not self.x_placeholder or not self.use_hip_kernels or not self.fused_layers
                 or not value.is_cuda or value.dtype != torch.float32 or value.dim() != 2 or value.shape[1] % 4):
             return None
         ext = torch.zeros(value.shape[0], value.shape[1] + 4, dtype=value.dtype, device=value.device)
         ext[:, value.shape[1]] = 1.0
-        self._x_ext = ext
+        self._x_ext[ext.data_ptr()] = ext
         return ext[:, :value.shape[1]]
 
     def _buffers(self, params, B):
-        key = (B, params[0].dtype, params[0].device)
+        n_layers = (len(params) - 1) // 2
+        widths = [params[2 * l].shape[1] for l in range(n_layers)]
+        key = (B, params[0].dtype, params[0].device, tuple(widths))
         ws = self._ws.get(key)
         if ws is None:
-            n_layers = (len(params) - 1) // 2
-            widths = [params[2 * l].shape[1] for l in range(n_layers)]
             dt, dev = params[0].dtype, params[0].device
             mk = lambda w: torch.empty(B, w, dtype=dt, device=dev)
             ws = {"h": [mk(w) for w in widths], "d": [mk(w) for w in widths],
@@ -258,6 +264,7 @@ class BNNCost(object):
                   "tsq_parts": torch.zeros(16, dtype=torch.float64, device=dev),
                   "cost": torch.zeros(1, dtype=dt, device=dev), "mse": torch.zeros(1, dtype=dt, device=dev)}
             self._ws = {key: ws}
+            self._plans = {}
         return ws
 
     @torch.no_grad()
@@ -285,54 +292,107 @@ class BNNCost(object):
                 torch.tanh_(hs[l])
             h = hs[l]
 
+    # ---- the plan: which launch sequence this configuration runs, decided once
+    def _plan(self, params, grad_views, X, ws, have_partials):
+        """Launch sequence for (layer shapes, dtype, batch, feed buffer, prior mode, statistics partials available), cached.
+
+        forward[l]:  "dense_tanh" | "dense_tanh+dot" (last hidden layer: + the output unit's partial dot products and the
+                     sum(theta^2) slices) | "mm+bias_tanh" | "mm+bias_tanh_rowdot" | "by rowdot" (the single output unit: formed
+                     in the launch before) | "addmm" (a multi-output last layer)
+        head:        "head+last_layer_backward" (one launch; needs the statistics partials) | "head"
+        backward[l]: how delta_{l-1} is formed from delta_l, l = L .. 1: "in head launch" | "last_layer_backward" |
+                     "dense_tanh_backward" | "mm+tanh_backward_colsum" | "mm+tanh_backward" (bias gradient from the product)
+        ones_row:    the first layer's [gW_0 ; gb_0] = [x | 1]^T delta as one product."""
+        from pysgmcmc_amd import kernels
+        key = (X.data_ptr(), X.stride(0), tuple(X.shape), bool(have_partials), self.fold_prior, self.fused_layers,
+               params[0].data_ptr(), grad_views[0].data_ptr())
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        B, n_layers = int(X.shape[0]), (len(params) - 1) // 2
+        L = n_layers - 1
+        hs, ds = ws["h"], ws["d"]
+        single_out = params[2 * L].shape[1] == 1 and n_layers >= 2
+        fused_head = single_out and have_partials
+        forward, h = [], X
+        for l in range(n_layers):
+            W = params[2 * l]
+            fits = l < L and self.fused_layers and kernels.bnn_dense_tanh_fits(h, W, hs[l])
+            if l == L:
+                forward.append("by rowdot" if single_out else "addmm")
+            elif l == L - 1 and single_out:
+                # with the output unit's dot product in the launch, the loss head must add the partials: the fused head only
+                top_fits = fits and fused_head and (B // 32) * (int(W.shape[1]) // 64) >= 16 and B <= 1024
+                forward.append("dense_tanh+dot" if top_fits else "mm+bias_tanh_rowdot")
+            else:
+                forward.append("dense_tanh" if fits else "mm+bias_tanh")
+            h = hs[l]
+        ext = self._x_ext.get(X.data_ptr())
+        D_in = int(X.shape[1])
+        adjacent = lambda a, b: (a.is_contiguous() and b.is_contiguous()
+                                 and b.data_ptr() == a.data_ptr() + a.numel() * a.element_size())
+        # [W_0 ; b_0] must be one contiguous matrix in the gradient arena (and in theta's when the prior rides in the product)
+        ones_row = (self.fused_layers and ext is not None and L >= 2 and X.shape[0] == ext.shape[0]
+                    and X.stride(0) == ext.stride(0) and ext.shape[1] > D_in and adjacent(grad_views[0], grad_views[1])
+                    and (self.fold_prior or adjacent(params[0], params[1])))
+        backward = {}
+        for l in range(L, 0, -1):
+            if l == L and fused_head:
+                backward[l] = "in head launch"
+            elif l == L and single_out:
+                backward[l] = "last_layer_backward"
+            elif self.fused_layers and kernels.bnn_dense_tanh_backward_fits(ds[l], params[2 * l], hs[l - 1], ds[l - 1]):
+                backward[l] = "dense_tanh_backward"
+            else:
+                backward[l] = "mm+tanh_backward" if (l == 1 and ones_row) else "mm+tanh_backward_colsum"
+        if "dense_tanh_backward" in backward.values() and "colsum_parts" not in ws:
+            widest = max(int(p.shape[0]) for p in params[0:-1:2])
+            ws["colsum_parts"] = [torch.zeros((B // 32) * widest, dtype=X.dtype, device=X.device) for _ in range(2)]
+        plan = _CostPlan(forward, "head+last_layer_backward" if fused_head else "head", backward, bool(ones_row),
+                         ext[:, :D_in + 1] if ones_row else None, single_out)
+        self._plans[key] = plan
+        return plan
+
+    def plan_summary(self, params, grad_views, theta_sumsq_partials=None):
+        """The launch sequence :meth:`cost_and_grad` runs for the current feeds, as a dict (see :meth:`_plan`)."""
+        X = self.x_placeholder.value
+        return self._plan(params, grad_views, X, self._buffers(params, X.shape[0]), theta_sumsq_partials is not None).as_dict()
+
     def _cost_and_grad_hip(self, params, grad_views, theta_sumsq, theta_sumsq_partials=None):
         from pysgmcmc_amd import kernels
         X, Y = self.x_placeholder.value, self.y_placeholder.value
         B = X.shape[0]
-        n_layers = (len(params) - 1) // 2
+        L = (len(params) - 1) // 2 - 1
         ws = self._buffers(params, B)
         hs, ds = ws["h"], ws["d"]
-        L = n_layers - 1
-        single_out = params[2 * L].shape[1] == 1 and n_layers >= 2
-        # forward; a single-output last layer is a plain GEMV whose bias the loss head adds
-        h = X
-        fuse_top = single_out and self.fuse_tanh_rowdot
-        # loss head folded into the last layer's backward (one launch less): needs the sum(theta^2) records of the
-        # previous step kernel, which the rowdot launch reduces to 16 slices on the side
-        fuse_head = fuse_top and self.fuse_head and theta_sumsq_partials is not None
-        mean = hs[L].view(-1)                                     # the output unit's pre-bias mean, as the loss head reads it
-        for l in range(n_layers):
+        plan = self._plan(params, grad_views, X, ws, theta_sumsq_partials is not None)
+        fused_head = plan.head == "head+last_layer_backward"
+        # ---- forward
+        h, mean = X, hs[L].view(-1)                               # mean: the output unit's pre-bias mean, as the loss head reads it
+        for l, op in enumerate(plan.forward):
             W, b = params[2 * l], params[2 * l + 1]
-            top = l == L - 1 and fuse_top
-            if (l < L and self.fused_dense and kernels.bnn_dense_tanh_fits(h, W, hs[l])
-                    and (not top or (fuse_head and (h.shape[0] // 32) * (W.shape[1] // 64) >= 16 and h.shape[0] <= 1024))):
-                # product + bias + tanh in ONE launch; for the last hidden layer also the output unit's partial dot products
-                # (added up by the loss head) and the 16 slices of the previous step kernel's sum(theta^2) records
-                if top:
-                    kernels.bnn_dense_tanh(h, W, b.view(-1), hs[l], w_next=params[2 * L].view(-1), dot_parts=ws["dot_parts"],
-                                           stats_workspace=theta_sumsq_partials, tsq_parts=ws["tsq_parts"])
-                    mean = ws["dot_parts"]
-                else:
-                    kernels.bnn_dense_tanh(h, W, b.view(-1), hs[l])
-                h = hs[l]
-                continue
-            if l == L and single_out:
-                if not fuse_top:
-                    torch.mv(h, W.view(-1), out=hs[l].view(-1))
-            elif l < L:
-                # hidden layer: plain product, the bias rides in the activation launch (the library's plain GEMM is 1.4-2.1 us
-                # faster than its bias-epilogue one at batch 256: tools/fwd_gemm_probe.py)
+            if op == "dense_tanh":
+                kernels.bnn_dense_tanh(h, W, b.view(-1), hs[l])
+            elif op == "dense_tanh+dot":
+                kernels.bnn_dense_tanh(h, W, b.view(-1), hs[l], w_next=params[2 * L].view(-1), dot_parts=ws["dot_parts"],
+                                       stats_workspace=theta_sumsq_partials, tsq_parts=ws["tsq_parts"])
+                mean = ws["dot_parts"]
+            elif op == "mm+bias_tanh":
+                # plain product, the bias rides in the activation launch (the library's plain GEMM is 1.4-2.1 us faster than its
+                # bias-epilogue one at batch 256: tools/fwd_gemm_probe.py)
                 torch.mm(h, W, out=hs[l])
-            else:
-                torch.addmm(b, h, W, out=hs[l])
-            if top:
-                # bias + tanh of the last hidden layer and the output unit's dot product in one launch
-                kernels.tanh_rowdot(hs[l], params[2 * L].view(-1), hs[L].view(-1),
-                                    stats_workspace=theta_sumsq_partials if fuse_head else None,
-                                    tsq_parts=ws["tsq_parts"] if fuse_head else None, bias=b.view(-1))
-            elif l < L:
                 kernels.bias_tanh(hs[l], b.view(-1))
+            elif op == "mm+bias_tanh_rowdot":
+                # bias + tanh of the last hidden layer and the output unit's dot product in one launch (+ the 16 slices of the
+                # previous step kernel's sum(theta^2) records when the fused head follows)
+                torch.mm(h, W, out=hs[l])
+                kernels.tanh_rowdot(hs[l], params[2 * L].view(-1), hs[L].view(-1),
+                                    stats_workspace=theta_sumsq_partials if fused_head else None,
+                                    tsq_parts=ws["tsq_parts"] if fused_head else None, bias=b.view(-1))
+            elif op == "addmm":
+                torch.addmm(b, h, W, out=hs[l])
             h = hs[l]
+        # ---- loss head
         n_params = float(sum(p.numel() for p in params))
         if theta_sumsq is None and theta_sumsq_partials is None:
             theta_sumsq = torch.zeros((), dtype=torch.float64, device=X.device)
@@ -341,7 +401,7 @@ class BNNCost(object):
         prior_coef = self.wdecay / ((n_params + 3e-16) * self.n_examples)
         self.grad_theta_coef = prior_coef if self.fold_prior else 0.0
         beta = 0.0 if self.fold_prior else prior_coef
-        if fuse_head:
+        if fused_head:
             # loss head + gW_L + delta_{L-1} (incl. tanh') + gb_{L-1} + gb_L + d/d log_var in ONE launch
             kernels.bnn_head_last_layer_backward(
                 mean, Y.reshape(-1), params[-1], ws["tsq_parts"], params[2 * L + 1], self.batch_size,
@@ -350,83 +410,72 @@ class BNNCost(object):
                 grad_views[2 * (L - 1) + 1], grad_views[2 * L].view(-1), fold_prior_grad=self.fold_prior, add_last_bias=True)
         else:
             # loss head: delta_L, cost, d/d log_var, mse and (single-output net) the last bias gradient
+            so = plan.single_out
             kernels.bnn_head(hs[L].view(-1), Y.reshape(-1), params[-1], theta_sumsq, self.batch_size, self.n_examples,
                              n_params, self.wdecay, self.prior_mean, self.prior_var,
                              ds[L].view(-1), ws["cost"], grad_views[-1], ws["mse"], fold_prior_grad=self.fold_prior,
                              stats_workspace=theta_sumsq_partials,
-                             last_bias=params[2 * L + 1] if single_out else None,
-                             grad_last_bias_out=grad_views[2 * L + 1] if single_out else None,
-                             add_last_bias=single_out)
+                             last_bias=params[2 * L + 1] if so else None,
+                             grad_last_bias_out=grad_views[2 * L + 1] if so else None, add_last_bias=so)
         self.last_mse = ws["mse"]
-        # first layer's bias gradient from its weight-gradient product: X is the cost function's own pitched feed buffer with a
-        # column of ones behind the data (static_feed_buffer), and [W_0 ; b_0] is one contiguous matrix in both arenas
-        D_in = int(X.shape[1])
-        ext = self._x_ext
-        ones_row = (self.bias_gradient_from_product and ext is not None and L >= 2 and X.data_ptr() == ext.data_ptr()
-                    and X.shape[0] == ext.shape[0] and X.stride(0) == ext.stride(0) and ext.shape[1] > D_in
-                    and all(t[0].is_contiguous() and t[1].is_contiguous()
-                            and t[1].data_ptr() == t[0].data_ptr() + t[0].numel() * t[0].element_size()
-                            for t in ((grad_views[0], grad_views[1]),) + (() if self.fold_prior else ((params[0], params[1]),))))
-        pending, parts_turn = None, 0                         # column sums a fused backward launch left to be added up
-        if self.fused_dense_backward and "colsum_parts" not in ws and X.is_cuda and X.dtype == torch.float32 and B % 32 == 0:
-            widest = max(int(p.shape[0]) for p in params[0:-1:2])
-            ws["colsum_parts"] = [torch.zeros((B // 32) * widest, dtype=X.dtype, device=X.device) for _ in range(2)]
+        self._backward_hip(plan, params, grad_views, X, ws, prior_coef, beta)
+        return ws["cost"].reshape(())
+
+    def _backward_hip(self, plan, params, grad_views, X, ws, prior_coef, beta):
+        """delta_{l-1} = (delta_l W_l^T) tanh'(h_{l-1}) first (the last reader of W_l), then gW_l = h_{l-1}^T delta_l written
+        directly into the gradient arena; the weight-prior term coef * theta is added by the update kernel (fold_prior) or rides
+        in the GEMM epilogue (beta). Bias gradients: column sums of delta, from whichever launch the plan names."""
+        from pysgmcmc_amd import kernels
+        hs, ds = ws["h"], ws["d"]
+        L, B = len(hs) - 1, int(X.shape[0])
+        pending, parts_turn = None, 0                             # column sums a fused backward launch left to be added up
         for l in range(L, -1, -1):
-            h_in = X if l == 0 else hs[l - 1]
             W, b = params[2 * l], params[2 * l + 1]
-            if l == L and fuse_head:
+            op = plan.backward.get(l)
+            if op == "in head launch":
                 continue
-            if l == L and single_out:
+            if op == "last_layer_backward":
                 # gW_L, delta_{L-1} (incl. tanh') and gb_{L-1} in one launch
-                kernels.bnn_last_layer_backward(ds[l].view(-1), W.view(-1), hs[l - 1], ds[l - 1],
-                                                grad_views[2 * (l - 1) + 1], grad_views[2 * l].view(-1),
-                                                bias_prev=params[2 * (l - 1) + 1], beta=beta)
+                kernels.bnn_last_layer_backward(ds[l].view(-1), W.view(-1), hs[l - 1], ds[l - 1], grad_views[2 * (l - 1) + 1],
+                                                grad_views[2 * l].view(-1), bias_prev=params[2 * (l - 1) + 1], beta=beta)
                 continue
-            # delta_{l-1} = delta_l W_l^T first (the last reader of W_l), then gW_l
-            fused_back = False
-            # the first layer's bias gradient comes out of its weight-gradient product (below): no column sums for it here
-            below_from_product = l == 1 and ones_row
-            if l > 0:
-                fused_back = self.fused_dense_backward and kernels.bnn_dense_tanh_backward_fits(ds[l], W, hs[l - 1], ds[l - 1])
-                if fused_back:
-                    # product and tanh' of the layer below in ONE launch; the bias gradient of the layer below as column sums
-                    # per 32-row tile, added up on the side by the NEXT such launch (or by a small launch after the loop) --
-                    # which is also how this launch finishes the sums of the one before it
-                    parts = None
-                    if not below_from_product:
-                        n_tiles, width = B // 32, int(W.shape[0])
-                        parts = ws["colsum_parts"][parts_turn][:n_tiles * width].view(n_tiles, width)
-                        parts_turn ^= 1
-                    kernels.bnn_dense_tanh_backward(ds[l], W, hs[l - 1], ds[l - 1], colsum_parts=parts, finish=pending)
-                    pending = None if parts is None else (parts, grad_views[2 * (l - 1) + 1], params[2 * (l - 1) + 1].view(-1), beta)
-                else:
-                    torch.mm(ds[l], W.t(), out=ds[l - 1])
-            # gW_l = h_{l-1}^T delta_l written directly into the gradient arena. The weight-prior term
-            # coef * theta is added by the update kernel (fold_prior) or rides in the GEMM epilogue (beta).
-            if l == 0 and ones_row:
+            if op == "dense_tanh_backward":
+                # product and tanh' of the layer below in ONE launch; its bias gradient as column sums per 32-row tile, added up
+                # on the side by the NEXT such launch (or by a small launch after the loop) -- which is also how this launch
+                # finishes the sums of the one before it. (Layer 0's bias gradient comes out of its weight-gradient product.)
+                parts = None
+                if not (l == 1 and plan.ones_row):
+                    n_tiles, width = B // 32, int(W.shape[0])
+                    parts = ws["colsum_parts"][parts_turn][:n_tiles * width].view(n_tiles, width)
+                    parts_turn ^= 1
+                kernels.bnn_dense_tanh_backward(ds[l], W, hs[l - 1], ds[l - 1], colsum_parts=parts, finish=pending)
+                pending = None if parts is None else (parts, grad_views[2 * (l - 1) + 1], params[2 * (l - 1) + 1].view(-1), beta)
+            elif op is not None:
+                torch.mm(ds[l], W.t(), out=ds[l - 1])
+            # weight gradient
+            if l == 0 and plan.ones_row:
                 # [x | 1]^T delta = [gW_0 ; gb_0] onto the arena's [W_0 ; b_0] slice: 785 rows cost the library what 784 do
-                x1 = self._x_ext[:, :D_in + 1]
-                width = int(W.shape[1])
-                gWb = torch.as_strided(grad_views[0], (D_in + 1, width), (width, 1))
+                rows, width = int(X.shape[1]) + 1, int(W.shape[1])
+                gWb = torch.as_strided(grad_views[0], (rows, width), (width, 1))
                 if self.fold_prior:
-                    torch.mm(x1.t(), ds[0], out=gWb)
+                    torch.mm(plan.x_ones.t(), ds[0], out=gWb)
                 else:
-                    torch.addmm(torch.as_strided(W, (D_in + 1, width), (width, 1)), x1.t(), ds[0], beta=prior_coef, alpha=1.0, out=gWb)
+                    torch.addmm(torch.as_strided(W, (rows, width), (width, 1)), plan.x_ones.t(), ds[0], beta=prior_coef, alpha=1.0, out=gWb)
             elif self.fold_prior:
-                torch.mm(h_in.t(), ds[l], out=grad_views[2 * l])
+                torch.mm((X if l == 0 else hs[l - 1]).t(), ds[l], out=grad_views[2 * l])
             else:
-                torch.addmm(W, h_in.t(), ds[l], beta=prior_coef, alpha=1.0, out=grad_views[2 * l])
+                torch.addmm(W, (X if l == 0 else hs[l - 1]).t(), ds[l], beta=prior_coef, alpha=1.0, out=grad_views[2 * l])
             if l == L:
-                # bias gradient of a multi-output last layer (hidden layers get theirs from the fused kernel below)
+                # bias gradient of a multi-output last layer (hidden layers get theirs from the launches above / below)
                 if self.fold_prior:
                     torch.mv(ds[l].t(), ws["ones"], out=grad_views[2 * l + 1])
                 else:
                     torch.addmv(b, ds[l].t(), ws["ones"], beta=prior_coef, alpha=1.0, out=grad_views[2 * l + 1])
-            if l > 0 and not fused_back:
+            if op in ("mm+tanh_backward", "mm+tanh_backward_colsum"):
                 if pending is not None:
                     kernels.colsum_finish(*pending)
                     pending = None
-                if below_from_product:
+                if op == "mm+tanh_backward":
                     kernels.tanh_backward(ds[l - 1], hs[l - 1])
                 else:
                     # delta_{l-1} *= 1 - h_{l-1}^2, and gb_{l-1} = column sums of the result (+ beta * b_{l-1})
@@ -434,7 +483,6 @@ class BNNCost(object):
                                                  bias=params[2 * (l - 1) + 1], beta=beta)
         if pending is not None:
             kernels.colsum_finish(*pending)
-        return ws["cost"].reshape(())
 
     def _cost_and_grad_torch(self, params, grad_views, theta_sumsq):
         self.grad_theta_coef = 0.0                                # the torch path always writes the full gradient

@@ -33,6 +33,7 @@ What differs, by design:
     ``"device"`` (cloned device tensors) or ``"view"`` (zero-copy views of the
     live arena; they change at the next step).
 """
+import logging
 import os
 
 import numpy as np
@@ -85,6 +86,7 @@ class MCMCSampler(object):
     # "sghmc" / "sgld" / "rsghmc": the kernel can read its stepsize-derived scalars from a device block
     # (kernels.step_scalars); None: by value only
     _SCALARS_KIND = None
+    MAX_STEPSIZE_GRAPHS = 4               # use_hip_graph='full' on a by-value stepsize kernel: graphs kept before falling back
     # every parameter starts at a multiple of this many elements in the arena rows (1 = dense)
     _PARAM_ALIGN = 1
 
@@ -510,9 +512,26 @@ class MCMCSampler(object):
             self._ctr_value = self.n_iterations
         key = self._graph_key()
         if self._SCALARS_KIND is None:
-            # a sampler whose kernel takes its stepsize by value only (SVGD): one graph per stepsize
+            # a sampler whose kernel takes its stepsize by value only (SVGD): one graph per stepsize -- for a handful of
+            # stepsizes. A schedule that keeps moving would capture (and keep) a graph per step: after MAX_STEPSIZE_GRAPHS
+            # distinct values the sampler drops to the cost graph + direct update for good.
             self._scalars_dev = None
             key = key + (float(eps),)
+            if key not in self._graphs and sum(1 for k in self._graphs if k[:1] == ("full",)) >= self.MAX_STEPSIZE_GRAPHS:
+                logging.warning("pysgmcmc_amd: use_hip_graph='full' met more than %d stepsizes on a sampler whose kernel takes the "
+                                "stepsize by value; stepping with the cost graph + direct update from here on", self.MAX_STEPSIZE_GRAPHS)
+                for k in [k for k in self._graphs if k[:1] == ("full",)]:
+                    del self._graphs[k]
+                self.use_hip_graph = True
+                entry = self._graphs.get(("cost",))
+                if entry is None:
+                    entry = self._graphs[("cost",)] = self._capture_cost()
+                graph, cost = entry
+                with torch.no_grad():
+                    graph.replay()
+                    self._update(eps, None)
+                self.cost = cost
+                return self._finish_step(cost)
         else:
             scal = self._step_scalars(eps)
             if scal != self._scalars_value:       # the schedule moved: refresh the device block (1-thread launch)

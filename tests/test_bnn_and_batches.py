@@ -78,6 +78,30 @@ def test_fused_layer_launches_are_device_only():
     assert not c.wants_static_feeds
 
 
+def test_cost_plan_is_decided_once_and_has_three_switches():
+    """The launch sequence of the HIP cost path is a stored plan (``BNNCost._plan``), one per configuration; the only switches
+    are ``use_hip_kernels``, ``fold_prior`` and ``fused_layers``. On host tensors no layer fits a device launch: the plan names
+    library products only (and running it raises, see above) -- the mixed states of the old per-launch booleans do not exist."""
+    params = init_mlp_params(64, hidden=(128, 128), seed=1, dtype=torch.float32)
+    xp, yp = Placeholder().feed(torch.zeros(64, 64)), Placeholder().feed(torch.zeros(64, 1))
+    c = BNNCost(xp, yp, batch_size=64, n_examples=100)
+    for gone in ("fuse_tanh_rowdot", "fuse_head", "fused_dense", "fused_dense_backward", "bias_gradient_from_product"):
+        assert not hasattr(c, gone)
+    grads = [torch.zeros_like(p) for p in params]
+    plan = c.plan_summary(params, grads)
+    assert plan == {"forward": ["mm+bias_tanh", "mm+bias_tanh_rowdot", "by rowdot"], "head": "head",
+                    "backward": {2: "last_layer_backward", 1: "mm+tanh_backward_colsum"},
+                    "first_layer_bias_gradient": "column sums"}
+    assert c._plan(params, grads, xp.value, c._buffers(params, 64), False) is c._plan(params, grads, xp.value, c._buffers(params, 64), False)
+    assert c.plan_summary(params, grads, theta_sumsq_partials=torch.zeros(8))["head"] == "head+last_layer_backward"
+    # a multi-output last layer: generic products all the way, the loss head on its own
+    wide = init_mlp_params(64, hidden=(128,), seed=1, dtype=torch.float32)
+    wide[2] = torch.zeros(128, 3)
+    wide[3] = torch.zeros(3)
+    plan = c.plan_summary(wide, [torch.zeros_like(p) for p in wide])
+    assert plan["forward"] == ["mm+bias_tanh", "addmm"] and plan["head"] == "head" and plan["backward"] == {1: "mm+tanh_backward_colsum"}
+
+
 def test_init_seeding_and_shapes():
     """tests/bayesian_neural_network/test_seeding.py: same seed => identical initial weights."""
     a, b, c = init_mlp_params(1, seed=7), init_mlp_params(1, seed=7), init_mlp_params(1, seed=8)

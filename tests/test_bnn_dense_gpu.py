@@ -145,7 +145,7 @@ def _cost(gpu, fused, batch, hidden, n_in=64, seed=3, own_feed_buffer=False):
     for p in params[1:-1:2]:
         p.normal_(0.0, 0.2, generator=g)                         # non-zero biases
     cost = BNNCost(xp, yp, batch_size=batch, n_examples=1000)
-    cost.fused_dense = cost.fused_dense_backward = cost.bias_gradient_from_product = fused
+    cost.fused_layers = fused
     if own_feed_buffer:                                          # as the sampler's hipGraph modes feed x: pitched, ones behind the data
         buf = cost.static_feed_buffer(xp, x)
         assert buf is not None and buf.stride(0) == n_in + 4
@@ -161,7 +161,7 @@ def _cost(gpu, fused, batch, hidden, n_in=64, seed=3, own_feed_buffer=False):
                                                           (32, (64, 64, 64), False), (32, (64, 64, 64), True),
                                                           (20, (48, 40, 24), True)])     # nothing fits the fused launches: library products, bias row still there
 def test_cost_path_with_fused_dense_layers_equals_the_library_path(gpu, batch, hidden, own_feed_buffer, fold_prior):
-    """BNNCost.fused_dense / fused_dense_backward: same cost, mse and gradients as GEMM + activation / tanh' launches to
+    """BNNCost.fused_layers: same cost, mse and gradients as GEMM + activation / tanh' launches to
     matrix-product rounding -- with the output unit's dot product and the sum(theta^2) slices riding in the last hidden layer's
     launch (256 x 128: 16 tiles) and without (fewer tiles: that layer keeps the library product + rowdot launch); with the first
     layer's bias gradient from the [x | 1]^T delta product (the cost function's own pitched feed buffer, gradients in one arena)
@@ -205,7 +205,7 @@ def test_chain_with_fused_dense_layers_tracks_the_library_chain(gpu):
         xp, yp = Placeholder(dtype=torch.float32, device=gpu), Placeholder(dtype=torch.float32, device=gpu)
         params = init_mlp_params(64, hidden=(128, 128, 128), seed=5, dtype=torch.float32, device=gpu)
         cost = BNNCost(xp, yp, batch_size=256, n_examples=2000)
-        cost.fused_dense = cost.fused_dense_backward = cost.bias_gradient_from_product = fused
+        cost.fused_layers = fused
         s = SGHMCSampler(params=params, cost_fun=cost, batch_generator=generate_batches(X, y, xp, yp, batch_size=256, seed=2),
                          stepsize_schedule=ConstantStepsizeSchedule(0.01), burn_in_steps=5, scale_grad=2000.0, session=gpu,
                          dtype=torch.float32, seed=9)
@@ -221,3 +221,72 @@ def test_chain_with_fused_dense_layers_tracks_the_library_chain(gpu):
     assert torch.equal(got[False], got[True]) and torch.equal(got[True], got["full"])
     b, _ = chain(True, True)
     assert torch.equal(got[True], b)
+
+
+@pytest.mark.parametrize("name,batch,n_in,hidden,partials,want", [
+    # every hidden layer on the fused launches, the output unit's dot product in the last one, bias gradient of layer 0 from its product
+    ("all fused", 256, 64, (128, 128, 128), True,
+     {"forward": ["dense_tanh", "dense_tanh", "dense_tanh+dot", "by rowdot"], "head": "head+last_layer_backward",
+      "backward": {3: "in head launch", 2: "dense_tanh_backward", 1: "dense_tanh_backward"},
+      "first_layer_bias_gradient": "from the [x | 1]^T delta product"}),
+    # the reference's own net (3 x 50, batch 20): nothing fits, library products + the small launches
+    ("library only", 20, 1, (50, 50, 50), True,
+     {"forward": ["mm+bias_tanh", "mm+bias_tanh", "mm+bias_tanh_rowdot", "by rowdot"], "head": "head+last_layer_backward",
+      "backward": {3: "in head launch", 2: "mm+tanh_backward_colsum", 1: "mm+tanh_backward_colsum"},
+      "first_layer_bias_gradient": "column sums"}),
+    # mixed by shape: the 80-wide layer stays on the library, its neighbours are fused
+    ("mixed by shape", 256, 64, (128, 80, 128), True,
+     {"forward": ["dense_tanh", "mm+bias_tanh", "dense_tanh+dot", "by rowdot"], "head": "head+last_layer_backward",
+      "backward": {3: "in head launch", 2: "mm+tanh_backward_colsum", 1: "dense_tanh_backward"},
+      "first_layer_bias_gradient": "from the [x | 1]^T delta product"}),
+    # no statistics records from a step kernel (a bare cost_and_grad call): separate loss head, no dot product in the layer launch
+    ("no partials", 256, 64, (128, 128, 128), False,
+     {"forward": ["dense_tanh", "dense_tanh", "mm+bias_tanh_rowdot", "by rowdot"], "head": "head",
+      "backward": {3: "last_layer_backward", 2: "dense_tanh_backward", 1: "dense_tanh_backward"},
+      "first_layer_bias_gradient": "from the [x | 1]^T delta product"}),
+])
+@pytest.mark.parametrize("fold_prior", [True, False])
+def test_every_reachable_plan_against_autograd_and_the_oracle(gpu, name, batch, n_in, hidden, partials, want, fold_prior):
+    """BNNCost decides its launch sequence once per configuration (``_plan``); each reachable kind of plan is checked here
+    against autograd through the torch restatement of the cost and against the oracle's numpy NLL
+    (pysgmcmc/models/bayesian_neural_network.py:365-388), to matrix-product rounding."""
+    from oracle import sgmcmc_oracle as O
+    from pysgmcmc_amd import kernels
+    pad = n_in % 4 == 0
+    cost, params = _cost(gpu, True, batch, hidden, n_in=n_in, own_feed_buffer=pad)
+    cost.fold_prior = fold_prior
+    n = sum(p.numel() for p in params)
+    flat = torch.cat([p.reshape(-1) for p in params])
+    offs = np.cumsum([0] + [p.numel() for p in params])
+    params = [flat[offs[k]:offs[k + 1]].view(p.shape) for k, p in enumerate(params)]
+    gflat = torch.full((n,), float("nan"), device=gpu)
+    grads = [gflat[offs[k]:offs[k + 1]].view(p.shape) for k, p in enumerate(params)]
+    ws = None
+    if partials:
+        st = kernels.StepStats(n, gpu)
+        kernels.sghmc_step(flat.clone(), torch.zeros(n, device=gpu), torch.zeros(n, device=gpu), None, None, None,
+                           torch.ones(n, device=gpu), None, 0.0, 1.0, 0.0, False, xi=torch.zeros(n, device=gpu), stats=st,
+                           opts=dict(theta_sq_only=True))
+        ws = st.workspace
+    got_plan = cost.plan_summary(params, grads, ws)
+    if not pad:
+        want = dict(want, first_layer_bias_gradient="column sums")
+    assert got_plan == want, (name, got_plan)
+    c = float(cost.cost_and_grad(params, grads, theta_sumsq_partials=ws))
+    if fold_prior:                                               # the update kernel adds coef * theta: put it back for the comparison
+        gflat += cost.grad_theta_coef * flat
+    # autograd through the torch restatement
+    leaves = [p.detach().clone().double().requires_grad_(True) for p in params]
+    X, Y = cost.x_placeholder.value.double(), cost.y_placeholder.value.double()
+    nll, _ = cost.negative_log_likelihood(leaves, X, Y)
+    auto = torch.autograd.grad(nll, leaves)
+    nll_v = float(nll.detach())
+    assert abs(c - nll_v) <= 2e-6 * abs(nll_v)
+    for g, a in zip(grads, auto):
+        assert torch.isfinite(g).all() and float((g.double() - a).abs().max()) <= 3e-5 * float(a.abs().max()) + 1e-9, name
+    # the oracle's numpy restatement
+    c_ref, g_ref = O.bnn_cost_and_grad([p.cpu().numpy().astype(np.float64) for p in params], X.cpu().numpy(), Y.cpu().numpy(),
+                                       batch, 1000)
+    assert abs(c - c_ref) <= 2e-6 * abs(c_ref)
+    for g, w in zip(grads, g_ref):
+        assert np.allclose(g.cpu().numpy(), w, rtol=3e-4, atol=3e-5 * float(np.abs(w).max()) + 1e-9), name

@@ -348,9 +348,10 @@ def test_bias_tanh_kernels(gpu, dt):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])
 def test_fused_head_launch_equals_separate_kernels(gpu, dt):
-    """The loss head folded into the last layer's backward launch (``BNNCost.fuse_head``; sum(theta^2) slices from the
-    rowdot launch) against the separate head + backward kernels: every gradient bit-equal, cost / mse to the last bits
-    (sum(theta^2) is added in another order), for batches smaller and larger than the 16 slices and ragged widths."""
+    """The loss head folded into the last layer's backward launch (the plan of ``BNNCost`` whenever the previous step kernel's
+    sum(theta^2) records are at hand; slices from the rowdot launch) against the separate head + backward kernels (the plan
+    without them): every gradient bit-equal, cost / mse to the last bits (sum(theta^2) is added in another order), for batches
+    smaller and larger than the 16 slices and ragged widths."""
     from pysgmcmc_amd import kernels
     from pysgmcmc_amd.data_batches import Placeholder
     from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
@@ -371,10 +372,10 @@ def test_fused_head_launch_equals_separate_kernels(gpu, dt):
             outs = []
             for fuse in (False, True):
                 c = BNNCost(xp, yp, batch_size=20, n_examples=1000, fold_prior=fold)
-                c.fuse_head = fuse
-                c.fused_dense = False        # (its last-layer form needs the fused head: it would change the products between the two)
+                c.fused_layers = False       # (the fused last hidden layer needs the fused head: it would change the products between the two)
                 gv = [torch.full_like(p, float("nan")) for p in params]
-                cost = c.cost_and_grad(params, gv, theta_sumsq_partials=st.workspace)
+                cost = c.cost_and_grad(params, gv, theta_sumsq_partials=st.workspace if fuse else None)
+                assert c.plan_summary(params, gv, st.workspace if fuse else None)["head"] == ("head+last_layer_backward" if fuse else "head")
                 outs.append((float(cost), float(c.last_mse), [g.clone() for g in gv]))
             (c0, m0, g0), (c1, m1, g1) = outs
             rel = 1e-6 if dt == torch.float32 else 1e-14

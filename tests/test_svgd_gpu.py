@@ -269,6 +269,38 @@ def test_svgd_sampler_vmap_and_hip_graph_modes_agree():
     assert np.array_equal(a, b)                        # and reproducible bit for bit
 
 
+def test_full_graph_mode_gives_up_on_a_moving_stepsize():
+    """SVGD's kernel takes its stepsize by value, so ``use_hip_graph = "full"`` keeps one graph per stepsize: a schedule that
+    keeps moving must not capture one per step -- after MAX_STEPSIZE_GRAPHS values the sampler steps with the cost graph +
+    direct update, and the chain is the eager chain."""
+    from pysgmcmc_amd.samplers import SVGDSampler
+    from pysgmcmc_amd.stepsize_schedules import StepsizeSchedule
+
+    class Decay(StepsizeSchedule):
+        def __init__(self):
+            self.t, self.initial_value = 0, 0.1
+
+        def __next__(self):
+            self.t += 1
+            return 0.1 / self.t
+
+        def update(self, *a, **k):
+            pass
+    x0 = np.random.RandomState(5).normal(size=(16, 3))
+    cost = lambda p: 0.5 * (p ** 2).sum()
+
+    def chain(graph):
+        s = SVGDSampler(particles=[torch.tensor(r, device=DEV) for r in x0], cost_fun=cost, stepsize_schedule=Decay(), dtype=torch.float32)
+        s.sample_format, s.use_hip_graph = "device", graph
+        for _ in range(12):
+            sample, _ = next(s)
+        return torch.stack(sample).cpu().numpy(), s
+    ref, _ = chain(False)
+    got, s = chain("full")
+    assert s.use_hip_graph is True and sum(1 for k in s._graphs if k[:1] == ("full",)) == 0
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("n", [12, 32, 64, 100])
 def test_svgd_tight_cloud_far_from_origin(n):
     """Particles 0.01 apart around 100: the matrix-core path forms distances from a Gram matrix, which only works
