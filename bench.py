@@ -79,6 +79,10 @@ def parse():
                          "device time per step); 0 = steps // 5 clamped to [1, 7]")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="N > 1 started without a launcher: wall-clock limit of the ranks this process spawns (s)")
+    ap.add_argument("--product-defaults", action="store_true",
+                    help="step the same chain with NOTHING set (no pysgmcmc_amd.configure_for_device_bound_chains()): the rate a "
+                         "user of the public API gets by default; the main line runs this as a child process (value_product_defaults)")
+    ap.add_argument("--no-product-defaults", action="store_true", help="skip the value_product_defaults child run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-update-only", action="store_true", help="skip the kernel-only loops (for rocprof runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline leg")
@@ -87,10 +91,20 @@ def parse():
 
 def main():
     args = parse()
-    if WORKLOADS[args.workload]["sampler"] in ("sghmc", "sgld", "rsghmc") and not args.eager:
-        # device-bound hipGraph steps (10 M / 49.8 M parameters): the runtime's plain graph launch path, before any HIP call here
-        # or in the ranks spawned below (they inherit the environment); the line reports it (config.hip_runtime_env)
-        pysgmcmc_amd.prefer_plain_graph_launch()
+    args.device_bound_switch = None
+    if WORKLOADS[args.workload]["sampler"] in ("sghmc", "sgld", "rsghmc") and not args.eager and not args.product_defaults:
+        # device-bound hipGraph steps (10 M / 49.8 M parameters): the package's one documented switch -- TunableOp GEMM selection in
+        # the warm-up step + the runtime's plain graph launch path -- before any HIP call here or in the ranks spawned below (they
+        # inherit the environment). What took effect goes into the line (config.device_bound_switch): under rocprofv3 the runtime
+        # is initialised before Python runs and the second half is NOT in effect whatever the environment says.
+        args.device_bound_switch = pysgmcmc_amd.configure_for_device_bound_chains(
+            gemm_tuning=not args.no_gemm_tuning, tuning_ms=int(os.environ.get("BENCH_TUNE_MS", "30")),
+            tuning_iters=int(os.environ.get("BENCH_TUNE_ITERS", "20")))
+        args.no_gemm_tuning = not args.device_bound_switch["gemm_tuning"]
+        if not args.device_bound_switch["plain_graph_launch"]:
+            print("bench: the HIP runtime was initialised before bench.py ran: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is NOT in effect", file=sys.stderr)
+    elif args.product_defaults:
+        args.no_gemm_tuning = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: spawn the ranks from here, BEFORE anything in this process touches the GPU
         sys.exit(self_launch(args))
@@ -127,6 +141,9 @@ def main():
     run.warmup()                                               # phase 2: --warmup untimed steps
     run.timed()                                                # phase 3: exactly --steps steps between fences
     line = run.headline()                                      # rank 0: the JSON line from the timed region
+    if args.product_defaults:                                  # the child leg of value_product_defaults: the rate only
+        print(json.dumps({"value": line["value"], "ms_per_step": line["ms_per_step"], "config": line["config"]}))
+        return
     run.leave_group(line)                                      # N > 1: the collective alone, then the job ends for every rank
     if rank != 0:
         return

@@ -24,14 +24,8 @@ class ChainBench(object):
         from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange
         from pysgmcmc_amd.profiling import UpdateKernelTimer
         self.args, self.dev, self.rank, self.world, self.dist = args, dev, rank, world, dist
-        if not args.no_gemm_tuning:
-            from pysgmcmc_amd.models.bayesian_neural_network import enable_gemm_tuning
-            try:                                               # rocBLAS/hipBLASLt solution per shape, tuned in the prime phase
-                enable_gemm_tuning(True, max_duration_ms=int(os.environ.get("BENCH_TUNE_MS", "30")),
-                                   max_iterations=int(os.environ.get("BENCH_TUNE_ITERS", "20")))
-            except Exception as exc:                           # tuning is an optimisation, never a requirement
-                print("bench: GEMM tuning unavailable (%s); using the BLAS heuristics" % exc, file=sys.stderr)
-                args.no_gemm_tuning = True
+        # (GEMM selection and the graph launch path: pysgmcmc_amd.configure_for_device_bound_chains(), called by bench.py's main()
+        # before anything touched the GPU; args.device_bound_switch holds what took effect)
         # burn-in (preconditioner adaptation) happens in the PRIME phase, so every warm-up and every timed step is
         # in the frozen phase whatever --warmup is
         self.sampler = sampler = build_chain(dev, rank, args.workload, burn_in=PRIME_BURN_IN)
@@ -269,7 +263,9 @@ class ChainBench(object):
                        "prime_steps": {"burn_in": PRIME_BURN_IN, "frozen": PRIME_FROZEN + PRIME_STEADY},
                        "max_queue_depth": args.max_queue_depth, "time_every": self.time_every,
                        "launch": kernels.get_launch_config(), "kernel_source_hash": kernel_source_hash(),
-                       "hip_runtime_env": pysgmcmc_amd.runtime_env()},
+                       "device_bound_switch": getattr(args, "device_bound_switch", None),
+                       "hip_runtime_env": pysgmcmc_amd.runtime_env(),
+                       "hip_runtime_env_effective": bool((getattr(args, "device_bound_switch", None) or {}).get("plain_graph_launch", False))},
             # template args: <Op<float, ADAPT, INJECT>, quads per lane, NT, STATS (2 = sum theta^2 only), LOOP, MOMENTS>, from
             # the launch configuration in effect (library defaults: 1 quad per lane, nt iff the launch streams > 640 MiB,
             # single-pass variant while the grid is uncapped)
@@ -395,7 +391,7 @@ class ChainBench(object):
             c_us = legs.cost_pipeline_us(sampler)
             meas_us = float(np.median(self.step_ms)) * 1e3 if self.step_ms is not None else None
             line["step_breakdown_us"] = {
-                "gemm": round(g_us, 1), "small_launches": round(c_us - g_us, 1), "update": round(float(u_us.mean()), 1),
+                "gemm": round(g_us, 1), "cost_pipeline": round(c_us, 1), "update": round(float(u_us.mean()), 1),
                 "serial_sum": round(c_us + float(u_us.mean()), 1), "serial_step_measured": round(serial_step_us, 1),
                 "timed_region_step_median": None if meas_us is None else round(meas_us, 1),
                 "gemm_tflops": round(g_flops / (g_us * 1e-6) / 1e12, 1),
@@ -406,9 +402,10 @@ class ChainBench(object):
                         "the three forward layers (%d of them as ONE launch each with bias + tanh as the product's epilogue, "
                         "sgmcmc_bnn_dense_tanh_f32), the two delta W^T products (%d of them with tanh' of the layer below as the "
                         "epilogue, sgmcmc_bnn_dense_tanh_backward_f32) and three library weight-gradient GEMMs (the first layer's "
-                        "with its bias gradient as a 785th row) -- activations and tanh' are then inside `gemm`; small_launches = the "
-                        "captured cost pipeline alone minus gemm (window gather aside: the loss head, the per-row-tile column sums in "
-                        "the backward launches' epilogues, and the activation / tanh' launches of layers on library products); "
+                        "with its bias gradient as a 785th row) -- activations and tanh' are then inside `gemm`; cost_pipeline = the "
+                        "captured cost pipeline alone (gemm + the loss head + the launches of layers on library products; two graph "
+                        "replays differ by less than their noise, so their difference is not reported: the per-dispatch durations "
+                        "of the step are in profiles/r04_step_timeline.txt); "
                         % (n_fused, n_fused_back) +
                         "update = the fused update launched once after the backward pass. Differences of graph replays: rocprofv3's "
                         "per-kernel durations of the same step (profiles/r04_bench10m_kernel_stats.csv) carry ~1.5 us of profiler "
@@ -422,4 +419,6 @@ class ChainBench(object):
             line["roofline_hbm_resident"] = legs.hbm_resident_roofline(self.dev)
         if self.world == 1 and not args.no_cpu_baseline and self.kind == "sghmc":
             line["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
+        if self.world == 1 and self.K == 1 and sampler.use_hip_graph and not getattr(args, "no_product_defaults", False):
+            line["value_product_defaults"] = legs.product_defaults_leg(args)
         return line

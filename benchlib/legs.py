@@ -86,9 +86,35 @@ def hbm_resident_roofline(dev, n=N_HBM_RESIDENT, iters=40):
         "sgld_adapt": lambda i, L: kernels.sgld_step(theta, grad, tau, gg, vh, minv, None, 1e-3, 1.0, float(N_DATA),
                                                      True, seed=1, step=i, launch=L),
         "rsghmc": lambda i, L: kernels.rsghmc_step(theta, V, grad, 1e-3, 1.0, 1.0, 1.0, 0.0, seed=1, step=i, launch=L),
+        # burn-in steps that do not write minv (samplers' store_minv_every_step = False: only the LAST burn-in step stores it)
+        "sghmc_adapt_no_minv_store": lambda i, L: kernels.sghmc_step(theta, V, grad, tau, gg, vh, minv, None, 0.01, float(N_DATA), 0.05, True,
+                                                                    seed=1, step=i, launch=L, opts=dict(skip_minv_store=True)),
+        "sgld_adapt_no_minv_store": lambda i, L: kernels.sgld_step(theta, grad, tau, gg, vh, minv, None, 1e-3, 1.0, float(N_DATA), True,
+                                                                  seed=1, step=i, launch=L, opts=dict(skip_minv_store=True)),
     }
+    # the reference's default dtype is float64 (pysgmcmc/samplers/base_classes.py:25): the frozen-phase kernels on doubles, same
+    # parameter count (twice the bytes), own arrays
+    d64 = {}
+
+    def f64_arrays():
+        if not d64:
+            g64 = torch.Generator(device=dev).manual_seed(1)
+            d64["theta"] = torch.randn(n, device=dev, generator=g64, dtype=torch.float64) * 0.02
+            d64["V"] = torch.zeros(n, device=dev, dtype=torch.float64)
+            d64["grad"] = torch.randn(n, device=dev, generator=g64, dtype=torch.float64) * 0.1
+            d64["minv"] = torch.rand(n, device=dev, generator=g64, dtype=torch.float64) * 1.5 + 0.5
+        return d64["theta"], d64["V"], d64["grad"], d64["minv"]
+    calls64 = {
+        "sghmc_frozen_f64": lambda i, L: (lambda t, v, gr, mi: kernels.sghmc_step(t, v, gr, None, None, None, mi, None, 0.01, float(N_DATA), 0.05,
+                                                                              False, seed=1, step=i, launch=L))(*f64_arrays()),
+        "sgld_frozen_f64": lambda i, L: (lambda t, v, gr, mi: kernels.sgld_step(t, gr, None, None, None, mi, None, 1e-3, 1.0, float(N_DATA), False,
+                                                                            seed=1, step=i, launch=L))(*f64_arrays()),
+        "rsghmc_f64": lambda i, L: (lambda t, v, gr, mi: kernels.rsghmc_step(t, v, gr, 1e-3, 1.0, 1.0, 1.0, 0.0, seed=1, step=i, launch=L))(*f64_arrays()),
+    }
+    bytes_per_param = dict(BYTES_PER_PARAM, sghmc_adapt_no_minv_store=44, sgld_adapt_no_minv_store=36,
+                           sghmc_frozen_f64=48, sgld_frozen_f64=32, rsghmc_f64=40)
     out = {}
-    for name, call in calls.items():
+    for name, call in list(calls.items()) + list(calls64.items()):
         for i in range(5):
             call(i, None)
         torch.cuda.synchronize()
@@ -102,8 +128,8 @@ def hbm_resident_roofline(dev, n=N_HBM_RESIDENT, iters=40):
         torch.cuda.synchronize()
         us = np.array([k.elapsed_us() for k in kevs])                   # the kernels' own timestamps
         bracket = np.array([a.elapsed_time(b) for a, b in pairs]) * 1e3
-        alg = BYTES_PER_PARAM[name] * n
-        traffic, src = pmc_traffic(name, n)
+        alg = bytes_per_param[name] * n
+        traffic, src = pmc_traffic(name, n) if name in BYTES_PER_PARAM else (None, None)
         out[name] = {"us_per_launch_mean": round(float(us.mean()), 2), "us_per_launch_median": round(float(np.median(us)), 2),
                      "us_bracket_mean": round(float(bracket.mean()), 2),
                      "algorithmic_bytes_per_launch": alg, "achieved": round(alg / (us.mean() * 1e-6) / 1e9, 1),
@@ -111,7 +137,11 @@ def hbm_resident_roofline(dev, n=N_HBM_RESIDENT, iters=40):
                      "launches_timed": iters}
         theta.normal_(0.0, 0.02, generator=g)              # keep the chain finite across 225 synthetic steps
         V.zero_()
-    assert torch.isfinite(theta).all()
+        if d64:
+            d64["theta"].normal_(0.0, 0.02)
+            d64["V"].zero_()
+    assert torch.isfinite(theta).all() and torch.isfinite(d64["theta"]).all()
+    d64.clear()
     head = out["sghmc_frozen"]
     return {"bound": "hbm", "kernel": "stream_quads_vec<SghmcOp<float,false,false>,1,true,0,false,false> (128-lane blocks, nt)",
             "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
@@ -228,3 +258,28 @@ def launch_table(timer, n, bytes_per_param, moments_every):
     return rows
 
 
+
+
+def product_defaults_leg(args, timeout=600):
+    """`value` again for the SAME chain with nothing set: a child process (the graph launch path is fixed when the HIP runtime
+    initialises, so it cannot be switched back in this one) runs ``bench.py --product-defaults`` -- no
+    ``pysgmcmc_amd.configure_for_device_bound_chains()``: library GEMM heuristics, the runtime's default graph launch -- with the
+    same workload, steps and warm-up, while this process sits idle. What a user of the public API gets by default."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--workload", args.workload, "--moments-every", str(args.moments_every), "--product-defaults"]
+    torch.cuda.synchronize()
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, check=True).stdout.decode()
+        child = json.loads(out.strip().splitlines()[-1])
+    except Exception as exc:                                   # the main line must not die of its extra figure
+        return {"value": None, "error": repr(exc)[:300]}
+    return {"value": child["value"], "unit": "samples/s", "ms_per_step": child["ms_per_step"],
+            "gemm_tuning": child["config"]["gemm_tuning"], "hip_runtime_env": child["config"]["hip_runtime_env"],
+            "note": "the same workload, steps and warm-up in a child process WITHOUT pysgmcmc_amd.configure_for_device_bound_chains(): "
+                    "what the public API gives with nothing set; `value` is with that one documented call made first"}

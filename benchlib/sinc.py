@@ -150,6 +150,34 @@ def run_sinc(args, dev, rank, world, dist):
         c = build_sinc_chain(dev, 0, mode)
         c.fused_bnn_steps(CHUNK * 12)                          # through burn-in; the timed steps are frozen ones
         modes[label] = round(_rate(lambda k, c=c: [next(c) for _ in range(k)], 2000 if mode else 600, sync), 1)
+    # the ensemble form of the same kernel: one workgroup per chain, one chain per CU (pysgmcmc_amd.samplers.FusedBNNChains; the
+    # reference runs chains one after the other, diagnostics/sample_chains.py:369-382) -- chains x steps per second of ONE GPU
+    from pysgmcmc_amd.samplers.fused_chains import FusedBNNChains
+    X, y = sinc_data(1)
+    many = {}
+    for n_chains in (256,):
+        group = FusedBNNChains.for_dataset(X, y, n_chains, batch_size=BATCH_SINC, seed=11, dtype=torch.float32, device=dev,
+                                           stepsize=0.01, burn_in_steps=BURN_IN, mdecay=0.05)
+        for _ in range(12):
+            group.steps(CHUNK)                                 # through burn-in
+        e = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        sync()
+        t0 = time.perf_counter()
+        for e0, e1 in e:
+            e0.record()
+            group.steps(CHUNK)
+            e1.record()
+        sync()
+        wall = time.perf_counter() - t0
+        k_us = np.array([a.elapsed_time(b) for a, b in e]) * 1e3
+        assert torch.isfinite(group.theta()).all()
+        many["chains_%d" % n_chains] = {
+            "chains": n_chains, "steps_per_launch": CHUNK, "samples_per_s": round(n_chains * CHUNK * len(e) / wall, 1),
+            "us_per_launch_mean": round(float(k_us.mean()), 1), "us_per_step_of_all_chains": round(float(k_us.mean()) / CHUNK, 2),
+            "samples_per_s_device_time": round(n_chains * CHUNK / (float(k_us.mean()) * 1e-6), 1),
+            "note": "one launch advances %d independent chains by %d steps (one 1024-lane workgroup per chain, one chain per CU); "
+                    "samples_per_s is wall clock including the host side (window draws of every chain), not part of `value`" % (n_chains, CHUNK)}
+        del group
     alg_bytes = 6 * 4 * n + BATCH_SINC * 2 * 4                 # R{theta, V, grad, minv} W{theta, V} + the window rows, if it went to HBM
     line = {
         "metric": "MCMC samples/sec, sinc BNN 3x50 (BASELINE configs[1])",
@@ -163,6 +191,7 @@ def run_sinc(args, dev, rank, world, dist):
                                "%d steps per launch; 1 chain per GPU" % (n, CHUNK),
                    "params": n, "batch": BATCH_SINC, "chains": world, "steps_per_launch": CHUNK},
         "modes_samples_per_s": modes,
+        "many_chains_per_gpu": many,
         "roofline": {"bound": "hbm", "kernel": "bnn_fused_sghmc_kernel<float, 0> (ONE 1024-lane workgroup per chain)",
                      "achieved": round(alg_bytes / (us_per_step * 1e-6) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg_bytes / (us_per_step * 1e-6) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,

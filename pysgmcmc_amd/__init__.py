@@ -28,6 +28,32 @@ def prefer_plain_graph_launch():
     return not torch.cuda.is_initialized()
 
 
+def configure_for_device_bound_chains(gemm_tuning=True, plain_graph_launch=True, tuning_ms=30, tuning_iters=20):
+    """ONE switch for chains whose step is DEVICE-bound -- hipGraph stepping (the default of the samplers' ``use_hip_graph`` and of
+    ``BayesianNeuralNetwork.train``) on models of millions of parameters. It applies what ``bench.py`` runs its BNN workloads
+    with, so a chain built through the public API after this call steps at the rate the benchmark line reports as ``value``
+    (without it: ``value_product_defaults`` in the same line, ~4 % less at 10 M parameters):
+
+    * ``gemm_tuning``: PyTorch's TunableOp picks the library GEMM solution per shape during the chain's first (warm-up) step
+      (``models.bayesian_neural_network.enable_gemm_tuning``; process-wide PyTorch setting, same fp32 arithmetic);
+    * ``plain_graph_launch``: :func:`prefer_plain_graph_launch` -- only effective BEFORE the first HIP call of the process.
+
+    Host-bound chains (the 3 x 50 BNN of the reference's tests) lose with the second one: do not call this for them.
+    Returns what took effect: ``{"gemm_tuning": bool, "plain_graph_launch": bool}``."""
+    took = {"gemm_tuning": False, "plain_graph_launch": False}
+    if plain_graph_launch:
+        took["plain_graph_launch"] = bool(prefer_plain_graph_launch())
+    if gemm_tuning:
+        from pysgmcmc_amd.models.bayesian_neural_network import enable_gemm_tuning
+        try:
+            enable_gemm_tuning(True, max_duration_ms=int(tuning_ms), max_iterations=int(tuning_iters))
+            took["gemm_tuning"] = True
+        except Exception as exc:                              # tuning is an optimisation, never a requirement
+            import logging
+            logging.warning("pysgmcmc_amd: GEMM tuning unavailable (%s); the BLAS heuristics stay", exc)
+    return took
+
+
 def runtime_env():
     """The HIP-runtime settings this package asked for, as the process has them now (see above)."""
     return {k: _os.environ.get(k) for k in ("DEBUG_CLR_GRAPH_PACKET_CAPTURE",)}

@@ -32,6 +32,8 @@ def test_sinc_bnn_workload_is_configs_1(gpu):
     assert set(m) == {"fused_steps_100_per_launch", "fused_steps_1_per_launch", "full_graph", "hip_graph", "eager"}
     assert m["fused_steps_100_per_launch"] > m["hip_graph"] > m["eager"] > 100
     assert d["value"] > 5000 and abs(d["value"] - 1e3 / d["ms_per_step"]) <= 0.02 * d["value"]
+    mc = d["many_chains_per_gpu"]["chains_256"]                  # K8 with one workgroup per CU: chains x steps per second
+    assert mc["chains"] == 256 and mc["samples_per_s"] > 50 * d["value"] and mc["samples_per_s_device_time"] >= mc["samples_per_s"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["frac"] < 0.01 and "latency-bound, one workgroup" in r["note"] and r["launches_timed"] == 4
     c = d["cpu_baseline"]
@@ -51,3 +53,49 @@ def test_default_workload_line_at_n1(gpu):
     assert r["algorithmic_bytes_per_launch"] == 24 * 10002434 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
     assert "rccl" not in d and "value_ex_exchange" not in d
     assert "step_breakdown_us" in d and d["step_breakdown_us"]["gemm"] > 0
+    assert "small_launches" not in d["step_breakdown_us"] and d["step_breakdown_us"]["cost_pipeline"] >= d["step_breakdown_us"]["gemm"] * 0.9
+    # `value` is measured with the package's ONE documented switch; the line says what took effect and carries the rate with nothing set
+    sw = d["config"]["device_bound_switch"]
+    assert sw == {"gemm_tuning": True, "plain_graph_launch": True} and d["config"]["hip_runtime_env_effective"] is True
+    pd = d["value_product_defaults"]
+    assert pd["gemm_tuning"] is False and pd["hip_runtime_env"] == {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": None}
+    assert 0.8 * d["value"] < pd["value"] < 1.05 * d["value"], (pd["value"], d["value"])
+
+
+@pytest.mark.timeout(900)
+def test_public_api_chain_after_the_device_bound_switch_steps_at_the_bench_rate(gpu):
+    """a chain built through the public API (samplers + BNNCost + generate_batches, as
+    pysgmcmc/models/bayesian_neural_network.py:464-466,510-512 builds its sampler) after ONE call of
+    ``pysgmcmc_amd.configure_for_device_bound_chains()`` steps within 3 % of what bench.py reports as `value` (both in fresh
+    processes, 300 steps each, best of two)."""
+    code = """
+import time, numpy as np, torch, pysgmcmc_amd
+took = pysgmcmc_amd.configure_for_device_bound_chains()
+assert took == {"gemm_tuning": True, "plain_graph_launch": True}, took
+from pysgmcmc_amd.data_batches import Placeholder, generate_batches
+from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
+from pysgmcmc_amd.samplers import SGHMCSampler
+from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+dev = torch.device("cuda:0")
+rng = np.random.RandomState(0)
+X, y = rng.randn(100000, 784).astype(np.float32), rng.randn(100000).astype(np.float32)
+xp, yp = Placeholder(dtype=torch.float32, device=dev), Placeholder(dtype=torch.float32, device=dev)
+params = init_mlp_params(784, hidden=(2048, 2048, 2048), seed=0, dtype=torch.float32, device=dev)
+s = SGHMCSampler(params=params, cost_fun=BNNCost(xp, yp, batch_size=256, n_examples=100000),
+                 batch_generator=generate_batches(X, y, xp, yp, batch_size=256, seed=0), stepsize_schedule=ConstantStepsizeSchedule(1e-3),
+                 burn_in_steps=8, mdecay=0.05, scale_grad=1e5, session=dev, dtype=torch.float32, seed=1)
+s.sample_format = "view"                      # the reference copies every sample to the host; the roofline path does not
+for _ in range(60): next(s)
+best = 0.0
+for rep in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(300): next(s)
+    torch.cuda.synchronize(); best = max(best, 300 / (time.perf_counter() - t0))
+print("RATE", best)
+"""
+    res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    rate = float([l for l in res.stdout.splitlines() if l.startswith("RATE")][-1].split()[1])
+    best = max(_bench(["--gpus", "1", "--steps", "300", "--warmup", "20", "--no-update-only", "--no-cpu-baseline",
+                       "--no-product-defaults"])["value"] for _ in range(2))
+    assert rate >= 0.97 * best, (rate, best)

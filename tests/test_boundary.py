@@ -127,3 +127,25 @@ def test_plain_graph_launch_is_a_call_not_a_default(monkeypatch):
     import torch
     assert in_time == (not torch.cuda.is_initialized())
     monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
+
+
+def test_device_bound_switch_reports_what_took_effect(monkeypatch):
+    """``configure_for_device_bound_chains()`` is the one documented call behind bench.py's `value`: it returns what took effect
+    (the graph launch path only before the first HIP call; GEMM tuning only where TunableOp exists -- not on a box without a
+    device, where it must not raise either)."""
+    import pysgmcmc_amd
+    import torch
+    monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
+    try:
+        took = pysgmcmc_amd.configure_for_device_bound_chains()
+        assert took["plain_graph_launch"] == (not torch.cuda.is_initialized()) and set(took) == {"gemm_tuning", "plain_graph_launch"}
+        assert took["gemm_tuning"] or not torch.cuda.is_available()
+        assert pysgmcmc_amd.runtime_env() == {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "0"}
+        monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
+        assert pysgmcmc_amd.configure_for_device_bound_chains(gemm_tuning=False, plain_graph_launch=False) == {
+            "gemm_tuning": False, "plain_graph_launch": False}
+        assert pysgmcmc_amd.runtime_env() == {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": None}
+    finally:
+        if torch.cuda.is_available():
+            from pysgmcmc_amd.models.bayesian_neural_network import enable_gemm_tuning
+            enable_gemm_tuning(False)
