@@ -766,6 +766,24 @@ class BayesianNeuralNetwork(object):
         with torch.no_grad():
             return mlp_forward(ps, x).cpu().numpy()
 
+    def _network_outputs(self, x):
+        """Outputs ``(n_nets, N, 2)`` of EVERY kept network at ``x`` in one pass: the kept weights are stacked per layer and the
+        layers run as batched products on the device, with ONE copy to the host at the end -- the reference (and
+        :meth:`compute_network_output`) evaluates the networks one by one (``:599-607``), 100 small launches and 100 copies."""
+        nets = list(self.samples)
+        dev = nets[0][0].device
+        h = torch.as_tensor(x, dtype=self._torch_dtype, device=dev).unsqueeze(0).expand(len(nets), -1, -1)
+        n_layers = (len(nets[0]) - 1) // 2
+        with torch.no_grad():
+            for l in range(n_layers):
+                W = torch.stack([net[2 * l] for net in nets])                # (nets, fan_in, fan_out)
+                b = torch.stack([net[2 * l + 1] for net in nets]).unsqueeze(1)
+                h = torch.baddbmm(b, h, W)
+                if l < n_layers - 1:
+                    h = torch.tanh_(h)
+            log_var = torch.stack([net[-1].reshape(()) for net in nets]).reshape(-1, 1, 1).expand(-1, h.shape[1], 1)
+            return torch.cat([h, log_var], dim=2).cpu().numpy()
+
     def predict(self, X_test, return_individual_predictions=False, *args, **kwargs):
         """Predictive mean and variance at ``X_test (N, D)`` (``:560-630``): the kept networks' means and noise
         variances ``(n_nets, N)`` if ``return_individual_predictions``, else the ensemble mean and the variance of the
@@ -778,7 +796,7 @@ class BayesianNeuralNetwork(object):
                 "Please call `bnn.train()` before calling `bnn.predict()`"
             )
         x = zero_mean_unit_var_normalization(X_test, self.x_mean, self.x_std)[0] if self.normalize_input else X_test
-        outputs = np.stack([self.compute_network_output(params=net, input_data=x) for net in self.samples])    # (nets, N, 2)
+        outputs = self._network_outputs(x)                                   # (nets, N, 2)
         means, noise_var = outputs[:, :, 0], np.exp(outputs[:, :, 1])
         if return_individual_predictions:
             if self.normalize_output:

@@ -102,6 +102,26 @@ def test_cost_plan_is_decided_once_and_has_three_switches():
     assert plan["forward"] == ["mm+bias_tanh", "addmm"] and plan["head"] == "head" and plan["backward"] == {1: "mm+tanh_backward_colsum"}
 
 
+def test_predict_evaluates_every_kept_network_in_one_pass():
+    """``predict`` (pysgmcmc/models/bayesian_neural_network.py:599-630): ensemble mean / variance of the kept networks' means, or the
+    individual means and noise variances -- from ONE batched evaluation, equal to the net-by-net loop (host tensors here)."""
+    bnn = BayesianNeuralNetwork(session="cpu", dtype=torch.float64, n_nets=7, normalize_input=False, normalize_output=False)
+    bnn.is_trained = True
+    for k in range(7):
+        net = init_mlp_params(3, hidden=(8, 5), seed=k, dtype=torch.float64)
+        net[1].normal_()
+        net[-1].fill_(-2.0 - 0.1 * k)
+        bnn.samples.append(net)
+    X = np.random.RandomState(0).randn(11, 3)
+    out = bnn._network_outputs(X)
+    ref = np.stack([bnn.compute_network_output(params=net, input_data=X) for net in bnn.samples])
+    assert out.shape == (7, 11, 2) and np.allclose(out, ref, rtol=1e-13, atol=1e-13)
+    mean, var = bnn.predict(X)
+    assert np.allclose(mean, ref[:, :, 0].mean(0)) and np.allclose(var, ref[:, :, 0].var(0))
+    f, noise = bnn.predict(X, return_individual_predictions=True)
+    assert np.allclose(f, ref[:, :, 0]) and np.allclose(noise, np.exp(ref[:, :, 1]))
+
+
 def test_init_seeding_and_shapes():
     """tests/bayesian_neural_network/test_seeding.py: same seed => identical initial weights."""
     a, b, c = init_mlp_params(1, seed=7), init_mlp_params(1, seed=7), init_mlp_params(1, seed=8)
@@ -202,6 +222,12 @@ def test_train_predict_sinc(gpu, method, dtype):
     f_out, noise = bnn.predict(X_test, return_individual_predictions=True)
     assert f_out.shape == (10, 100) and noise.shape == (10, 100)
     assert bnn.sampler.use_hip_graph and bnn.sampler.n_iterations >= 1900
+    # predict evaluates all kept networks in ONE batched pass: same numbers as the reference's net-by-net loop (:599-607)
+    xn = (X_test - bnn.x_mean) / bnn.x_std
+    one_by_one = np.stack([bnn.compute_network_output(params=net, input_data=xn) for net in bnn.samples])
+    tol = 1e-5 if dtype == torch.float32 else 1e-12
+    assert np.allclose(one_by_one[:, :, 0] * bnn.y_std + bnn.y_mean, f_out, rtol=tol, atol=tol)
+    assert np.allclose(np.exp(one_by_one[:, :, 1]) * bnn.y_std ** 2, noise, rtol=tol, atol=tol)
 
 
 @pytest.mark.gpu
