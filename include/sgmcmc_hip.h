@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SGMCMC_ABI_VERSION 4
+#define SGMCMC_ABI_VERSION 5
 
 #define SGMCMC_EINVAL   (-1)   /* null/invalid argument */
 #define SGMCMC_ENODEV   (-2)   /* no HIP device / not gfx950 code object */
@@ -408,14 +408,19 @@ int sgmcmc_bias_tanh_f64(double *a, const double *bias, size_t rows, size_t cols
  *   out[m][n] = tanh( sum_k h[m][k] W[k][n] + bias[n] )
  * replacing library GEMM + sgmcmc_bias_tanh_f32 (two launches). h [M = batch][ldh >= K], W [K][ldw >= N] (the layer's
  * kernel as it lies in the arena), out [M][ldo >= N], all row-major.
- *   w_next, dot_parts: both NULL, or the single output unit's weights [N] and a [N / 64][M] buffer: the launch also leaves
- *     dot_parts[t][m] = sum over the 64 columns n of column tile t of out[m][n] * w_next[n] (fixed order) -- the Dense(1)
- *     layer of :53-56; sgmcmc_bnn_head_last_layer_backward_* adds the N / 64 partials per row (n_mean_parts = N / 64).
+ *   w_next, dot_parts: both NULL, or the single output unit's weights [N] and a [parts][M] buffer, parts =
+ *     sgmcmc_bnn_dense_tanh_dot_parts(M, N): the launch also leaves dot_parts[t][m] = sum over the columns n of column tile t
+ *     of out[m][n] * w_next[n] (fixed order) -- the Dense(1) layer of :53-56; sgmcmc_bnn_head_last_layer_backward_* adds the
+ *     partials per row in order (n_mean_parts = parts).
  *   stats_ws, tsq_parts: both NULL, or as in sgmcmc_tanh_rowdot_*: workgroups 0 .. 15 add up one slice each of the
- *     sum(theta^2) records of the previous step kernel (needs M / 32 * N / 64 >= 16 workgroups).
+ *     sum(theta^2) records of the previous step kernel (needs >= 16 full tiles; SGMCMC_EINVAL otherwise).
  * M % 32 == 0, N % 64 == 0, K % 16 == 0, K >= 64; every row 16-byte aligned (ld* % 4 == 0); operands < 2 GiB each.
- * One workgroup per 32 x 64 output tile, ONE per CU: meant for M * N / 2048 <= the CU count (batch 256 x 2048 columns).
- * fp32 MFMA is an exact k-ordered fmaf chain: results differ from a library GEMM in summation order only; deterministic.  */
+ * One workgroup (8 waves, one per CU: the operand ring fills LDS) per 32 x 64 output tile. More tiles than compute units run in
+ * rounds; when the last round would be less than half full (256 x 4864 outputs: 608 tiles on 256 CUs) the columns it covers are
+ * computed as 32 x 32 HALF tiles by a second launch on the same stream -- twice the workgroups at half the work each, 2.5 rounds
+ * instead of 3. Which columns that is depends only on (M, N, compute units of the current device): results are deterministic.
+ * fp32 MFMA is an exact k-ordered fmaf chain: results differ from a library GEMM in summation order only.                  */
+int sgmcmc_bnn_dense_tanh_dot_parts(int M, int N);   /* rows of dot_parts for an M x N layer on the current device (0: invalid shape) */
 int sgmcmc_bnn_dense_tanh_f32(const float *h, const float *W, const float *bias, float *out, int M, int N, int K, int ldh,
                               int ldw, int ldo, const float *w_next, float *dot_parts, const void *stats_ws, double *tsq_parts,
                               sgmcmc_stream_t stream);
@@ -427,8 +432,8 @@ int sgmcmc_bnn_dense_tanh_f32(const float *h, const float *W, const float *bias,
  *                                                                      W [N][K] that layer's weights, act [M][N] this layer's tanh outputs
  *   colsum_parts[t][n] = sum of out[m][n] over row tile t (rows 32 t .. 32 t + 31)      (optional; [M / 32][N])
  * i.e. out = d cost / d pre-activation of this layer; its column sums are this layer's bias gradient. Same pipeline and shape
- * limits as sgmcmc_bnn_dense_tanh_f32 (M % 32, N % 64, K % 16, K >= 64, 16-byte aligned rows, operands < 2 GiB); W is read along
- * its rows, no transpose is formed. A workgroup owns 32 rows, so the sums over ALL rows need a second pass over what other
+ * limits and the same tiling (half tiles for a thin last round) as sgmcmc_bnn_dense_tanh_f32 (M % 32, N % 64, K % 16, K >= 64,
+ * 16-byte aligned rows, operands < 2 GiB); W is read along its rows, no transpose is formed. A workgroup owns 32 rows, so the sums over ALL rows need a second pass over what other
  * workgroups wrote: inside one launch that costs more than the launch it saves (measured), so the row-tile
  * sums are left in colsum_parts and added up -- in row-tile order: bit-reproducible, no atomics --
  *   * by the NEXT launch of this function on the stream, on the side (fin_*: fin_colsum[c] = sum_r fin_parts[r][c]

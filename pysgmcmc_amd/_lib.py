@@ -37,7 +37,7 @@ def build(force=False):
 
 
 _lib = None
-ABI_VERSION = 4               # SGMCMC_ABI_VERSION of include/sgmcmc_hip.h
+ABI_VERSION = 5               # SGMCMC_ABI_VERSION of include/sgmcmc_hip.h
 
 _u64 = ctypes.c_uint64
 _sz = ctypes.c_size_t
@@ -161,6 +161,8 @@ def _declare(lib):
         f.restype = _ci
     lib.sgmcmc_bnn_dense_tanh_f32.argtypes = [_vp] * 4 + [_ci] * 6 + [_vp] * 5
     lib.sgmcmc_bnn_dense_tanh_f32.restype = _ci
+    lib.sgmcmc_bnn_dense_tanh_dot_parts.argtypes = [_ci, _ci]
+    lib.sgmcmc_bnn_dense_tanh_dot_parts.restype = _ci
     lib.sgmcmc_bnn_dense_tanh_backward_f32.argtypes = [_vp] * 5 + [_ci] * 7 + [_vp, _ci, _ci, _vp, ctypes.c_float, _vp, _vp]
     lib.sgmcmc_bnn_dense_tanh_backward_f32.restype = _ci
     lib.sgmcmc_colsum_finish_f32.argtypes = [_vp, _ci, _ci, _vp, ctypes.c_float, _vp, _vp]

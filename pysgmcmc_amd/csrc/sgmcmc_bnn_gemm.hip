@@ -53,9 +53,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 32, BN = 64, BK = 64;
-constexpr int KQ = 4;                                       // K quarters of a chunk = partial tiles the epilogue adds
-constexpr int TP = BN + 4;                                  // pitch of the accumulator tiles in LDS (floats)
+constexpr int BM = 32, BK = 64;
+// BN (template parameter of the kernel): 64 = the tile the pipeline was built for -- 8 waves = 2 MFMA tiles x 4 K quarters; 32 = the
+// HALF tile of a launch's last, partly filled round of workgroups -- 8 waves = 1 MFMA tile x 8 K eighths (see the entry points)
 constexpr int TSQ_SLICES = 16;                              // as sgmcmc_kernels.hip: slices of the sum(theta^2) partials
 
 // s_waitcnt immediate on gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14; expcnt / lgkmcnt = no wait
@@ -67,15 +67,15 @@ __device__ __forceinline__ void wait_vm()
     __builtin_amdgcn_s_waitcnt(vmcnt_imm(N));
 }
 
-// at most `chunks` chunks (3 direct loads per wave each) may still be in flight
-template <int MAXC>
+// at most `chunks` chunks (LPW direct loads per wave each) may still be in flight
+template <int MAXC, int LPW>
 __device__ __forceinline__ void wait_chunks_in_flight(int chunks)
 {
     if constexpr (MAXC == 0) {
         wait_vm<0>();
     } else {
-        if (chunks >= MAXC) wait_vm<3 * MAXC>();
-        else wait_chunks_in_flight<MAXC - 1>(chunks);
+        if (chunks >= MAXC) wait_vm<LPW * MAXC>();
+        else wait_chunks_in_flight<MAXC - 1, LPW>(chunks);
     }
 }
 
@@ -83,7 +83,8 @@ struct FwdArgs {
     const float *h, *W, *bias;  // BWD: h = delta of the layer above [M][K], W [N][K] (the layer's weights, read along their rows)
     float *out;
     const float *w_next;        // nullable
-    float *dot_parts;           // [N / 64][M]
+    float *dot_parts;           // [column tiles][M]: row part_base + (n0 - n_base) / BN of this launch's tile at column n0
+    int n_base, n_cols, part_base;  // this launch covers columns [n_base, n_base + n_cols) of the N outputs
     const double *stats_ws;     // nullable: statistics workspace of the previous step kernel ...
     double *tsq_parts;          // ... whose sum(theta^2) records workgroups 0 .. 15 add up into 16 slices
     int M, N, K, ldh, ldw, ldo;
@@ -99,8 +100,9 @@ struct FwdArgs {
     int fin_rows, fin_n;
 };
 
-template <int NS>
+template <int NS, int BN>
 struct __attribute__((aligned(16))) FwdLds {
+    static constexpr int KQ = 256 / BN, TP = BN + 4;        // K parts of a chunk = partial tiles the epilogue adds; their pitch
     union {
         struct {
             float A[NS][BM][BK];
@@ -110,7 +112,7 @@ struct __attribute__((aligned(16))) FwdLds {
         double red[8];
         struct {
             float T_[KQ][BM][TP];
-            float cs[8][BN];    // BWD: column sums of the 8 waves' rows
+            float cs[8][BN];    // BWD: column sums of the waves' rows
         } epi;
     };
 };
@@ -123,13 +125,15 @@ __device__ __forceinline__ float dpp_mov(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-// sum over the 16 lanes of a DPP row; the total arrives in the row's lane 15 (fixed order)
+// sum over the 16 lanes of a DPP row; the total arrives in the row's lane 15 (fixed order). LANES = 8: over each half of the
+// row, totals in lanes 7 and 15
+template <int LANES = 16>
 __device__ __forceinline__ float row16_sum_lane15(float v)
 {
     v += dpp_mov<0x111>(v);     // row_shr:1
     v += dpp_mov<0x112>(v);     // row_shr:2
     v += dpp_mov<0x114>(v);     // row_shr:4
-    v += dpp_mov<0x118>(v);     // row_shr:8
+    if constexpr (LANES == 16) v += dpp_mov<0x118>(v);     // row_shr:8
     return v;
 }
 
@@ -137,32 +141,40 @@ __device__ __forceinline__ float row16_sum_lane15(float v)
 //   out[m][n] = ( sum_k delta[m][k] W[n][k] ) * (1 - act[m][n]^2),  colsum[n] = sum_m out[m][n] (+ beta bias[n])
 // -- the same pipeline with B read along the rows of W (contraction-contiguous like A: same swizzled LDS image, two
 // ds_read_b128 per chunk instead of eight ds_read_b32).
-template <int NS, bool BWD>
+template <int NS, bool BWD, int BN>
 __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
 {
     static_assert(NS >= 4 && NS % 2 == 0, "ring: one chunk being read, one landing, one free; unrolled by NS with two fragment sets");
+    static_assert(BN == 64 || BN == 32, "a workgroup's 8 waves are 2 MFMA tiles x 4 K parts or 1 x 8");
     constexpr int D = NS - 1;                               // chunk kc + D is requested in iteration kc
-    __shared__ FwdLds<NS> lds;                              // ONE shared object (a second one de-pipelines the direct loads)
+    constexpr int KQ = 256 / BN, KW = BK / KQ;              // K parts of a chunk; k values per wave and chunk (16 or 8)
+    constexpr int NM = KW / 2;                              // ... = MFMAs per wave and chunk x 2 (lane halves kl = 0 / 1 hold k pairs)
+    constexpr int LPW = BN == 64 ? 3 : 2;                   // direct loads per wave and chunk
+    __shared__ FwdLds<NS, BN> lds;                          // ONE shared object (a second one de-pipelines the direct loads)
     static_assert(sizeof(lds.ring) >= sizeof(lds.T), "the accumulator tiles reuse the ring");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = wave & 1, kq = wave >> 1;                // this wave's MFMA tile (columns 32 nt ...) and quarter of every chunk
+    const int nt = BN == 64 ? (wave & 1) : 0, kq = BN == 64 ? (wave >> 1) : wave;     // this wave's MFMA tile (columns 32 nt ...) and K part of every chunk
     // ---- workgroup -> tile, XCD-aware: XCD x owns tiles [x T/8, (x+1) T/8), consecutive tiles share the column tile
-    const int tiles_m = g.M / BM, tiles = tiles_m * (g.N / BN);
+    const int tiles_m = g.M / BM, tiles = tiles_m * (g.n_cols / BN);
     int t = blockIdx.x;
     if (tiles % 8 == 0) t = (t & 7) * (tiles >> 3) + (t >> 3);
-    const int n0 = (t / tiles_m) * BN, m0 = (t % tiles_m) * BM;
+    const int n0 = g.n_base + (t / tiles_m) * BN, m0 = (t % tiles_m) * BM;
     const int nk = (g.K + BK - 1) / BK;                     // K % 16 == 0: the last chunk may hold 16, 32 or 48 valid k only
-    // ---- direct loads: wave w requests 4 rows of A (256 B each) and 2 x 4 rows of B per chunk
+    // ---- direct loads: wave w requests 4 rows of A (256 B each) and, BN = 64, 2 x 4 rows of B per chunk (BN = 32: ONE 1 KiB
+    // piece of B: forward 8 rows k of 128 B, backward 4 rows n of 256 B)
     const int ar = 4 * wave + (lane >> 4);                  // A row of this lane's 16 bytes
     const int aq = (lane & 15) ^ (ar & 15);                 // logical quad stored at physical slot lane & 15
-    const int br = 8 * wave + (lane >> 4);                  // B rows br, br + 4
+    // B rows of this lane: BN = 64 br, br + 4 (two pieces); BN = 32 forward 8 w + lane / 8 (quad lane & 7), backward = A's pattern
+    const int br = BN == 64 ? 8 * wave + (lane >> 4) : (BWD ? ar : 8 * wave + (lane >> 3));
     [[maybe_unused]] const unsigned a_lane = (unsigned)(ar * g.ldh + 4 * aq) * 4u;
     // B forward: rows k of W (n contiguous), lane & 15 = quad of the 64 tile columns. B backward: tile column n = row n0 + br of W
     // (k contiguous): quads swizzled like A's (rows br and br + 4 differ in bit 2 of the swizzle: two lane offsets)
     const int bq0 = (lane & 15) ^ (br & 15), bq1 = (lane & 15) ^ ((br + 4) & 15);
-    [[maybe_unused]] const unsigned b_lane = BWD ? (unsigned)(br * g.ldw + 4 * bq0) * 4u : (unsigned)(br * g.ldw + 4 * (lane & 15)) * 4u;
+    [[maybe_unused]] const unsigned b_lane = BWD ? (unsigned)(br * g.ldw + 4 * bq0) * 4u
+                                                 : (unsigned)(br * g.ldw + 4 * (BN == 64 ? (lane & 15) : (lane & 7))) * 4u;
     [[maybe_unused]] const unsigned b_lane1 = (unsigned)((br + 4) * g.ldw + 4 * bq1) * 4u;
+    [[maybe_unused]] constexpr int BR0 = BN == 64 ? 8 : (BWD ? 4 : 8);       // first B row of wave w's piece = BR0 w
     [[maybe_unused]] const unsigned b_chunk = (unsigned)BK * (unsigned)g.ldw * 4u, b_rows4 = 4u * (unsigned)g.ldw * 4u;
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
@@ -170,17 +182,19 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(BWD ? g.W + (size_t)n0 * g.ldw : g.W + n0), 0, 0x7fffffff, 0x00020000);
 #endif
+    // row r of the B image of stage st: forward [k][BN n], backward [n][BK k] (same bytes, BK * BN floats per stage)
+    [[maybe_unused]] auto ldsB = [&](int st, int r) { return &lds.ring.B[st][0][0] + r * (BWD ? BK : BN); };
     auto issue = [&](int kc, int st) {                      // chunks that lie wholly below K: scalar offsets only
 #if defined(__HIP_DEVICE_COMPILE__)
         const unsigned sa = (unsigned)kc * (BK * 4);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, &lds.ring.A[st][4 * wave][0], 16, a_lane, sa, 0, 0);
         if constexpr (BWD) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave][0], 16, b_lane, sa, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave + 4][0], 16, b_lane1, sa, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, ldsB(st, BR0 * wave), 16, b_lane, sa, 0, 0);
+            if constexpr (BN == 64) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, ldsB(st, 8 * wave + 4), 16, b_lane1, sa, 0, 0);
         } else {
             const unsigned sb = (unsigned)kc * b_chunk;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave][0], 16, b_lane, sb, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave + 4][0], 16, b_lane, sb + b_rows4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, ldsB(st, 8 * wave), 16, b_lane, sb, 0, 0);
+            if constexpr (BN == 64) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, ldsB(st, 8 * wave + 4), 16, b_lane, sb + b_rows4, 0, 0);
         }
 #endif
     };
@@ -194,40 +208,49 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
             int k0 = kc * BK + 4 * bq0, k1 = kc * BK + 4 * bq1;
             if (k0 + 4 > g.K) k0 = g.K - 4;
             if (k1 + 4 > g.K) k1 = g.K - 4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave][0], 16, (unsigned)(br * g.ldw + k0) * 4u, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave + 4][0], 16, (unsigned)((br + 4) * g.ldw + k1) * 4u, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, ldsB(st, BR0 * wave), 16, (unsigned)(br * g.ldw + k0) * 4u, 0, 0, 0);
+            if constexpr (BN == 64)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, ldsB(st, 8 * wave + 4), 16, (unsigned)((br + 4) * g.ldw + k1) * 4u, 0, 0, 0);
         } else {
             int kb0 = kc * BK + br, kb1 = kc * BK + br + 4;
             if (kb0 >= g.K) kb0 = g.K - 1;
             if (kb1 >= g.K) kb1 = g.K - 1;
-            const unsigned c4 = 4u * (unsigned)(lane & 15) * 4u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave][0], 16, (unsigned)kb0 * (unsigned)g.ldw * 4u + c4, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds.ring.B[st][8 * wave + 4][0], 16, (unsigned)kb1 * (unsigned)g.ldw * 4u + c4, 0, 0, 0);
+            const unsigned c4 = 4u * (unsigned)(BN == 64 ? (lane & 15) : (lane & 7)) * 4u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, ldsB(st, 8 * wave), 16, (unsigned)kb0 * (unsigned)g.ldw * 4u + c4, 0, 0, 0);
+            if constexpr (BN == 64)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, ldsB(st, 8 * wave + 4), 16, (unsigned)kb1 * (unsigned)g.ldw * 4u + c4, 0, 0, 0);
         }
 #endif
     };
     // ---- fragment addresses
     const int fm = lane & 31, kl = lane >> 5;
     const int sw = fm & 15;
-    const int aoff0 = fm * BK + 4 * ((4 * kq + 2 * kl) ^ sw), aoff1 = fm * BK + 4 * ((4 * kq + 2 * kl + 1) ^ sw);
-    const int boff = BWD ? 32 * nt * BK + aoff0 : (16 * kq + 8 * kl) * BN + 32 * nt + fm;      // BWD: row 32 nt + fm, same quads as A
+    // a lane holds NM = 8 (4) consecutive k of its wave's K part: quads 4 kq + 2 kl, + 1 (BN = 32: the one quad 2 kq + kl)
+    constexpr int QW = KW / 4;                              // quads per wave and chunk
+    const int aoff0 = fm * BK + 4 * ((QW * kq + (QW / 2) * kl) ^ sw), aoff1 = fm * BK + 4 * ((QW * kq + (QW / 2) * kl + 1) ^ sw);
+    const int boff = BWD ? 32 * nt * BK + aoff0 : (KW * kq + NM * kl) * BN + 32 * nt + fm;     // BWD: row 32 nt + fm, same quads as A
     const int boff1 = 32 * nt * BK + aoff1;
     struct Frag {
         f32x4_t a0, a1;
-        float b[8];
+        float b[NM];
     };
     auto read_frags = [&](int st, Frag &f) {
         const float *A = &lds.ring.A[st][0][0];
         const float *B = &lds.ring.B[st][0][0];
         f.a0 = *reinterpret_cast<const f32x4_t *>(A + aoff0);
-        f.a1 = *reinterpret_cast<const f32x4_t *>(A + aoff1);
+        if constexpr (NM == 8) f.a1 = *reinterpret_cast<const f32x4_t *>(A + aoff1);
         if constexpr (BWD) {
-            const f32x4_t b0 = *reinterpret_cast<const f32x4_t *>(B + boff), b1 = *reinterpret_cast<const f32x4_t *>(B + boff1);
+            const f32x4_t b0 = *reinterpret_cast<const f32x4_t *>(B + boff);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { f.b[j] = b0[j]; f.b[4 + j] = b1[j]; }
+            for (int j = 0; j < 4; ++j) f.b[j] = b0[j];
+            if constexpr (NM == 8) {
+                const f32x4_t b1 = *reinterpret_cast<const f32x4_t *>(B + boff1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f.b[4 + j] = b1[j];
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f.b[j] = B[boff + j * BN];
+            for (int j = 0; j < NM; ++j) f.b[j] = B[boff + j * BN];
         }
     };
     f32x16 acc0, acc1;
@@ -235,7 +258,7 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
     auto mfmas = [&](const Frag &f, int j0, int j1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < NM; ++j)
             if (j >= j0 && j < j1) {
                 const float a = j < 4 ? f.a0[j & 3] : f.a1[j & 3];
                 if (!(j & 1)) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f.b[j], acc0, 0, 0, 0);
@@ -244,7 +267,12 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
     };
     // ---- prologue: (BWD) this lane's quad of the activations for the epilogue, then chunks 0 .. D - 1 requested ...
     f32x4_t actv = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (BWD) actv = *reinterpret_cast<const f32x4_t *>(g.act + (size_t)(m0 + (tid >> 4)) * g.lda + n0 + (tid & 15) * 4);
+    constexpr int QR = BN / 4;                              // quads (= epilogue lanes) per tile row; lanes >= 8 BN idle in the epilogue
+    const int erow = tid / QR, ec4 = (tid % QR) * 4;
+    const bool eactive = tid < BM * QR;
+    if constexpr (BWD) {
+        if (eactive) actv = *reinterpret_cast<const f32x4_t *>(g.act + (size_t)(m0 + erow) * g.lda + n0 + ec4);
+    }
     // (BWD) side job of wave 0: the bias gradient of the layer ABOVE -- the per-row-tile column sums the previous launch left are
     // added up in row-tile order (deterministic; the launch boundary is what makes them visible). Loads first, the sums after
     // the chunk requests: older vector-memory operations only make the counted waits below stronger.
@@ -292,7 +320,7 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) tsq += __shfl_down(tsq, off, 64);
     }
-    wait_chunks_in_flight<D - 1>(nk - 1);
+    wait_chunks_in_flight<D - 1, LPW>(nk - 1);
     __builtin_amdgcn_s_barrier();
     Frag fa, fb;
     read_frags(0, fa);
@@ -301,20 +329,20 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
     // without register copies.
     auto steady = [&](int kc, const Frag &cur, Frag &nxt, auto stage) {
         constexpr int I = decltype(stage)::value;           // kc % NS
-        wait_vm<3 * (D - 2)>();                             // chunk kc + 1 landed: chunks kc + 2 .. kc + D - 1 may be in flight
+        wait_vm<LPW * (D - 2)>();                           // chunk kc + 1 landed: chunks kc + 2 .. kc + D - 1 may be in flight
         __builtin_amdgcn_s_barrier();                       // ... for every wave; and the stage of chunk kc - 1 is free
         // order inside an iteration (tools/fwd_fused_step_probe.py, 10 M-parameter chain, us per step): the fragment reads right
         // after the second MFMA and the loads after the fourth 186.0; loads + reads bunched after the second 187.0; one load per
         // MFMA gap 186.0; s_setprio 1 for the later-dispatched wave of each SIMD 187.7
-        mfmas(cur, 0, 2);
+        mfmas(cur, 0, NM / 4);
         __builtin_amdgcn_sched_barrier(0);
         read_frags((I + 1) % NS, nxt);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(cur, 2, 4);
+        mfmas(cur, NM / 4, NM / 2);
         __builtin_amdgcn_sched_barrier(0);
         issue(kc + D, (I + D) % NS);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(cur, 4, 8);
+        mfmas(cur, NM / 2, NM);
     };
     int kc = 0;
     for (; kc + D + NS < nk; kc += NS) {                    // every chunk requested here (up to kc + NS - 1 + D) lies wholly below K
@@ -325,71 +353,76 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
     }
     int st_read = 1, st_issue = D % NS;                     // kc % NS == 0 here: stage of chunk kc + 1, stage of chunk kc + D
     for (; kc + 1 < nk; ++kc) {                             // the last chunks: counted waits, the (possibly short) last chunk requested
-        wait_chunks_in_flight<D - 2>(nk - 2 - kc);
+        wait_chunks_in_flight<D - 2, LPW>(nk - 2 - kc);
         __builtin_amdgcn_s_barrier();
-        mfmas(fa, 0, 2);
+        mfmas(fa, 0, NM / 4);
         __builtin_amdgcn_sched_barrier(0);
         read_frags(st_read, fb);
         if (kc + D < nk) issue_clamped(kc + D, st_issue);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(fa, 2, 8);
+        mfmas(fa, NM / 4, NM);
         fa = fb;
         st_read = st_read + 1 == NS ? 0 : st_read + 1;
         st_issue = st_issue + 1 == NS ? 0 : st_issue + 1;
     }
-    // last chunk: only the quarters that lie below K exist
-    if ((nk - 1) * BK + 16 * kq < g.K) mfmas(fa, 0, 8);
-    // ---- epilogue: the four K quarters meet in LDS (fixed order), bias + tanh on row-major quads, 16-byte stores
+    // last chunk: only the K parts that lie below K exist (K % 16 == 0: a half tile's eighths exist in pairs)
+    if ((nk - 1) * BK + KW * kq < g.K) mfmas(fa, 0, NM);
+    // ---- epilogue: the KQ partial tiles meet in LDS (fixed order), bias + tanh on row-major quads, 16-byte stores
     __syncthreads();                                        // every fragment read is done: the ring is free
 #pragma unroll
     for (int r = 0; r < 16; ++r) lds.T[kq][(r & 3) + 8 * (r >> 2) + 4 * kl][32 * nt + fm] = acc0[r] + acc1[r];
     __syncthreads();
     {
-        const int row = tid >> 4, c4 = (tid & 15) * 4;
-        f32x4_t s = *reinterpret_cast<const f32x4_t *>(&lds.T[0][row][c4]);
+        const int row = erow, c4 = ec4;                     // lanes tid < 8 BN own one quad of the tile each
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+        if (eactive) {
+            s = *reinterpret_cast<const f32x4_t *>(&lds.T[0][row][c4]);
 #pragma unroll
-        for (int p = 1; p < KQ; ++p) {
-            const f32x4_t sp = *reinterpret_cast<const f32x4_t *>(&lds.T[p][row][c4]);
+            for (int p = 1; p < KQ; ++p) {
+                const f32x4_t sp = *reinterpret_cast<const f32x4_t *>(&lds.T[p][row][c4]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s[j] += sp[j];
+                for (int j = 0; j < 4; ++j) s[j] += sp[j];
+            }
         }
         if constexpr (BWD) {
             // tanh' of the layer below as the epilogue (sgmcmc_tanh_backward_colsum_*'s arithmetic) ...
             f32x4_t v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = s[j] * (1.f - actv[j] * actv[j]);
-            *reinterpret_cast<f32x4_t *>(g.out + (size_t)(m0 + row) * g.ldo + n0 + c4) = v;
-            // ... and the bias gradient: column sums over the tile's 32 rows (4 rows of a wave by shuffles, the 8 waves in order).
+            if (eactive) *reinterpret_cast<f32x4_t *>(g.out + (size_t)(m0 + row) * g.ldo + n0 + c4) = v;
+            // ... and the bias gradient: column sums over the tile's 32 rows (the rows of a wave by shuffles, the waves in order).
             // The row tiles of a column are NOT added here: that takes a second pass over what other workgroups wrote, and in
             // one launch it costs more than it saves (arrival counter + agent-scope fences: +12 us; relaxed write-through
             // atomics: +2.5 us, the step got slower -- tools/bwd_fused_probe.py). The partial rows are left
             // for the NEXT launch to add up on the side (fin_* above), or for sgmcmc_colsum_finish_f32.
             if (g.colsum_parts == nullptr) return;          // (the first layer's bias gradient comes from the [x | 1]^T delta product)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] += __shfl_xor(v[j], 16, 64);
-                v[j] += __shfl_xor(v[j], 32, 64);
-            }
-            if (lane < 16) *reinterpret_cast<f32x4_t *>(&lds.epi.cs[wave][c4]) = v;
+            for (int off = QR; off < 64; off <<= 1)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += __shfl_xor(v[j], off, 64);
+            if (eactive && lane < QR) *reinterpret_cast<f32x4_t *>(&lds.epi.cs[wave][c4]) = v;
             __syncthreads();
             if (tid < BN) {
+                constexpr int AW = BM * QR / 64;            // waves that hold tile rows
                 float tot = lds.epi.cs[0][tid];
 #pragma unroll
-                for (int w = 1; w < 8; ++w) tot += lds.epi.cs[w][tid];
+                for (int w = 1; w < AW; ++w) tot += lds.epi.cs[w][tid];
                 g.colsum_parts[(size_t)(m0 / BM) * g.N + n0 + tid] = tot;
             }
             return;
         }
-        const f32x4_t b = *reinterpret_cast<const f32x4_t *>(g.bias + n0 + c4);
-        f32x4_t v;
+        if (eactive) {
+            const f32x4_t b = *reinterpret_cast<const f32x4_t *>(g.bias + n0 + c4);
+            f32x4_t v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = tanh_f32(s[j] + b[j]);
-        *reinterpret_cast<f32x4_t *>(g.out + (size_t)(m0 + row) * g.ldo + n0 + c4) = v;
-        if (g.w_next != nullptr) {
-            const f32x4_t w = *reinterpret_cast<const f32x4_t *>(g.w_next + n0 + c4);
-            float d = ((v[0] * w[0] + v[1] * w[1]) + v[2] * w[2]) + v[3] * w[3];
-            d = row16_sum_lane15(d);                        // the 16 lanes of a DPP row hold one tile row
-            if ((lane & 15) == 15) g.dot_parts[(size_t)(n0 / BN) * g.M + m0 + row] = d;
+            for (int j = 0; j < 4; ++j) v[j] = tanh_f32(s[j] + b[j]);
+            *reinterpret_cast<f32x4_t *>(g.out + (size_t)(m0 + row) * g.ldo + n0 + c4) = v;
+            if (g.w_next != nullptr) {
+                const f32x4_t w = *reinterpret_cast<const f32x4_t *>(g.w_next + n0 + c4);
+                float d = ((v[0] * w[0] + v[1] * w[1]) + v[2] * w[2]) + v[3] * w[3];
+                d = row16_sum_lane15<QR>(d);                // the QR lanes of a tile row are (half of) one DPP row
+                if ((lane & (QR - 1)) == QR - 1) g.dot_parts[(size_t)(g.part_base + (n0 - g.n_base) / BN) * g.M + m0 + row] = d;
+            }
         }
     }
     if (slicer) {                                           // uniform per workgroup
@@ -412,9 +445,64 @@ __global__ void __launch_bounds__(256) colsum_finish_kernel(const float *__restr
     colsum[c] = (beta != 0.f) ? tot + beta * bias[c] : tot;
 }
 
+// Which columns of the N outputs run as 32 x 64 tiles and which as 32 x 32 half tiles. A launch of T tiles on C compute units
+// takes ceil(T / C) rounds of workgroups (one per CU: the ring fills LDS); when the last round is less than half full, the columns
+// it would cover are cut into HALF tiles instead -- twice as many workgroups of half the work, all running at once -- so that
+// e.g. 256 x 4864 (608 tiles on 256 CUs) takes 2.5 rounds instead of 3. Full tiles come first (columns [0, n_full)).
+struct ColumnPlan {
+    int n_full;                 // columns on full tiles (a multiple of 64)
+    int parts;                  // column tiles in all = rows of dot_parts: n_full / 64 + (N - n_full) / 32
+};
+
+ColumnPlan plan_columns(int M, int N)
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const int tiles_m = M / BM, col_tiles = N / 64, tiles = tiles_m * col_tiles;
+    ColumnPlan p{N, col_tiles};
+    if (tiles <= cus || tiles % cus == 0) return p;
+    const int full_cols = (tiles / cus) * cus / tiles_m;     // column tiles that fill whole rounds
+    const int left = col_tiles - full_cols;
+    if (full_cols >= 1 && 2 * left * tiles_m <= cus) {       // the half tiles run as ONE round
+        p.n_full = full_cols * 64;
+        p.parts = full_cols + 2 * left;
+    }
+    return p;
+}
+
+template <bool BWD>
+int launch_dense(FwdArgs g, const ColumnPlan &plan, hipStream_t stream, const char *what)
+{
+    g.n_base = 0;
+    g.n_cols = plan.n_full;
+    g.part_base = 0;
+    hipLaunchKernelGGL((bnn_dense_tanh_kernel<4, BWD, 64>), dim3((g.M / BM) * (plan.n_full / 64)), dim3(512), 0, stream, g);
+    if (plan.n_full < g.N) {
+        // the rest of the columns as half tiles, behind the full ones on the stream; the side jobs (column-sum finish, sum(theta^2)
+        // slices) belong to the first launch
+        g.n_base = plan.n_full;
+        g.n_cols = g.N - plan.n_full;
+        g.part_base = plan.n_full / 64;
+        g.fin_parts = nullptr;
+        g.stats_ws = nullptr;
+        g.tsq_parts = nullptr;
+        hipLaunchKernelGGL((bnn_dense_tanh_kernel<4, BWD, 32>), dim3((g.M / BM) * (g.n_cols / 32)), dim3(512), 0, stream, g);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, what);
+}
+
 }  // namespace
 
 extern "C" {
+
+/* see include/sgmcmc_hip.h */
+int sgmcmc_bnn_dense_tanh_dot_parts(int M, int N)
+{
+    if (M <= 0 || N <= 0 || M % BM || N % 64) return 0;
+    return plan_columns(M, N).parts;
+}
 
 /* see include/sgmcmc_hip.h */
 int sgmcmc_bnn_dense_tanh_f32(const float *h, const float *W, const float *bias, float *out, int M, int N, int K, int ldh,
@@ -423,20 +511,20 @@ int sgmcmc_bnn_dense_tanh_f32(const float *h, const float *W, const float *bias,
 {
     if (!h || !W || !bias || !out || ((w_next != nullptr) != (dot_parts != nullptr)) || ((stats_ws != nullptr) != (tsq_parts != nullptr)))
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh: NULL argument (w_next / dot_parts and stats_ws / tsq_parts go together)");
-    if (M <= 0 || N <= 0 || K < 64 || M % BM || N % BN || K % 16 || ldh < K || ldw < N || ldo < N || ldh % 4 || ldw % 4 || ldo % 4 ||
+    if (M <= 0 || N <= 0 || K < 64 || M % BM || N % 64 || K % 16 || ldh < K || ldw < N || ldo < N || ldh % 4 || ldw % 4 || ldo % 4 ||
         ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(bias) |
           reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(w_next)) & 15u))
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh: needs M %% 32 == 0, N %% 64 == 0, K %% 16 == 0, K >= 64, 16-byte aligned rows");
     if ((double)K * ldw * 4.0 >= 2147483648.0 || (double)M * ldh * 4.0 >= 2147483648.0)
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh: an operand spans more than 2 GiB (32-bit buffer offsets)");
-    if (stats_ws != nullptr && (M / BM) * (N / BN) < TSQ_SLICES)
+    const ColumnPlan plan = plan_columns(M, N);
+    if (stats_ws != nullptr && (M / BM) * (plan.n_full / 64) < TSQ_SLICES)
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh: the sum(theta^2) side job needs at least 16 output tiles (the loss head adds 16 slices)");
-    FwdArgs g{h, W, bias, out, w_next, dot_parts, static_cast<const double *>(stats_ws), tsq_parts, M, N, K, ldh, ldw, ldo,
-              nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f, 0, 0};
-    const int tiles = (M / BM) * (N / BN);
-    hipLaunchKernelGGL((bnn_dense_tanh_kernel<4, false>), dim3(tiles), dim3(512), 0, static_cast<hipStream_t>(stream), g);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : hip_fail(e, "launch bnn_dense_tanh");
+    FwdArgs g{};
+    g.h = h; g.W = W; g.bias = bias; g.out = out; g.w_next = w_next; g.dot_parts = dot_parts;
+    g.stats_ws = static_cast<const double *>(stats_ws); g.tsq_parts = tsq_parts;
+    g.M = M; g.N = N; g.K = K; g.ldh = ldh; g.ldw = ldw; g.ldo = ldo;
+    return launch_dense<false>(g, plan, static_cast<hipStream_t>(stream), "launch bnn_dense_tanh");
 }
 
 /* see include/sgmcmc_hip.h */
@@ -447,23 +535,22 @@ int sgmcmc_bnn_dense_tanh_backward_f32(const float *delta, const float *W, const
 {
     if (!delta || !W || !act || !out)
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh_backward: NULL argument");
-    if (M <= 0 || N <= 0 || K < 64 || M % BM || N % BN || K % 16 || ldd < K || ldw < K || lda < N || ldo < N || ldd % 4 || ldw % 4 ||
+    if (M <= 0 || N <= 0 || K < 64 || M % BM || N % 64 || K % 16 || ldd < K || ldw < K || lda < N || ldo < N || ldd % 4 || ldw % 4 ||
         lda % 4 || ldo % 4 ||
         ((reinterpret_cast<uintptr_t>(delta) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(act) |
           reinterpret_cast<uintptr_t>(out)) & 15u))
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh_backward: needs M %% 32 == 0, N %% 64 == 0, K %% 16 == 0, K >= 64, 16-byte aligned rows");
     if ((double)N * ldw * 4.0 >= 2147483648.0 || (double)M * ldd * 4.0 >= 2147483648.0)
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh_backward: an operand spans more than 2 GiB (32-bit buffer offsets)");
-    const int tiles = (M / BM) * (N / BN);
     if (fin_parts != nullptr &&
         (!fin_colsum || fin_rows <= 0 || fin_n <= 0 || (fin_beta != 0.f && !fin_bias) || fin_parts == colsum_parts))
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh_backward: the side job needs fin_colsum, fin_rows > 0, fin_n > 0, fin_bias with "
                                    "fin_beta != 0 and partial sums other than the ones this launch writes");
-    FwdArgs g{delta, W, nullptr, out, nullptr, nullptr, nullptr, nullptr, M, N, K, ldd, ldw, ldo, act, colsum_parts, lda,
-              fin_parts, fin_bias, fin_colsum, fin_beta, fin_rows, fin_n};
-    hipLaunchKernelGGL((bnn_dense_tanh_kernel<4, true>), dim3(tiles), dim3(512), 0, static_cast<hipStream_t>(stream), g);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : hip_fail(e, "launch bnn_dense_tanh_backward");
+    FwdArgs g{};
+    g.h = delta; g.W = W; g.out = out; g.M = M; g.N = N; g.K = K; g.ldh = ldd; g.ldw = ldw; g.ldo = ldo;
+    g.act = act; g.colsum_parts = colsum_parts; g.lda = lda;
+    g.fin_parts = fin_parts; g.fin_bias = fin_bias; g.fin_colsum = fin_colsum; g.fin_beta = fin_beta; g.fin_rows = fin_rows; g.fin_n = fin_n;
+    return launch_dense<true>(g, plan_columns(M, N), static_cast<hipStream_t>(stream), "launch bnn_dense_tanh_backward");
 }
 
 /* see include/sgmcmc_hip.h */

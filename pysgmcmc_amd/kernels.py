@@ -498,26 +498,14 @@ def bias_tanh(a, bias):
     return a
 
 
-_CU_COUNT = {}
-
-
-def _cu_count(device):
-    n = _CU_COUNT.get(device)
-    if n is None:
-        n = _CU_COUNT[device] = int(torch.cuda.get_device_properties(device).multi_processor_count)
-    return n
-
-
 def bnn_dense_tanh_fits(h, W, out):
     """Can :func:`bnn_dense_tanh` take this layer? f32 device tensors, batch a multiple of 32, fan-out a multiple of 64, fan-in a
-    multiple of 16 and >= 64, 16-byte aligned rows -- and at most one 32 x 64 output tile per compute unit (the kernel is built for
-    ONE wave of workgroups: batch 256 x 2048 columns; larger grids run the library product)."""
+    multiple of 16 and >= 64, 16-byte aligned rows. Any number of 32 x 64 output tiles: more than one per compute unit run in
+    rounds, a thin last round as half tiles (``include/sgmcmc_hip.h``)."""
     if not (h.is_cuda and h.dtype == W.dtype == out.dtype == torch.float32 and h.dim() == W.dim() == out.dim() == 2):
         return False
     M, K, N = int(h.shape[0]), int(h.shape[1]), int(W.shape[1])
     if W.shape[0] != K or tuple(out.shape) != (M, N) or M % 32 or N % 64 or K % 16 or K < 64:
-        return False
-    if (M // 32) * (N // 64) > _cu_count(h.device):
         return False
     for t in (h, W, out):
         if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
@@ -525,17 +513,28 @@ def bnn_dense_tanh_fits(h, W, out):
     return True
 
 
+def bnn_dense_tanh_dot_parts(M, N, device):
+    """Rows of the ``dot_parts`` buffer :func:`bnn_dense_tanh` fills for an ``M x N`` layer on ``device`` (one per column tile:
+    64 columns, or 32 where the launch uses half tiles)."""
+    with torch.cuda.device(device):
+        n = int(lib().sgmcmc_bnn_dense_tanh_dot_parts(int(M), int(N)))
+    if n <= 0:
+        raise ValueError("pysgmcmc_amd: bnn_dense_tanh_dot_parts: M %% 32 == 0 and N %% 64 == 0 required, got %d x %d" % (M, N))
+    return n
+
+
 def bnn_dense_tanh(h, W, bias, out, w_next=None, dot_parts=None, stats_workspace=None, tsq_parts=None):
     """``out = tanh(h @ W + bias)`` in ONE launch on the fp32 matrix cores (``sgmcmc_bnn_dense_tanh_f32``; shapes as
-    :func:`bnn_dense_tanh_fits` demands). With ``w_next [N]`` and ``dot_parts [N // 64, M]`` the launch also leaves the
-    per-column-tile partial dot products of ``out`` with ``w_next`` (the single output unit); with ``stats_workspace`` and
+    :func:`bnn_dense_tanh_fits` demands). With ``w_next [N]`` and ``dot_parts [bnn_dense_tanh_dot_parts(M, N), M]`` the launch also
+    leaves the per-column-tile partial dot products of ``out`` with ``w_next`` (the single output unit); with ``stats_workspace`` and
     ``tsq_parts`` it adds up the sum(theta^2) records like :func:`tanh_rowdot`."""
     M, K = int(h.shape[0]), int(h.shape[1])
     N = int(W.shape[1])
     if not bnn_dense_tanh_fits(h, W, out) or bias.numel() != N or bias.dtype != h.dtype:
         raise ValueError("pysgmcmc_amd: bnn_dense_tanh: shapes / dtypes / alignment do not fit the kernel (see bnn_dense_tanh_fits)")
-    if dot_parts is not None and (w_next is None or w_next.numel() != N or dot_parts.numel() != (N // 64) * M):
-        raise ValueError("pysgmcmc_amd: bnn_dense_tanh needs w_next [N] and dot_parts [N // 64, M]")
+    if dot_parts is not None and (w_next is None or w_next.numel() != N or not dot_parts.is_contiguous()
+                                  or dot_parts.numel() != bnn_dense_tanh_dot_parts(M, N, h.device) * M):
+        raise ValueError("pysgmcmc_amd: bnn_dense_tanh needs w_next [N] and dot_parts [bnn_dense_tanh_dot_parts(M, N), M]")
     if tsq_parts is not None and (tsq_parts.dtype != torch.float64 or tsq_parts.numel() < 16 or (M // 32) * (N // 64) < 16):
         raise ValueError("pysgmcmc_amd: bnn_dense_tanh: tsq_parts must be float64[16] and the launch needs >= 16 output tiles")
     with torch.cuda.device(h.device):                          # (h may be a pitched view: rows are what must be contiguous)
@@ -554,8 +553,6 @@ def bnn_dense_tanh_backward_fits(delta, W, act, out):
         return False
     M, K, N = int(delta.shape[0]), int(delta.shape[1]), int(W.shape[0])
     if W.shape[1] != K or tuple(out.shape) != (M, N) or tuple(act.shape) != (M, N) or M % 32 or N % 64 or K % 16 or K < 64:
-        return False
-    if (M // 32) * (N // 64) > _cu_count(delta.device):
         return False
     for t in (delta, W, act, out):
         if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:

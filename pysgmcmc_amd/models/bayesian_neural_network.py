@@ -201,6 +201,10 @@ class BNNCost(object):
         # layer's bias gradient comes out of its weight-gradient product as the extra row of [x | 1]^T delta. False: library
         # products + the small activation / tanh' launches for every layer. Which launches a configuration gets is decided once,
         # in _plan(); the steps only walk the plan (see plan_summary()).
+        # True takes a layer to the fused launch where that PAYS: at most one 32 x 64 output tile per compute unit (batch 256 x
+        # 2048 columns). The kernels also run larger layers (rounds of workgroups, a thin last round as half tiles) and "all"
+        # forces them there, but on configs[4]'s 256 x 4864 x 4864 layers the library's stream-K product is within 3 % of the
+        # matrix pipe and the step LOSES 25 us of 783 with the fused launches (profiles/r05_dense_rounds.txt).
         self.fused_layers = True
         self._x_ext = {}                                          # pitched feed buffers handed out by static_feed_buffer()
         self._plans = {}
@@ -260,7 +264,7 @@ class BNNCost(object):
             ws = {"h": [mk(w) for w in widths], "d": [mk(w) for w in widths],
                   "ones": torch.ones(B, dtype=dt, device=dev),
                   # per-column-tile partial dot products of the last hidden layer with the output unit's weights (bnn_dense_tanh)
-                  "dot_parts": torch.zeros(max(widths[-2] // 64, 1) if n_layers >= 2 else 1, B, dtype=dt, device=dev),
+                  "dot_parts": None,
                   "tsq_parts": torch.zeros(16, dtype=torch.float64, device=dev),
                   "cost": torch.zeros(1, dtype=dt, device=dev), "mse": torch.zeros(1, dtype=dt, device=dev)}
             self._ws = {key: ws}
@@ -314,16 +318,21 @@ class BNNCost(object):
         hs, ds = ws["h"], ws["d"]
         single_out = params[2 * L].shape[1] == 1 and n_layers >= 2
         fused_head = single_out and have_partials
+        cus = torch.cuda.get_device_properties(X.device).multi_processor_count if X.is_cuda else 0
+        # the fused launch pays while its workgroups run as ONE round (see __init__); "all": wherever the kernel takes the shape
+        pays = lambda rows, cols: self.fused_layers == "all" or (rows // 32) * (cols // 64) <= cus
         forward, h = [], X
         for l in range(n_layers):
             W = params[2 * l]
-            fits = l < L and self.fused_layers and kernels.bnn_dense_tanh_fits(h, W, hs[l])
+            fits = l < L and self.fused_layers and kernels.bnn_dense_tanh_fits(h, W, hs[l]) and pays(B, int(W.shape[1]))
             if l == L:
                 forward.append("by rowdot" if single_out else "addmm")
             elif l == L - 1 and single_out:
                 # with the output unit's dot product in the launch, the loss head must add the partials: the fused head only
                 top_fits = fits and fused_head and (B // 32) * (int(W.shape[1]) // 64) >= 16 and B <= 1024
                 forward.append("dense_tanh+dot" if top_fits else "mm+bias_tanh_rowdot")
+                if top_fits and ws["dot_parts"] is None:
+                    ws["dot_parts"] = torch.zeros(kernels.bnn_dense_tanh_dot_parts(B, int(W.shape[1]), X.device), B, dtype=X.dtype, device=X.device)
             else:
                 forward.append("dense_tanh" if fits else "mm+bias_tanh")
             h = hs[l]
@@ -341,7 +350,8 @@ class BNNCost(object):
                 backward[l] = "in head launch"
             elif l == L and single_out:
                 backward[l] = "last_layer_backward"
-            elif self.fused_layers and kernels.bnn_dense_tanh_backward_fits(ds[l], params[2 * l], hs[l - 1], ds[l - 1]):
+            elif (self.fused_layers and kernels.bnn_dense_tanh_backward_fits(ds[l], params[2 * l], hs[l - 1], ds[l - 1])
+                  and pays(B, int(params[2 * l].shape[0]))):
                 backward[l] = "dense_tanh_backward"
             else:
                 backward[l] = "mm+tanh_backward" if (l == 1 and ones_row) else "mm+tanh_backward_colsum"

@@ -10,10 +10,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("M,K,N", [(256, 2048, 2048), (256, 784, 2048), (32, 64, 64), (64, 80, 128), (96, 272, 192), (32, 1040, 64)])
+# (256, 4864, 4864): configs[4]'s hidden layer, 608 tiles = 2 rounds of full tiles + 192 HALF tiles on 256 compute units;
+# (512, 2048, 2048): two full rounds; (64, 144, 8704) / (32, 80, 8320): half tiles with K tails, XCD map on / off for the halves
+BIG_SHAPES = [(256, 4864, 4864), (512, 2048, 2048), (64, 144, 8704), (32, 80, 8320)]
+
+
+@pytest.mark.parametrize("M,K,N", [(256, 2048, 2048), (256, 784, 2048), (32, 64, 64), (64, 80, 128), (96, 272, 192), (32, 1040, 64)] + BIG_SHAPES)
 def test_dense_tanh_equals_an_fp64_product(gpu, M, K, N):
-    """Every K tail (K % 64 in {0, 16, 32, 48}), ragged tile counts (XCD map on and off), pitched operands; the output unit's
-    partial dot products add up to the GEMV; two launches give the same bits (no atomics, fixed summation order)."""
+    """Every K tail (K % 64 in {0, 16, 32, 48}), ragged tile counts (XCD map on and off), pitched operands, more tiles than compute
+    units (rounds of workgroups, a thin last round as half tiles); the output unit's partial dot products add up to the GEMV;
+    two launches give the same bits (no atomics, fixed summation order)."""
     from pysgmcmc_amd import kernels
     g = torch.Generator(device=gpu).manual_seed(M + K + N)
     hbuf = torch.randn(M, K + 8, device=gpu, generator=g)
@@ -22,7 +28,14 @@ def test_dense_tanh_equals_an_fp64_product(gpu, M, K, N):
     b = torch.randn(N, device=gpu, generator=g) * 0.3
     w_next = torch.randn(N, device=gpu, generator=g)
     out = torch.full((M + 1, N), -7.0, device=gpu)
-    parts = torch.zeros(N // 64, M, device=gpu)
+    n_parts = kernels.bnn_dense_tanh_dot_parts(M, N, gpu)
+    cus = torch.cuda.get_device_properties(gpu).multi_processor_count
+    tiles = (M // 32) * (N // 64)
+    if tiles <= cus or tiles % cus == 0:
+        assert n_parts == N // 64
+    elif (M, N) in ((256, 4864), (64, 8704), (32, 8320)) and cus == 256:
+        assert n_parts > N // 64                                 # the thin last round runs as half tiles
+    parts = torch.zeros(n_parts, M, device=gpu)
     assert kernels.bnn_dense_tanh_fits(h, W, out[:M])
     kernels.bnn_dense_tanh(h, W, b, out[:M], w_next=w_next, dot_parts=parts)
     ref = torch.tanh(h.double() @ W.double() + b.double())
@@ -45,7 +58,7 @@ def test_dense_tanh_refuses_what_it_cannot_take(gpu):
     assert not kernels.bnn_dense_tanh_fits(h[:20], W, out[:20])                    # the reference BNN's batch of 20
     assert not kernels.bnn_dense_tanh_fits(h.double(), W.double(), out.double())   # f32 only
     assert not kernels.bnn_dense_tanh_fits(h[:, :50].contiguous(), W[:50], out)    # K < 64
-    assert not kernels.bnn_dense_tanh_fits(torch.randn(512, 2048, device=gpu), W, torch.empty(512, 2048, device=gpu))   # > one tile per CU
+    assert kernels.bnn_dense_tanh_fits(torch.randn(512, 2048, device=gpu), W, torch.empty(512, 2048, device=gpu))   # more than one tile per CU: rounds
     assert not kernels.bnn_dense_tanh_fits(h[:, 1:65], W[:64], out)                # rows not 16-byte aligned
     with pytest.raises(ValueError, match="bnn_dense_tanh"):
         kernels.bnn_dense_tanh(h[:20], W, torch.randn(2048, device=gpu), out[:20])
@@ -56,7 +69,7 @@ def test_dense_tanh_refuses_what_it_cannot_take(gpu):
 
 
 @pytest.mark.parametrize("M,K,N", [(256, 2048, 2048), (256, 2048, 784 + 48), (32, 64, 64), (64, 80, 128), (96, 272, 192), (32, 1040, 64),
-                                   (160, 64, 320)])
+                                   (160, 64, 320)] + BIG_SHAPES)
 def test_dense_tanh_backward_equals_an_fp64_product(gpu, M, K, N):
     """out = (delta W^T) (1 - act^2) and its column sums per 32-row tile: every K tail, one and several row tiles, XCD map on and
     off, pitched operands. The row tiles are added up -- in order -- by a small launch or by the NEXT backward launch on the
@@ -290,3 +303,36 @@ def test_every_reachable_plan_against_autograd_and_the_oracle(gpu, name, batch, 
     assert abs(c - c_ref) <= 2e-6 * abs(c_ref)
     for g, w in zip(grads, g_ref):
         assert np.allclose(g.cpu().numpy(), w, rtol=3e-4, atol=3e-5 * float(np.abs(w).max()) + 1e-9), name
+
+
+def test_plan_keeps_multi_round_layers_on_the_library_unless_forced(gpu):
+    """configs[4]'s 256 x 4864 layers are 608 tiles on 256 compute units: the fused launches take them (rounds + half tiles,
+    tested above against fp64) but the step is faster on the library's products (profiles/r05_dense_rounds.txt), so the default
+    plan leaves them there; ``fused_layers = "all"`` forces the fused launches, and both give the same cost and gradients to
+    matrix-product rounding."""
+    from pysgmcmc_amd import kernels
+    cus = torch.cuda.get_device_properties(gpu).multi_processor_count
+    wide = 64 * (cus // 8 + 12)                                  # 8 row tiles x (cus / 8 + 12) column tiles > cus
+    res = {}
+    for mode in (True, "all"):
+        cost, params = _cost(gpu, mode, 256, (wide, wide), n_in=64, own_feed_buffer=True)
+        n = sum(p.numel() for p in params)
+        flat = torch.cat([p.reshape(-1) for p in params])
+        offs = np.cumsum([0] + [p.numel() for p in params])
+        params = [flat[offs[k]:offs[k + 1]].view(p.shape) for k, p in enumerate(params)]
+        gflat = torch.full((n,), float("nan"), device=gpu)
+        grads = [gflat[offs[k]:offs[k + 1]].view(p.shape) for k, p in enumerate(params)]
+        st = kernels.StepStats(n, gpu)
+        kernels.sghmc_step(flat.clone(), torch.zeros(n, device=gpu), torch.zeros(n, device=gpu), None, None, None,
+                           torch.ones(n, device=gpu), None, 0.0, 1.0, 0.0, False, xi=torch.zeros(n, device=gpu), stats=st,
+                           opts=dict(theta_sq_only=True))
+        plan = cost.plan_summary(params, grads, st.workspace)
+        if mode is True:
+            assert plan["forward"][:2] == ["mm+bias_tanh", "mm+bias_tanh_rowdot"] and plan["backward"][1] == "mm+tanh_backward", plan
+        else:
+            assert plan["forward"][:2] == ["dense_tanh", "dense_tanh+dot"] and plan["backward"][1] == "dense_tanh_backward", plan
+        c = float(cost.cost_and_grad(params, grads, theta_sumsq_partials=st.workspace))
+        res[mode] = (c, gflat.clone())
+    (c0, g0), (c1, g1) = res[True], res["all"]
+    assert abs(c0 - c1) <= 2e-6 * abs(c0)
+    assert torch.isfinite(g1).all() and float((g0 - g1).abs().max()) <= 3e-5 * float(g0.abs().max()) + 1e-9

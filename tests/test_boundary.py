@@ -35,7 +35,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in _declared_symbols():
         assert hasattr(handle, name), "libsgmcmc_hip.so does not export %s" % name
     lib = _lib.lib()
-    assert lib.sgmcmc_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.sgmcmc_abi_version() == _lib.ABI_VERSION == 5
     assert lib.sgmcmc_summary_workspace_bytes() >= 1024 * 32
     # the per-call launch geometry is validated on the host before anything is launched: checkable without a
     # GPU (the output pointer is a dummy that is never dereferenced because the call fails first)
