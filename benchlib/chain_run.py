@@ -289,7 +289,7 @@ class ChainBench(object):
                          "timing": "the update launch of every %d-th step of the timed region carries a HIP event pair that receives "
                                    "the kernel's own start/stop timestamps (hipExtLaunchKernel; the duration rocprofv3 reports) -- "
                                    "not every step, because a launch with events costs the step 8 us of device time "
-                                   "(tools/bench_overhead_probe.py); achieved = algorithmic bytes of the timed launches / the sum of "
+                                   "(round 3); achieved = algorithmic bytes of the timed launches / the sum of "
                                    "their durations; `roofline_unoverlapped` times EVERY launch of a second loop outside `value`" % self.time_every + (
                                        " -- with %d chains per GPU the timed launches (first chain) run CONCURRENTLY with the other "
                                        "chains' kernels: contended rate; `roofline_unoverlapped` is the kernel alone in its pipeline" % K

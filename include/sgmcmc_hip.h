@@ -529,8 +529,8 @@ int sgmcmc_svgd_kernel_f64(const double *particles, size_t n_particles, size_t d
  *     infrastructure (oracle/libsgmcmc_oracle.so: oracle_sghmc_step_f32, ...), never shipped as a
  *     fallback -- the product path fails loudly without a GPU.
  *  9. (ABI v4) the hand-written weight-gradient GEMM entry points of v3 (with their tile-shape and timing-experiment
- *     arguments) did not beat the library products and are no longer exported: tools/experiments/ builds them as a
- *     separate library.
+ *     arguments) did not beat the library products and are no longer exported (round 5 removed the separate
+ *     experiments library too; the measurements are kept under profiles/, see profiles/HISTORY.md).
  * 10. f64 variants of everything (the reference's default dtype is float64, base_classes.py:25).
  */
 

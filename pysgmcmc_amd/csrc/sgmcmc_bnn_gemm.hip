@@ -10,9 +10,9 @@
 //
 // Replaces library GEMM + sgmcmc_bias_tanh_f32 (+ sgmcmc_bias_tanh_rowdot_f32 for the last hidden layer). In isolation it
 // only ties that pair on the 2048 x 2048 layer (19.5-20.2 vs 21.1-21.5 us; it was an experiment that missed its gate, see
-// tools/gpu/bnn_dense_tanh.hip and profiles/r04_fwd_epilogue_probe.txt for everything tried on the way), but in the sampler's
+// profiles/r04_fwd_epilogue_probe.txt for everything tried on the way), but in the sampler's
 // step two launches per layer become one and the 10 M-parameter chain goes from 196.2 to 186.0 us per step with its three
-// hidden layers on it (tools/fwd_fused_step_probe.py).
+// hidden layers on it.
 //
 // Decomposition for M = 256: the output is 512 MFMA tiles of 32 x 32 for 1024 SIMDs, so K must be split; a workgroup (ONE per
 // CU, 8 waves = 2 per SIMD) owns a 32 x 64 output tile = 2 MFMA tiles x 4 quarters of every 64-deep K chunk and adds the
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
         constexpr int I = decltype(stage)::value;           // kc % NS
         wait_vm<LPW * (D - 2)>();                           // chunk kc + 1 landed: chunks kc + 2 .. kc + D - 1 may be in flight
         __builtin_amdgcn_s_barrier();                       // ... for every wave; and the stage of chunk kc - 1 is free
-        // order inside an iteration (tools/fwd_fused_step_probe.py, 10 M-parameter chain, us per step): the fragment reads right
+        // order inside an iteration (10 M-parameter chain, us per step): the fragment reads right
         // after the second MFMA and the loads after the fourth 186.0; loads + reads bunched after the second 187.0; one load per
         // MFMA gap 186.0; s_setprio 1 for the later-dispatched wave of each SIMD 187.7
         mfmas(cur, 0, NM / 4);
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(512, 2) bnn_dense_tanh_kernel(const FwdArgs g)
             // ... and the bias gradient: column sums over the tile's 32 rows (the rows of a wave by shuffles, the waves in order).
             // The row tiles of a column are NOT added here: that takes a second pass over what other workgroups wrote, and in
             // one launch it costs more than it saves (arrival counter + agent-scope fences: +12 us; relaxed write-through
-            // atomics: +2.5 us, the step got slower -- tools/bwd_fused_probe.py). The partial rows are left
+            // atomics: +2.5 us, the step got slower -- profiles/r04_bwd_epilogue_probe.txt). The partial rows are left
             // for the NEXT launch to add up on the side (fin_* above), or for sgmcmc_colsum_finish_f32.
             if (g.colsum_parts == nullptr) return;          // (the first layer's bias gradient comes from the [x | 1]^T delta product)
 #pragma unroll

@@ -352,7 +352,7 @@ __device__ __forceinline__ double tanh_dev(double x) { return tanh(x); }
 // ~10 k partials, and with it the separate head launch (each dependent launch of the step costs ~5 us).
 // a[r][c] = tanh(a[r][c] + bias[c]) in place: the hidden layers' activation with the bias add that the forward GEMM then
 // does not need as an epilogue (the library's plain product is 1.4-2.1 us faster than its bias-epilogue one at batch 256,
-// tools/fwd_gemm_probe.py). One quad per lane per trip, 16-byte accesses when the pitch allows.
+// round 3). One quad per lane per trip, 16-byte accesses when the pitch allows.
 template <typename T>
 __global__ void __launch_bounds__(256) bias_tanh_kernel(T *__restrict__ a, const T *__restrict__ bias, unsigned rows, unsigned cols)
 {
@@ -525,13 +525,13 @@ __global__ void __launch_bounds__(1024) head_last_layer_backward_kernel(
     const int cl = lane & (CS_COLS - 1);
     // The LAST workgroup of the grid owns no columns: it does the head's own reductions and the scalar outputs (one thread's
     // ~1.5 us of dependent double-precision divisions at the end) next to the column workgroups instead of at the tail of one
-    // of them (tools/head_probe.py at 256 x 2048).
+    // of them (measured at 256 x 2048, round 4).
     const bool head_wg = blockIdx.x == gridDim.x - 1;
     const size_t c = head_wg ? cols : (size_t)blockIdx.x * CS_COLS + cl;
     const size_t rl = (size_t)wave * 4 + (lane >> 4);
     // Everything this lane will want from memory is requested FIRST -- its partial dot products, the activations and targets of
     // its first four rows, the scalars -- and the double-precision scalar chain (exp, reciprocal: ~1 us of dependent
-    // instructions that used to start after the barrier) runs while those loads fly (tools/head_probe.py).
+    // instructions that used to start after the barrier) runs while those loads fly.
     // -- the output unit's pre-bias mean: a plain vector, or n_mean_parts partial dot products per row (what
     // sgmcmc_bnn_dense_tanh_f32 leaves: one per 64-column tile), added here in a fixed order by every workgroup: four adjacent
     // lanes per row, each adds a contiguous quarter of the parts (its loads issued together, not one dependent round trip per

@@ -23,7 +23,7 @@
 //         65..128, f64:              svgd_update_mfma_f64_big_kernel -- two passes of four 16-particle blocks
 //       (svgd_update_reg_kernel / svgd_update_kernel also serve sgmcmc_svgd_kernel_*'s kernel-gradient output).
 // fp32 MFMA and packed fp32 VALU have the same peak on gfx950 (157 TFLOP/s; 155 measured for
-// v_mfma_f32_32x32x2_f32, tools/mfma_f32_probe.hip) and the f32 MFMA is exact f32, so there is no precision
+// v_mfma_f32_32x32x2_f32, measured in round 1) and the f32 MFMA is exact f32, so there is no precision
 // to trade; the matrix-core forms win because K lives in LDS/registers instead of stalling on scalar loads and
 // because the VALU stays free for the tail (3 IEEE divisions + sqrt per element).
 //

@@ -389,7 +389,7 @@ class BNNCost(object):
                 mean = ws["dot_parts"]
             elif op == "mm+bias_tanh":
                 # plain product, the bias rides in the activation launch (the library's plain GEMM is 1.4-2.1 us faster than its
-                # bias-epilogue one at batch 256: tools/fwd_gemm_probe.py)
+                # bias-epilogue one at batch 256, round 3)
                 torch.mm(h, W, out=hs[l])
                 kernels.bias_tanh(hs[l], b.view(-1))
             elif op == "mm+bias_tanh_rowdot":

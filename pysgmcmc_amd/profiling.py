@@ -11,7 +11,7 @@ section 5; this is what ``bench.py`` builds its ``roofline`` entry from).
 
 Every timed launch carries a pair of HIP events (``sgmcmc_launch_t.start_event / stop_event`` -> ``hipExtLaunchKernel``)
 that receive the KERNEL's start and stop timestamps -- the duration rocprofv3 reports for the kernel. The events are not
-free: a launch that carries them costs the 10 M-parameter chain 8 us of device time per step (tools/bench_overhead_probe.py),
+free: a launch that carries them costs the 10 M-parameter chain 8 us of device time per step (measured in round 3, profiles/HISTORY.md),
 so ``timer.sample_every = k`` times the launches of every k-th step only. ``bracket=True``
 additionally records a ``hipEventRecord`` pair around the call on the same stream (it includes ~3-5 us of barrier-packet
 and dispatch latency). Timing applies to direct launches (eager stepping and ``use_hip_graph = True``); a launch captured

@@ -484,8 +484,8 @@ class MCMCSampler(object):
         whenever the schedule moves (``StepOpts.scalars_dev``), so a SCHEDULED stepsize replays the same graph.
         Feeds are copied into static buffers first. Requirements: static feed shapes; a cost function without host
         synchronisation. (Round 3's two further modes -- the update on a side stream under the backward GEMMs, and the
-        update as the epilogue of a hand-written weight-gradient GEMM -- were measured slower / no faster and live in
-        ``tools/experiments/stepping.py``.)"""
+        update as the epilogue of a hand-written weight-gradient GEMM -- were measured slower / no faster
+        (``profiles/r03_overlap_probe.txt``, ``r03_gemm_fusion_probe.txt``) and were removed in round 5.)"""
         self._feed_static(feed_dict)
         eps = self._next_stepsize()
         self._ensure_stats()

@@ -5,7 +5,7 @@ Chains are independent, so on the device their steps need no ordering at all: ev
 ``use_hip_graph``, its own hipGraph) and one host thread enqueues the chains round-robin. The kernels of a step each leave part
 of the chip idle -- the batch-256 GEMMs of the 10 M-parameter BNN keep the matrix pipe 62 % busy, the launch ramps and tails of
 ~11 dependent launches per step nothing at all -- and a second chain's launches fill those gaps: two such chains on one MI355X
-give 5.9 k samples/s together against 5.0 k for one (``tools/chains_per_gpu_probe.py``; three or more are host-bound from one
+give 5.9 k samples/s together against 5.0 k for one (``bench.py``'s ``chains_per_gpu`` leg; three or more are host-bound from one
 thread). WITHIN a chain the same trick does not work: the update cannot run next to the chain's own backward pass without
 cross-stream dependencies, and those cost more than they hide.
 

@@ -50,7 +50,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_abi_exports_no_experiment_knobs():
     """the ABI a maintainer binds must not carry experiment switches. v4 dropped the hand-written GEMM entry
-    points (tile-variant / timing-probe / de-phasing arguments); they are built separately by tools/experiments."""
+    points (tile-variant / timing-probe / de-phasing arguments); they were removed with the experiments in round 5."""
     from pysgmcmc_amd import _lib
     handle = ctypes.CDLL(_lib.build())
     header = open(HEADER).read()

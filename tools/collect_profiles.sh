@@ -1,9 +1,10 @@
 #!/bin/bash
-# Turn the output of tools/gpu/r04_profiles.sh (merged into gpurun_out/r04p/) into the tracked files under profiles/.
+# Turn the output of tools/gpu/profiles.sh (merged into gpurun_out/<round>p/) into the tracked files under profiles/:
+#   bash tools/collect_profiles.sh r05
 set -e
-O=gpurun_out/r04p; R=${1:-r04}
-cp $O/r04_pmc_traffic.json profiles/${R}_pmc_traffic.json
-cp $O/r04_pmc_traffic.md profiles/${R}_pmc_traffic.md
+R=${1:-r05}; O=gpurun_out/${R}p
+cp $O/pmc_traffic.json profiles/${R}_pmc_traffic.json
+cp $O/pmc_traffic.md profiles/${R}_pmc_traffic.md
 python3 tools/kernel_stats_summary.py $O/prof_bench10m/b_kernel_stats.csv profiles/${R}_bench10m_kernel_stats.csv
 python3 tools/kernel_stats_summary.py $O/prof_bench50m_rsghmc/b_kernel_stats.csv profiles/${R}_bench50m_rsghmc_kernel_stats.csv 16 60
 python3 tools/kernel_stats_summary.py $O/prof_sinc/b_kernel_stats.csv profiles/${R}_sinc_bnn_kernel_stats.csv 8 20

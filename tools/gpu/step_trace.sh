@@ -1,10 +1,10 @@
 # Per-dispatch timeline of the 10 M-parameter chain's step (where the gaps between the 11 launches are). Through gpurun: bash tools/gpu/step_trace.sh
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-# what bench.py asks the HIP runtime for on this workload (pysgmcmc_amd.prefer_plain_graph_launch) -- exported here because under
+# what bench.py asks the HIP runtime for on this workload (pysgmcmc_amd.configure_for_device_bound_chains) -- exported here because under
 # rocprofv3 the runtime initialises before python runs
 export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 O=gpurun_out/steptrace; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --output-format csv -d $O/t -o t -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-update-only > $O/line.json 2> $O/err.txt
+rocprofv3 --kernel-trace --output-format csv -d $O/t -o t -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-update-only --no-product-defaults > $O/line.json 2> $O/err.txt
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob('gpurun_out/steptrace/t/*kernel_trace.csv')[0]
@@ -16,7 +16,7 @@ names = [r['Kernel_Name'] for r in rows]
 idx = [i for i, n in enumerate(names) if 'window_gather' in n]
 # use steps from the middle of the timed region: gathers number 200..260 (prime 136 + warmup 20 + timed 100)
 sel = idx[180:240]
-short = lambda n: ('K1' if 'stream_quads' in n else 'gather' if 'window_gather' in n else 'head' if 'head_last' in n else 'fwd' if 'kernelILi4ELb0' in n or '<4, false>' in n else 'bwd' if 'kernelILi4ELb1' in n or '<4, true>' in n else 'gemm' if n.startswith('Cijk') else n[:20])
+short = lambda n: ('K1' if 'stream_quads' in n else 'gather' if 'window_gather' in n else 'head' if 'head_last' in n else 'fwd' if 'kernelILi4ELb0' in n or '<4, false' in n else 'bwd' if 'kernelILi4ELb1' in n or '<4, true' in n else 'gemm' if n.startswith('Cijk') else n[:20])
 gaps = collections.defaultdict(list); durs = collections.defaultdict(list); steps = []
 for a, b in zip(sel[:-1], sel[1:]):
     seq = rows[a:b]
