@@ -1,4 +1,5 @@
 """Constants and small helpers shared by the legs of ``bench.py``."""
+import glob
 import hashlib
 import json
 import os
@@ -8,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:35
 # algorithmic bytes per parameter per launch, fp32
 BYTES_PER_PARAM = {"sghmc_frozen": 24, "sghmc_adapt": 48, "sgld_frozen": 16, "sgld_adapt": 40, "rsghmc": 20}
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+PMC_TRAFFIC_GLOB = os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")    # the newest table collected with THIS build's kernel sources is used
 FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix-core peak, /opt/skills/guides/MI355X_MICROARCH.md
 PRIME_BURN_IN = 8              # adapting steps of the chain, run in the prime phase (never timed)
 PRIME_FROZEN = 4               # frozen steps of the prime phase with a moments update + trace append each
@@ -42,18 +43,21 @@ def pmc_traffic(mode, n, variant=""):
     known byte counts) -- but ONLY if that table was collected with the kernel sources this run uses (source hash
     recorded in the file); a stale table yields None rather than an old byte count next to fresh timings. Returns
     (bytes per launch or None, source string)."""
-    name = os.path.relpath(PMC_TRAFFIC_FILE, ROOT)
-    try:
-        with open(PMC_TRAFFIC_FILE) as fh:
-            doc = json.load(fh)
-        have, want = doc.get("kernel_source_hash"), kernel_source_hash()
-        if have != want:
-            return None, "%s was collected with kernel sources %s, this build is %s: traffic not reported" % (name, have, want)
-        sizes = doc["sizes"][str(n)]
-        entry = sizes[mode + variant]         # "" plain, "_stats" every statistic, "_tsq" sum theta^2 only, "_tsq_mom" + fused moments
-        return int(round(entry["bytes_per_param"] * n)), "%s (%s, kernel sources %s)" % (name, doc.get("collected", "?"), have)
-    except (OSError, KeyError, ValueError):
-        return None, "no PMC pass for n=%d in %s" % (n, name)
+    want, stale = kernel_source_hash(), None
+    for path in sorted(glob.glob(PMC_TRAFFIC_GLOB), reverse=True):        # newest round first
+        name = os.path.relpath(path, ROOT)
+        try:
+            with open(path) as fh:
+                doc = json.load(fh)
+            have = doc.get("kernel_source_hash")
+            if have != want:
+                stale = stale or "%s was collected with kernel sources %s, this build is %s: traffic not reported" % (name, have, want)
+                continue
+            entry = doc["sizes"][str(n)][mode + variant]   # "" plain, "_stats" every statistic, "_tsq" sum theta^2 only, "_tsq_mom" + fused moments
+            return int(round(entry["bytes_per_param"] * n)), "%s (%s, kernel sources %s)" % (name, doc.get("collected", "?"), have)
+        except (OSError, KeyError, ValueError):
+            stale = stale or "no PMC pass for n=%d in %s" % (n, name)
+    return None, stale or "no PMC traffic table under profiles/"
 
 
 def usable_cores():

@@ -10,7 +10,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/probe_${N}_stats -o s
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_${N}_fetch -o f -- python3 tools/pmc_probe.py $N 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${N}_write -o w -- python3 tools/pmc_probe.py $N 3 > /dev/null 2>&1
 done
-PMC_KERNEL_SOURCE_HASH=$(cat $O/kernel_source_hash.txt) python3 tools/pmc_traffic.py $O/pmc_traffic $O/pmc_10002434 $O/pmc_49826818 > $O/pmc_traffic.log 2>&1
+PMC_KERNEL_SOURCE_HASH=$(cat $O/kernel_source_hash.txt) python3 tools/pmc_traffic.py profiles/${R}_pmc_traffic $O/pmc_10002434 $O/pmc_49826818 > $O/pmc_traffic.log 2>&1
+cp profiles/${R}_pmc_traffic.json $O/pmc_traffic.json; cp profiles/${R}_pmc_traffic.md $O/pmc_traffic.md
 # (2) the driver's command, twice, the long forms, configs[4]'s and configs[1]'s workloads
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd_a.json 2> $O/bench.err
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd_b.json 2>> $O/bench.err
