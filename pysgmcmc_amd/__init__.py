@@ -19,7 +19,7 @@ def prefer_plain_graph_launch():
     """Ask the HIP runtime for its plain hipGraph launch path instead of the pre-recorded AQL packets ("packet capture", the default
     in ROCm 7): ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0``. For chains whose step is DEVICE-bound -- the hipGraph stepping modes of
     ``samplers/base_classes.py`` on models of millions of parameters -- it takes 3.5 us of idle device time off every graph launch on
-    MI355X (10 M parameters: 181.0 -> 177.5 us per step; 49.8 M: 778 -> 759). It costs host time per launch
+    MI355X (10 M parameters: 181.0 -> 177.5 us per step; 49.8 M: 778 -> 759; profiles/HISTORY.md). It costs host time per launch
     (45 -> 65-87 us per step there), so chains whose step is HOST-bound lose: the 3 x 50 BNN of BASELINE configs[1] replays its
     graph at 9.2 k instead of 14.9 k steps/s. Hence a call, not a default. The runtime reads the variable when it initialises (its
     first HIP call, not ``import torch``): call this before anything touches the GPU. Returns False when that is already too late."""

@@ -7,7 +7,7 @@ of the chip idle -- the batch-256 GEMMs of the 10 M-parameter BNN keep the matri
 ~11 dependent launches per step nothing at all -- and a second chain's launches fill those gaps: two such chains on one MI355X
 give 5.9 k samples/s together against 5.0 k for one (``bench.py``'s ``chains_per_gpu`` leg; three or more are host-bound from one
 thread). WITHIN a chain the same trick does not work: the update cannot run next to the chain's own backward pass without
-cross-stream dependencies, and those cost more than they hide.
+cross-stream dependencies, and those cost more than they hide (profiles/HISTORY.md, round 3).
 
     chains = ConcurrentChains([make_sampler(seed=k) for k in range(2)])
     for step_results in itertools.islice(chains, 1000):     # [(sample, cost) of chain 0, (sample, cost) of chain 1]
