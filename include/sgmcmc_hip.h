@@ -62,8 +62,9 @@ int sgmcmc_device_count(void);
  *                than 640 MiB (HBM-resident working set), else 256
  *   quads_per_thread: 1, 2 or 4 float4 groups in flight per lane (default 1)
  *   max_blocks: grid cap, the kernel grid-strides beyond it (default 2^20 = uncapped)
- *   nontemporal: 0 plain, 1 nt loads+stores, 2 auto = nt iff one launch touches more
- *                than 640 MiB, i.e. cannot live in the 256 MiB Infinity Cache (default 2)      */
+ *   nontemporal: 0 plain, 1 nt loads+stores, 2 auto = nt iff one f32 launch touches more
+ *                than 640 MiB, i.e. cannot live in the 256 MiB Infinity Cache; f64 launches
+ *                stay plain (measured faster at every size) (default 2)                       */
 typedef struct sgmcmc_launch {
     int block_threads;
     int quads_per_thread;

@@ -362,7 +362,10 @@ int launch(const Op &op, size_t n, bool vec_ok, size_t bytes_per_elem, const sgm
     // measured (profiles/r01_block_sweep.txt): 128-lane blocks +7 % at 50 M params (HBM-resident), 256 +2 % at 10 M
     cfg.bt = cfg.block_threads > 0 ? cfg.block_threads : (big ? 128 : 256);
     if (!vec_ok) return launch_scalar<Op>(op, n, cfg, se, st);
-    const bool nt = cfg.nt == 2 ? big : (cfg.nt != 0);
+    // auto (2): nt for f32 launches that cannot stay in the Infinity Cache. f64 launches never: with 32 B per lane per array plain
+    // accesses win at every size (49.8 M parameters: K1 frozen 412.8 vs 439.0 us, K1 burn-in 796 vs 870, K2 283 vs 295, K3 376 vs 385;
+    // profiles/r05_tune_50m_f64.txt)
+    const bool nt = cfg.nt == 2 ? (big && sizeof(typename Op::real) == 4) : (cfg.nt != 0);
     if (sizeof(typename Op::real) == 8) {
         return nt ? launch_vec<Op, 1, true, FAST_VARIANTS>(op, n, cfg, se, moments_done, st)
                   : launch_vec<Op, 1, false, FAST_VARIANTS>(op, n, cfg, se, moments_done, st);
