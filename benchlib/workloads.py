@@ -34,8 +34,9 @@ def build_chain(dev, rank, workload="bnn10m-sghmc", burn_in=8):
     yp = Placeholder(dtype=torch.float32, device=dev, name="Y_Minibatch")
     params = init_mlp_params(layers[0], hidden=layers[1:], seed=1000 + rank, dtype=torch.float32, device=dev)
     cost = BNNCost(xp, yp, batch_size=BATCH, n_examples=N_DATA)
-    if os.environ.get("BENCH_FUSED_LAYERS") == "library":      # profiling aid (tools/gpu/r05_prof50m.sh): hidden layers on library products
-        cost.fused_layers = False
+    # profiling aid (tools/gpu/r05_prof50m.sh): hidden layers on library products / on the fused launches whatever their tile count
+    if os.environ.get("BENCH_FUSED_LAYERS") in ("library", "all"):
+        cost.fused_layers = False if os.environ["BENCH_FUSED_LAYERS"] == "library" else "all"
     common = dict(params=params, cost_fun=cost,
                   batch_generator=generate_batches(X, y, xp, yp, batch_size=BATCH, seed=rank),
                   session=dev, dtype=torch.float32, seed=1234 + rank)

@@ -22,10 +22,17 @@ def prefer_plain_graph_launch():
     MI355X (10 M parameters: 181.0 -> 177.5 us per step; 49.8 M: 778 -> 759; profiles/HISTORY.md). It costs host time per launch
     (45 -> 65-87 us per step there), so chains whose step is HOST-bound lose: the 3 x 50 BNN of BASELINE configs[1] replays its
     graph at 9.2 k instead of 14.9 k steps/s. Hence a call, not a default. The runtime reads the variable when it initialises (its
-    first HIP call, not ``import torch``): call this before anything touches the GPU. Returns False when that is already too late."""
+    first HIP call, not ``import torch``): call this before anything touches the GPU. Returns False when that is already too late (HIP initialised, or a
+    profiler's tool library preloaded -- unless the variable was already exported by the caller's environment)."""
     import torch
+    already = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
     _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
-    return not torch.cuda.is_initialized()
+    if already:
+        return True               # whoever started the process exported it: the runtime sees it whenever it initialises
+    # a profiler's preloaded tool library (rocprofv3) initialises the HIP runtime before Python runs: too late, export it outside
+    preloaded = ("rocprof" in _os.environ.get("LD_PRELOAD", "") or "ROCP_TOOL_LIBRARIES" in _os.environ
+                 or "HSA_TOOLS_LIB" in _os.environ)
+    return not torch.cuda.is_initialized() and not preloaded
 
 
 def configure_for_device_bound_chains(gemm_tuning=True, plain_graph_launch=True, tuning_ms=30, tuning_iters=20):

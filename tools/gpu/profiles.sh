@@ -27,8 +27,8 @@ python3 bench.py --gpus 8 --steps 20 --warmup 5 --backend gloo --all-ranks-on-gp
 # (3) kernel-trace stats of the bench commands (program directly after --). Under rocprofv3 the HIP runtime initialises before python
 # runs, so what pysgmcmc_amd.configure_for_device_bound_chains() asks of it is exported here
 export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench10m -o b -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-product-defaults > $O/prof_bench10m.json 2> $O/prof_bench10m.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench50m_rsghmc -o b -- python3 bench.py --workload bnn50m-rsghmc --steps 100 --warmup 10 --no-cpu-baseline --no-product-defaults > $O/prof_bench50m_rsghmc.json 2> $O/prof_bench50m_rsghmc.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench10m -o b -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-only --no-product-defaults > $O/prof_bench10m.json 2> $O/prof_bench10m.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench50m_rsghmc -o b -- python3 bench.py --workload bnn50m-rsghmc --steps 100 --warmup 10 --no-cpu-baseline --no-update-only --no-product-defaults > $O/prof_bench50m_rsghmc.json 2> $O/prof_bench50m_rsghmc.err
 unset DEBUG_CLR_GRAPH_PACKET_CAPTURE
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sinc -o b -- python3 bench.py --workload sinc-bnn --steps 3000 --warmup 100 --no-cpu-baseline > $O/prof_sinc.json 2> $O/prof_sinc.err
 # keep only the small summaries (the per-dispatch traces are MBs)

@@ -3,7 +3,7 @@
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 O=gpurun_out/prof50m; rm -rf $O; mkdir -p $O
-for mode in fused library; do
+for mode in all library; do
   BENCH_FUSED_LAYERS=$mode rocprofv3 --kernel-trace --stats --output-format csv -d $O/$mode -o s -- python3 bench.py --workload bnn50m-sgld --steps 100 --warmup 10 --no-update-only --no-cpu-baseline --no-product-defaults > $O/$mode.json 2> $O/$mode.err
   echo "== $mode"; python3 -c "
 import json,sys; d=json.load(open('$O/$mode.json')); print(d['value'], d['ms_per_step'])"
