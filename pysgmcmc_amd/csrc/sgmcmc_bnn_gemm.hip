@@ -32,6 +32,11 @@
 //   * two accumulators per wave (alternating MFMAs, added in the epilogue): consecutive MFMAs are independent.
 // Workgroup -> tile map is XCD-aware (workgroup b runs on XCD b % 8): every XCD owns a contiguous range of column tiles, so
 // each slice of W is pulled into exactly one XCD's L2.
+// More tiles than compute units (round 5): the grid simply runs in rounds of workgroups; when the last round would be less than
+// half full, its columns are cut into 32 x 32 HALF tiles (template parameter BN = 32: 8 waves = 1 MFMA tile x 8 K parts, a second
+// launch on the same stream, see plan_columns()) -- 256 x 4864 outputs = 608 tiles run as 2 rounds + 192 half tiles on 256 CUs.
+// Correct (tests/test_bnn_dense_gpu.py) but at that shape slower in the step than the library's stream-K product + activation
+// launch (profiles/r05_dense_rounds.txt), so BNNCost's plan fuses a layer only while its launch is ONE round.
 //
 // fp32 MFMA is an exact fmaf chain (MI355X_MICROARCH.md): the product differs from a library GEMM in summation order only.
 #include <hip/hip_runtime.h>
