@@ -149,3 +149,16 @@ def test_device_bound_switch_reports_what_took_effect(monkeypatch):
         if torch.cuda.is_available():
             from pysgmcmc_amd.models.bayesian_neural_network import enable_gemm_tuning
             enable_gemm_tuning(False)
+
+
+def test_dense_layer_column_plan_without_a_device():
+    """``sgmcmc_bnn_dense_tanh_dot_parts`` is host arithmetic (which columns of an M x N layer run as 32 x 64 tiles and which as
+    half tiles): without a device it assumes 256 compute units, MI355X's count."""
+    from pysgmcmc_amd import _lib
+    lib = _lib.lib()
+    parts = lib.sgmcmc_bnn_dense_tanh_dot_parts
+    assert parts(256, 2048) == 32                                # one tile per CU: 32 column tiles of 64
+    assert parts(512, 2048) == 32                                # two full rounds
+    assert parts(256, 4864) == 64 + 24                           # configs[4]: 512 full tiles + the last 12 column tiles as 24 half tiles
+    assert parts(256, 4096 + 64 * 20) == (4096 + 64 * 20) // 64  # a last round more than half full stays on full tiles
+    assert parts(20, 2048) == 0 and parts(256, 100) == 0         # shapes the launch refuses
