@@ -188,7 +188,12 @@ def gemm_only_us(sampler, iters=60):
                 else:
                     torch.mm(ds[l], params[2 * l].t(), out=ds[l - 1])
                 flops += 2 * ds[l].shape[0] * ds[l].shape[1] * params[2 * l].shape[0]
-            if l == 0 and plan.ones_row:
+            if plan.gw_batch is not None and plan.gw_batch[0] <= l <= plan.gw_batch[1]:
+                lo, hi, s_h, s_d, s_g, _ = plan.gw_batch
+                if l == lo:                                    # the group's weight gradients as ONE strided batched product
+                    stack = lambda t, st: torch.as_strided(t, (hi - lo + 1,) + tuple(t.shape), (st,) + tuple(t.stride()))
+                    torch.bmm(stack(hs[lo - 1], s_h).transpose(1, 2), stack(ds[lo], s_d), out=stack(gv[2 * lo], s_g))
+            elif l == 0 and plan.ones_row:
                 d_in, width = int(X.shape[1]), int(params[0].shape[1])
                 torch.mm(plan.x_ones.t(), ds[0], out=torch.as_strided(gv[0], (d_in + 1, width), (width, 1)))
             else:

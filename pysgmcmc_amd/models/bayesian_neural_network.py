@@ -152,15 +152,18 @@ def weight_prior_log_like(parameters, wdecay=1.0, dtype=torch.float64):
 
 class _CostPlan(object):
     """The launch sequence one configuration of the MLP cost path runs (built by ``BNNCost._plan``, walked by every step)."""
-    __slots__ = ("forward", "head", "backward", "ones_row", "x_ones", "single_out")
+    __slots__ = ("forward", "head", "backward", "ones_row", "x_ones", "single_out", "gw_batch")
 
-    def __init__(self, forward, head, backward, ones_row, x_ones, single_out):
+    def __init__(self, forward, head, backward, ones_row, x_ones, single_out, gw_batch=None):
         self.forward, self.head, self.backward = tuple(forward), head, dict(backward)
-        self.ones_row, self.x_ones, self.single_out = ones_row, x_ones, single_out
+        self.ones_row, self.x_ones, self.single_out, self.gw_batch = ones_row, x_ones, single_out, gw_batch
 
     def as_dict(self):
-        return {"forward": list(self.forward), "head": self.head, "backward": dict(self.backward),
-                "first_layer_bias_gradient": "from the [x | 1]^T delta product" if self.ones_row else "column sums"}
+        d = {"forward": list(self.forward), "head": self.head, "backward": dict(self.backward),
+             "first_layer_bias_gradient": "from the [x | 1]^T delta product" if self.ones_row else "column sums"}
+        if self.gw_batch is not None:
+            d["weight_gradients_in_one_batched_product"] = list(range(self.gw_batch[0], self.gw_batch[1] + 1))
+        return d
 
 
 class BNNCost(object):
@@ -260,8 +263,20 @@ class BNNCost(object):
         ws = self._ws.get(key)
         if ws is None:
             dt, dev = params[0].dtype, params[0].device
-            mk = lambda w: torch.empty(B, w, dtype=dt, device=dev)
-            ws = {"h": [mk(w) for w in widths], "d": [mk(w) for w in widths],
+
+            def rows_of(widths):
+                # layers of equal width share ONE block [layers][B][w] (their weight-gradient products can then run as one strided
+                # batched product, see _plan); others get their own buffer
+                out, i = [], 0
+                while i < len(widths):
+                    j = i
+                    while j + 1 < len(widths) and widths[j + 1] == widths[i]:
+                        j += 1
+                    block = torch.empty(j - i + 1, B, widths[i], dtype=dt, device=dev)
+                    out.extend(block[k] for k in range(j - i + 1))
+                    i = j + 1
+                return out
+            ws = {"h": rows_of(widths), "d": rows_of(widths),
                   "ones": torch.ones(B, dtype=dt, device=dev),
                   # per-column-tile partial dot products of the last hidden layer with the output unit's weights (bnn_dense_tanh)
                   "dot_parts": None,
@@ -358,8 +373,31 @@ class BNNCost(object):
         if "dense_tanh_backward" in backward.values() and "colsum_parts" not in ws:
             widest = max(int(p.shape[0]) for p in params[0:-1:2])
             ws["colsum_parts"] = [torch.zeros((B // 32) * widest, dtype=X.dtype, device=X.device) for _ in range(2)]
+        # weight gradients of consecutive hidden layers of one shape as ONE strided batched product (2 x [2048 x 2048 x 256]: 34.9 us
+        # against 41.5 for two products in a row): layers lo .. hi whose inputs h_{l-1}, deltas, gradient slices (and, with the prior
+        # in the product, weights) lie at one constant stride each
+        gw_batch = None
+
+        def stride_of(ts):
+            """Elements between consecutive tensors of ``ts`` if they are contiguous, equally spaced views of ONE allocation, else None."""
+            base = ts[0].untyped_storage().data_ptr()
+            if not all(t.is_contiguous() and t.untyped_storage().data_ptr() == base for t in ts):
+                return None                                       # (one strided view must be able to span them: one allocation)
+            gaps = {ts[k + 1].data_ptr() - ts[k].data_ptr() for k in range(len(ts) - 1)}
+            gap = gaps.pop() if len(gaps) == 1 else 0
+            return gap // ts[0].element_size() if gap > 0 and gap % ts[0].element_size() == 0 else None
+        hi = L - 1 if single_out else L
+        for lo in range(1, hi):
+            run = range(lo, hi + 1)
+            if not all(params[2 * l].shape == params[2 * lo].shape and hs[l - 1].shape == hs[lo - 1].shape for l in run):
+                continue
+            strides = [stride_of([hs[l - 1] for l in run]), stride_of([ds[l] for l in run]), stride_of([grad_views[2 * l] for l in run]),
+                       0 if self.fold_prior else stride_of([params[2 * l] for l in run])]
+            if None not in strides and hs[0].is_cuda:
+                gw_batch = (lo, hi) + tuple(strides)
+                break
         plan = _CostPlan(forward, "head+last_layer_backward" if fused_head else "head", backward, bool(ones_row),
-                         ext[:, :D_in + 1] if ones_row else None, single_out)
+                         ext[:, :D_in + 1] if ones_row else None, single_out, gw_batch)
         self._plans[key] = plan
         return plan
 
@@ -463,7 +501,17 @@ class BNNCost(object):
             elif op is not None:
                 torch.mm(ds[l], W.t(), out=ds[l - 1])
             # weight gradient
-            if l == 0 and plan.ones_row:
+            if plan.gw_batch is not None and plan.gw_batch[0] <= l <= plan.gw_batch[1]:
+                lo, hi, s_h, s_d, s_g, s_w = plan.gw_batch
+                if l == lo:                                       # the last delta of the group exists now: ONE strided batched product
+                    n = hi - lo + 1
+                    stack = lambda t, st: torch.as_strided(t, (n,) + tuple(t.shape), (st,) + tuple(t.stride()))
+                    A, D, G = stack(hs[lo - 1], s_h).transpose(1, 2), stack(ds[lo], s_d), stack(grad_views[2 * lo], s_g)
+                    if self.fold_prior:
+                        torch.bmm(A, D, out=G)
+                    else:
+                        torch.baddbmm(stack(W, s_w), A, D, beta=prior_coef, alpha=1.0, out=G)
+            elif l == 0 and plan.ones_row:
                 # [x | 1]^T delta = [gW_0 ; gb_0] onto the arena's [W_0 ; b_0] slice: 785 rows cost the library what 784 do
                 rows, width = int(X.shape[1]) + 1, int(W.shape[1])
                 gWb = torch.as_strided(grad_views[0], (rows, width), (width, 1))

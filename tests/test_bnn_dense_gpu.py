@@ -241,12 +241,12 @@ def test_chain_with_fused_dense_layers_tracks_the_library_chain(gpu):
     ("all fused", 256, 64, (128, 128, 128), True,
      {"forward": ["dense_tanh", "dense_tanh", "dense_tanh+dot", "by rowdot"], "head": "head+last_layer_backward",
       "backward": {3: "in head launch", 2: "dense_tanh_backward", 1: "dense_tanh_backward"},
-      "first_layer_bias_gradient": "from the [x | 1]^T delta product"}),
+      "first_layer_bias_gradient": "from the [x | 1]^T delta product", "weight_gradients_in_one_batched_product": [1, 2]}),
     # the reference's own net (3 x 50, batch 20): nothing fits, library products + the small launches
     ("library only", 20, 1, (50, 50, 50), True,
      {"forward": ["mm+bias_tanh", "mm+bias_tanh", "mm+bias_tanh_rowdot", "by rowdot"], "head": "head+last_layer_backward",
       "backward": {3: "in head launch", 2: "mm+tanh_backward_colsum", 1: "mm+tanh_backward_colsum"},
-      "first_layer_bias_gradient": "column sums"}),
+      "first_layer_bias_gradient": "column sums", "weight_gradients_in_one_batched_product": [1, 2]}),
     # mixed by shape: the 80-wide layer stays on the library, its neighbours are fused
     ("mixed by shape", 256, 64, (128, 80, 128), True,
      {"forward": ["dense_tanh", "mm+bias_tanh", "dense_tanh+dot", "by rowdot"], "head": "head+last_layer_backward",
@@ -256,11 +256,12 @@ def test_chain_with_fused_dense_layers_tracks_the_library_chain(gpu):
     ("no partials", 256, 64, (128, 128, 128), False,
      {"forward": ["dense_tanh", "dense_tanh", "mm+bias_tanh_rowdot", "by rowdot"], "head": "head",
       "backward": {3: "last_layer_backward", 2: "dense_tanh_backward", 1: "dense_tanh_backward"},
-      "first_layer_bias_gradient": "from the [x | 1]^T delta product"}),
+      "first_layer_bias_gradient": "from the [x | 1]^T delta product", "weight_gradients_in_one_batched_product": [1, 2]}),
 ])
 @pytest.mark.parametrize("fold_prior", [True, False])
 def test_every_reachable_plan_against_autograd_and_the_oracle(gpu, name, batch, n_in, hidden, partials, want, fold_prior):
-    """BNNCost decides its launch sequence once per configuration (``_plan``); each reachable kind of plan is checked here
+    """BNNCost decides its launch sequence once per configuration (``_plan``; consecutive hidden layers of one shape get their weight
+    gradients from ONE strided batched product); each reachable kind of plan is checked here
     against autograd through the torch restatement of the cost and against the oracle's numpy NLL
     (pysgmcmc/models/bayesian_neural_network.py:365-388), to matrix-product rounding."""
     from oracle import sgmcmc_oracle as O
