@@ -401,8 +401,8 @@ class ChainBench(object):
                 "note": "gemm = the step's eight fp32 products replayed alone from a hipGraph, each as the pipeline runs it: "
                         "the three forward layers (%d of them as ONE launch each with bias + tanh as the product's epilogue, "
                         "sgmcmc_bnn_dense_tanh_f32), the two delta W^T products (%d of them with tanh' of the layer below as the "
-                        "epilogue, sgmcmc_bnn_dense_tanh_backward_f32) and three library weight-gradient GEMMs (the first layer's "
-                        "with its bias gradient as a 785th row) -- activations and tanh' are then inside `gemm`; cost_pipeline = the "
+                        "epilogue, sgmcmc_bnn_dense_tanh_backward_f32) and the library weight-gradient products (the two 2048 x 2048 ones as ONE "
+                        "strided batched product, the first layer's with its bias gradient as a 785th row) -- activations and tanh' are then inside `gemm`; cost_pipeline = the "
                         "captured cost pipeline alone (gemm + the loss head + the launches of layers on library products; two graph "
                         "replays differ by less than their noise, so their difference is not reported: the per-dispatch durations "
                         "of the step are in profiles/r04_step_timeline.txt); "

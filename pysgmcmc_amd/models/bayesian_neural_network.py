@@ -290,8 +290,8 @@ class BNNCost(object):
     def cost_and_grad(self, params, grad_views, theta_sumsq=None, theta_sumsq_partials=None):
         """NLL at ``params`` with d NLL/d params written into ``grad_views`` (views of the sampler's
         gradient arena): rocBLAS GEMMs + the library's loss-head and fused tanh-backward/bias-gradient
-        kernels (11 launches per step for the 4-layer net at batch 256: gather, 3 fused forward layers, loss head + last layer's
-        backward, 2 fused backward products, 3 weight-gradient GEMMs, update)."""
+        kernels (10 launches per step for the 4-layer net at batch 256: gather, 3 fused forward layers, loss head + last layer's
+        backward, 2 fused backward products, the hidden layers' weight gradients as one batched product, the first layer's, update)."""
         if self.use_hip_kernels:
             # no silent fallback: the HIP path needs device tensors (kernels.* raises on CPU tensors)
             return self._cost_and_grad_hip(params, grad_views, theta_sumsq, theta_sumsq_partials)
