@@ -405,7 +405,7 @@ class ChainBench(object):
                         "strided batched product, the first layer's with its bias gradient as a 785th row) -- activations and tanh' are then inside `gemm`; cost_pipeline = the "
                         "captured cost pipeline alone (gemm + the loss head + the launches of layers on library products; two graph "
                         "replays differ by less than their noise, so their difference is not reported: the per-dispatch durations "
-                        "of the step are in profiles/r04_step_timeline.txt); "
+                        "of the step are in profiles/r05_step_timeline.txt); "
                         % (n_fused, n_fused_back) +
                         "update = the fused update launched once after the backward pass. Differences of graph replays: rocprofv3's "
                         "per-kernel durations of the same step (profiles/r04_bench10m_kernel_stats.csv) carry ~1.5 us of profiler "

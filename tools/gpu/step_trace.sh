@@ -1,4 +1,4 @@
-# Per-dispatch timeline of the 10 M-parameter chain's step (where the gaps between the 11 launches are). Through gpurun: bash tools/gpu/step_trace.sh
+# Per-dispatch timeline of the 10 M-parameter chain's step (where the gaps between the 10 launches are). Through gpurun: bash tools/gpu/step_trace.sh
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 # what bench.py asks the HIP runtime for on this workload (pysgmcmc_amd.configure_for_device_bound_chains) -- exported here because under
 # rocprofv3 the runtime initialises before python runs
@@ -20,7 +20,7 @@ short = lambda n: ('K1' if 'stream_quads' in n else 'gather' if 'window_gather' 
 gaps = collections.defaultdict(list); durs = collections.defaultdict(list); steps = []
 for a, b in zip(sel[:-1], sel[1:]):
     seq = rows[a:b]
-    if len(seq) != 11: continue
+    if len(seq) != 10: continue                       # gather, 3 forward, head, 2 backward, batched gW, gW_0, update
     steps.append((int(seq[-1]['End_Timestamp']) - int(seq[0]['Start_Timestamp'])) / 1e3)
     nxt = rows[b]
     for k, r in enumerate(seq):
