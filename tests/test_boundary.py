@@ -127,6 +127,12 @@ def test_plain_graph_launch_is_a_call_not_a_default(monkeypatch):
     import torch
     assert in_time == (not torch.cuda.is_initialized())
     monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
+    # under a profiler's preloaded tool library the HIP runtime is up before Python runs: setting the variable here is too late ...
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert pysgmcmc_amd.prefer_plain_graph_launch() is False
+    # ... unless whoever started the process exported it already
+    assert pysgmcmc_amd.prefer_plain_graph_launch() is True      # (the first call left it in the environment)
+    monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
 
 
 def test_device_bound_switch_reports_what_took_effect(monkeypatch):
