@@ -396,7 +396,12 @@ class ChainBench(object):
                 "timed_region_step_median": None if meas_us is None else round(meas_us, 1),
                 "gemm_tflops": round(g_flops / (g_us * 1e-6) / 1e12, 1),
                 "gemm_frac_of_fp32_mfma_peak": round(g_flops / (g_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3),
-                "gemm_flop_per_step": int(g_flops), "forward_layers_on_the_fused_launch": n_fused,
+                "gemm_flop_per_step": int(g_flops),
+                # the step against its own two rooflines: the products on the fp32 matrix pipe + the update on HBM, nothing else
+                "ideal_us": round(g_flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e6 + BYTES_PER_PARAM[mode] * n / (HBM_PEAK_GBS * 1e9) * 1e6, 1),
+                "frac_of_ideal": None if meas_us is None else round(
+                    (g_flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e6 + BYTES_PER_PARAM[mode] * n / (HBM_PEAK_GBS * 1e9) * 1e6) / meas_us, 3),
+                "forward_layers_on_the_fused_launch": n_fused,
                 "backward_products_on_the_fused_launch": n_fused_back,
                 "note": "gemm = the step's eight fp32 products replayed alone from a hipGraph, each as the pipeline runs it: "
                         "the three forward layers (%d of them as ONE launch each with bias + tanh as the product's epilogue, "

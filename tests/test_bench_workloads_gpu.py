@@ -54,6 +54,8 @@ def test_default_workload_line_at_n1(gpu):
     assert "rccl" not in d and "value_ex_exchange" not in d
     assert "step_breakdown_us" in d and d["step_breakdown_us"]["gemm"] > 0
     assert "small_launches" not in d["step_breakdown_us"] and d["step_breakdown_us"]["cost_pipeline"] >= d["step_breakdown_us"]["gemm"] * 0.9
+    # the step against its own rooflines (products at the fp32 matrix peak + the update at the HBM peak): 92.4 + 30.0 us
+    assert abs(d["step_breakdown_us"]["ideal_us"] - 122.4) < 0.2 and 0.4 < d["step_breakdown_us"]["frac_of_ideal"] < 1.0
     # `value` is measured with the package's ONE documented switch; the line says what took effect and carries the rate with nothing set
     sw = d["config"]["device_bound_switch"]
     assert sw == {"gemm_tuning": True, "plain_graph_launch": True} and d["config"]["hip_runtime_env_effective"] is True
