@@ -13,8 +13,9 @@ PMC_TRAFFIC_GLOB = os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json"
 FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix-core peak, /opt/skills/guides/MI355X_MICROARCH.md
 PRIME_BURN_IN = 8              # adapting steps of the chain, run in the prime phase (never timed)
 PRIME_FROZEN = 4               # frozen steps of the prime phase with a moments update + trace append each
-PRIME_STEADY = int(os.environ.get("BENCH_PRIME_STEADY", "124"))   # further frozen steps: ~30 ms of device work, after which
-                               # the step time has settled (measured: 0.237 ms/step right after start-up, 0.218 after 100 steps)
+PRIME_STEADY = int(os.environ.get("BENCH_PRIME_STEADY", "500"))   # further frozen steps: ~90 ms of device work, after which
+                               # the step time has settled (0.237 ms/step right after start-up, 0.218 after 100 steps -- round 2;
+                               # round 5: median step 180.3 us after 124 such steps, 177.2 after 500, 175.8 after 1500)
 N_HBM_RESIDENT = 49_826_818    # configs[4]'s parameter count: 1.2 GB per frozen SGHMC launch
 BATCH = 256
 N_DATA = 100_000

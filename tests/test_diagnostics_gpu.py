@@ -220,7 +220,7 @@ def _bench_n2(extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra + [
            "--backend", "gloo", "--all-ranks-on-gpu0", "--no-update-only"]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_PRIME_STEADY="60")    # (several ranks share one GPU here: a short prime phase)
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
     assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -284,6 +284,7 @@ def _bench_self_launched(n, extra, timeout=800):
         "--backend", "gloo", "--all-ranks-on-gpu0", "--no-update-only"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["BENCH_PRIME_STEADY"] = "60"                             # (several ranks share one GPU here: a short prime phase)
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     return res, [l for l in res.stdout.splitlines() if l.startswith("{")]
 

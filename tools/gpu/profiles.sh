@@ -22,8 +22,8 @@ python3 bench.py --workload bnn50m-sgld --steps 100 --warmup 10 > $O/bench_50m_s
 python3 bench.py --workload bnn50m-rsghmc --steps 100 --warmup 10 > $O/bench_50m_rsghmc.json 2>> $O/bench.err
 python3 bench.py --workload sinc-bnn --steps 3000 --warmup 100 > $O/bench_sinc_bnn.json 2>> $O/bench.err
 # N > 1 started WITHOUT a launcher (all ranks on this box's one GPU over gloo: the code path, not xGMI timings)
-python3 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --all-ranks-on-gpu0 --no-update-only > $O/bench_selflaunch_n2_gloo.json 2>> $O/bench.err
-python3 bench.py --gpus 8 --steps 20 --warmup 5 --backend gloo --all-ranks-on-gpu0 --no-update-only > $O/bench_selflaunch_n8_gloo.json 2>> $O/bench.err
+BENCH_PRIME_STEADY=60 python3 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --all-ranks-on-gpu0 --no-update-only > $O/bench_selflaunch_n2_gloo.json 2>> $O/bench.err
+BENCH_PRIME_STEADY=60 python3 bench.py --gpus 8 --steps 20 --warmup 5 --backend gloo --all-ranks-on-gpu0 --no-update-only > $O/bench_selflaunch_n8_gloo.json 2>> $O/bench.err
 # (3) kernel-trace stats of the bench commands (program directly after --). Under rocprofv3 the HIP runtime initialises before python
 # runs, so what pysgmcmc_amd.configure_for_device_bound_chains() asks of it is exported here
 export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0

@@ -3,6 +3,7 @@ cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 # what bench.py asks the HIP runtime for on this workload (pysgmcmc_amd.configure_for_device_bound_chains) -- exported here because under
 # rocprofv3 the runtime initialises before python runs
 export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
+export BENCH_PRIME_STEADY=124      # the step selection below counts gathers from the start of the run
 O=gpurun_out/steptrace; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --output-format csv -d $O/t -o t -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-update-only --no-product-defaults > $O/line.json 2> $O/err.txt
 python3 - <<'PY'
