@@ -175,7 +175,7 @@ def run_sinc(args, dev, rank, world, dist):
             "chains": n_chains, "steps_per_launch": CHUNK, "samples_per_s": round(n_chains * CHUNK * len(e) / wall, 1),
             "us_per_launch_mean": round(float(k_us.mean()), 1), "us_per_step_of_all_chains": round(float(k_us.mean()) / CHUNK, 2),
             "samples_per_s_device_time": round(n_chains * CHUNK / (float(k_us.mean()) * 1e-6), 1),
-            "note": "one launch advances %d independent chains by %d steps (one 1024-lane workgroup per chain, one chain per CU); "
+            "note": "one launch advances %d independent chains by %d steps (one 512-lane workgroup per chain, one chain per CU); "
                     "samples_per_s is wall clock including the host side (window draws of every chain), not part of `value`" % (n_chains, CHUNK)}
         del group
     alg_bytes = 6 * 4 * n + BATCH_SINC * 2 * 4                 # R{theta, V, grad, minv} W{theta, V} + the window rows, if it went to HBM
@@ -192,13 +192,13 @@ def run_sinc(args, dev, rank, world, dist):
                    "params": n, "batch": BATCH_SINC, "chains": world, "steps_per_launch": CHUNK},
         "modes_samples_per_s": modes,
         "many_chains_per_gpu": many,
-        "roofline": {"bound": "hbm", "kernel": "bnn_fused_sghmc_kernel<float, 0> (ONE 1024-lane workgroup per chain)",
+        "roofline": {"bound": "hbm", "kernel": "bnn_fused_sghmc_kernel<float, 0> (ONE 512-lane workgroup per chain)",
                      "achieved": round(alg_bytes / (us_per_step * 1e-6) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg_bytes / (us_per_step * 1e-6) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
                      "algorithmic_bytes_per_step": alg_bytes, "us_per_step": round(us_per_step, 2),
                      "us_per_launch_mean": round(float(launch_us.mean()), 1), "launches_timed": len(launches),
                      "note": "latency-bound, one workgroup: the chain's whole state (%d KB) lives in LDS / L2 for the length of a "
-                             "launch, so the HBM roofline does not bind -- a step is ~25 barrier-separated phases of 16 waves "
+                             "launch, so the HBM roofline does not bind -- a step is ~25 barrier-separated phases of 8 waves "
                              "on one CU (DESIGN.md section 3, K8); the figure that matters is us_per_step. rocprofv3 launch "
                              "durations: profiles/r04_sinc_bnn_kernel_stats.csv" % (7 * 4 * n // 1024),
                      "timing": "hipEvent pair around every launch of the timed region"},

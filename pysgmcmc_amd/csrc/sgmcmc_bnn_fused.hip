@@ -6,13 +6,17 @@
 // forward, loss head (pysgmcmc/models/bayesian_neural_network.py:365-388), analytic backward into
 // the gradient row, fused SGHMC update (pysgmcmc/samplers/sghmc.py:165-251, the same quad operator
 // and the same Philox stream as kernel K1), sum(theta^2) for the next cost -- with ONE workgroup of
-// 1024 lanes per chain and `__syncthreads()` between phases. Activations, deltas and a copy of the
+// 512 lanes per chain and `__syncthreads()` between phases. Activations, deltas and a copy of the
 // parameters live in LDS (the dot-product loops never wait on global memory); the sampler state stays
-// in its arena rows (L2-resident at this size) and is streamed once per step by the update phase.
-// Measured (MI355X, 3x50 net, batch 20): 27 us per step = forward 7 + backward 13 + head/update/sums 7,
-// bound by the instruction latency of ONE workgroup (16 waves on one CU), not by memory: 256 chains in
-// one launch take the same 27 us per step (8.8 M samples/s aggregate). 4-wide register blocking and
-// software-pipelined LDS reads were tried and gave nothing (fewer active waves, same latency chain). blockIdx.x is
+// in its arena rows (L2-resident at this size) and is streamed once per step by the update phase, which
+// also drops theta' straight into the LDS copy for the next step.
+// Measured (MI355X, 3x50 net, batch 20): 20.0 us per step (round 5; 27.2 before) = forward 5.2 + weight / bias gradients 3.2 +
+// delta products 4.5 + update 3.2 + head / sums / barriers 3.9, bound by the instruction and LDS latency of ONE workgroup on one CU,
+// not by memory: 256 chains in one launch take the same time per step. What round 5 changed: 512 lanes instead of 1024 (the
+// 128-register cap of a 1024-lane workgroup spilled: 24.3 -> 20.4 us), pairs of adjacent outputs per lane with 8-byte LDS
+// accesses (2 x 2 register tiles for the weight gradients, the bias gradients riding in the same loop), theta' written to the
+// LDS copy by the update (no reload through L2), the next step's minibatch window requested a step ahead. Every output keeps
+// its k-ordered fma chain, so the results are bit-identical to the scalar loops. blockIdx.x is
 // the chain: independent chains (seed = seed_base + chain, own state rows, own window stream) run
 // concurrently on other CUs at no extra cost.
 //
@@ -37,7 +41,7 @@ using namespace sgmcmc_host;
 namespace {
 
 constexpr int FUSED_MAX_LAYERS = 8;
-constexpr int FUSED_THREADS = 1024;
+constexpr int FUSED_THREADS = 512;       // 8 waves: 2 per SIMD, 256 registers each (1024 lanes spilled registers: 24.3 vs 20.4 us per step)
 
 __device__ __forceinline__ float tanh_t(float x) { return tanhf(x); }
 __device__ __forceinline__ double tanh_t(double x) { return tanh(x); }
@@ -45,6 +49,15 @@ __device__ __forceinline__ double tanh_t(double x) { return tanh(x); }
 // GEMM libraries fuse too); the UPDATE arithmetic below stays one rounding per reference op
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// pairs of consecutive elements as ONE LDS access (ds_read_b64 / b128): half the LDS instructions of the dot-product loops
+template <typename T> struct Pair;
+template <> struct Pair<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Pair<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <typename T>
+__device__ __forceinline__ typename Pair<T>::type ld2(const T *p) { return *reinterpret_cast<const typename Pair<T>::type *>(p); }
+template <typename T>
+__device__ __forceinline__ void st2(T *p, typename Pair<T>::type v) { *reinterpret_cast<typename Pair<T>::type *>(p) = v; }
 
 template <typename T>
 struct FusedArgs {
@@ -85,8 +98,10 @@ __device__ __forceinline__ double block_sum(double v, double *red)
     return red[16];
 }
 
+// wl: the LDS copy of the parameters the next step's forward pass reads -- theta' goes there straight from the registers, so the
+// next step does not wait for a round trip through L2 to get it back
 template <typename Op>
-__device__ __forceinline__ double run_update(Op &op, size_t n_params)
+__device__ __forceinline__ double run_update(Op &op, size_t n_params, typename Op::real *wl)
 {
     const size_t nq_full = n_params / 4;
     const int tail = (int)(n_params % 4);
@@ -96,6 +111,8 @@ __device__ __forceinline__ double run_update(Op &op, size_t n_params)
         op.template load_vec<false>(q, R);
         op.compute(q, R);
         op.template store_vec<false>(q, R);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wl[4 * q + j] = R.th[j];
         op.template accumulate<true>(R, 4, acc);
     }
     if (tail && threadIdx.x == blockDim.x - 1) {
@@ -103,6 +120,7 @@ __device__ __forceinline__ double run_update(Op &op, size_t n_params)
         op.load_part_(nq_full, tail, R);
         op.compute(nq_full, R);
         op.store_part_(nq_full, tail, R);
+        for (int j = 0; j < tail; ++j) wl[4 * nq_full + j] = R.th[j];
         op.template accumulate<true>(R, tail, acc);
     }
     return acc[0];                                        // this lane's share of sum(theta'^2)
@@ -111,7 +129,7 @@ __device__ __forceinline__ double run_update(Op &op, size_t n_params)
 // KIND 0: SGHMC (K1's operator, sghmc.py:165-251); KIND 1: preconditioned SGLD (K2's operator, sgld.py:149-211)
 template <typename T, int KIND, bool ADAPT, bool INJECT>
 __device__ __forceinline__ double update_phase(const FusedArgs<T> &a, T *theta, T *V, const T *grad, T *tau, T *g, T *vh,
-                                               T *minv, const T *xi, uint64_t seed, uint64_t step)
+                                               T *minv, const T *xi, uint64_t seed, uint64_t step, T *wl)
 {
     NoiseKey nk;
     nk.k0 = (uint32_t)seed; nk.k1 = (uint32_t)(seed >> 32);
@@ -120,11 +138,11 @@ __device__ __forceinline__ double update_phase(const FusedArgs<T> &a, T *theta, 
     if (KIND == 0) {
         SghmcOp<T, ADAPT, INJECT> op{theta, V, grad, tau, g, vh, minv, nullptr, xi,
                                      a.eps_e2, a.c1, a.c3, a.e4, a.mdecay, a.grad_decay, nk, nullptr};
-        return run_update(op, a.n_params);
+        return run_update(op, a.n_params, wl);
     } else {
         SgldOp<T, ADAPT, INJECT> op{theta, grad, tau, g, vh, minv, nullptr, xi, a.sgld_eps, a.sgld_A, a.sgld_a_eff,
                                     a.sgld_two_eps, a.sgld_den, a.grad_decay, nk, nullptr};
-        return run_update(op, a.n_params);
+        return run_update(op, a.n_params, wl);
     }
 }
 
@@ -148,17 +166,37 @@ __global__ void __launch_bounds__(FUSED_THREADS) bnn_fused_sghmc_kernel(const Fu
     for (size_t i = tid; i < a.n_params; i += nt) { double v = (double)theta[i]; part += v * v; }
     double tsq = block_sum(part, red);
 
+    // The next step's minibatch window is requested a whole step ahead (its start index, then one window element per lane, into
+    // registers): the dependent pair of global loads is off the step's critical path. Windows larger than the workgroup are
+    // loaded in place as before.
+    const int D0 = a.sizes[0];
+    const bool prefetch = (size_t)B * D0 <= (size_t)nt;
+    T x_next = T(0), y_next = T(0);
+    auto fetch_window = [&](uint64_t tt) {
+        const size_t st = (size_t)a.starts[(size_t)chain * a.n_steps + tt];
+        if (tid < B * D0) x_next = a.X[st * D0 + tid];
+        if (tid < B) y_next = a.y[st + tid];
+    };
+    if (prefetch) fetch_window(0);
     for (uint64_t t = 0; t < a.n_steps; ++t) {
         const uint64_t step = a.first_step + t;
-        const size_t start = (size_t)a.starts[(size_t)chain * a.n_steps + t];
-        // ---- parameters into LDS; minibatch window [start, start + B) (pysgmcmc/data_batches.py:118-123)
+        // ---- parameters into LDS (first step of the launch: later ones find theta' there, written by the update phase);
+        // minibatch window [start, start + B) (pysgmcmc/data_batches.py:118-123)
         {
+            if (t == 0) {
 #pragma unroll 4
-            for (size_t i = tid; i < a.n_params; i += nt) wl[i] = theta[i];
-            const int D = a.sizes[0];
+                for (size_t i = tid; i < a.n_params; i += nt) wl[i] = theta[i];
+            }
             T *x0 = lds + a.act_off[0];
-            for (int i = tid; i < B * D; i += nt) x0[i] = a.X[start * D + i];
-            for (int i = tid; i < B; i += nt) yb[i] = a.y[start + i];
+            if (prefetch) {
+                if (tid < B * D0) x0[tid] = x_next;
+                if (tid < B) yb[tid] = y_next;
+                if (t + 1 < a.n_steps) fetch_window(t + 1);
+            } else {
+                const size_t start = (size_t)a.starts[(size_t)chain * a.n_steps + t];
+                for (int i = tid; i < B * D0; i += nt) x0[i] = a.X[start * D0 + i];
+                for (int i = tid; i < B; i += nt) yb[i] = a.y[start + i];
+            }
         }
         __syncthreads();
         // ---- forward
@@ -167,12 +205,32 @@ __global__ void __launch_bounds__(FUSED_THREADS) bnn_fused_sghmc_kernel(const Fu
             const T *W = wl + a.off_w[l], *bias = wl + a.off_b[l];
             const T *hin = lds + a.act_off[l - 1];
             T *hout = lds + a.act_off[l];
-            for (int idx = tid; idx < B * nout; idx += nt) {
-                const int b = idx / nout, j = idx - b * nout;
-                T acc = bias[j];
+            // two adjacent outputs per lane where the layout allows pair accesses (even width, even offsets): the weight row and
+            // the bias come as pairs; every output keeps its own k-ordered fma chain (same bits as the scalar form)
+            const bool pairs = (nout % 2 == 0) && ((a.off_w[l] | a.off_b[l] | a.act_off[l] | a.lds_w) % 2 == 0);
+            if (pairs) {
+                const int half = nout / 2;
+                for (int idx = tid; idx < B * half; idx += nt) {
+                    const int b = idx / half, j = 2 * (idx - b * half);
+                    typename Pair<T>::type acc = ld2(bias + j);
 #pragma unroll 8
-                for (int k = 0; k < nin; ++k) acc = fma_t(hin[b * nin + k], W[(size_t)k * nout + j], acc);
-                hout[idx] = (l < L) ? tanh_t(acc) : acc;
+                    for (int k = 0; k < nin; ++k) {
+                        const T h = hin[b * nin + k];
+                        const typename Pair<T>::type w = ld2(W + (size_t)k * nout + j);
+                        acc.x = fma_t(h, w.x, acc.x);
+                        acc.y = fma_t(h, w.y, acc.y);
+                    }
+                    if (l < L) { acc.x = tanh_t(acc.x); acc.y = tanh_t(acc.y); }
+                    st2(hout + b * nout + j, acc);
+                }
+            } else {
+                for (int idx = tid; idx < B * nout; idx += nt) {
+                    const int b = idx / nout, j = idx - b * nout;
+                    T acc = bias[j];
+#pragma unroll 8
+                    for (int k = 0; k < nin; ++k) acc = fma_t(hin[b * nin + k], W[(size_t)k * nout + j], acc);
+                    hout[idx] = (l < L) ? tanh_t(acc) : acc;
+                }
             }
             __syncthreads();
         }
@@ -208,28 +266,71 @@ __global__ void __launch_bounds__(FUSED_THREADS) bnn_fused_sghmc_kernel(const Fu
             const T *hin = lds + a.act_off[l - 1];
             const T *dl = lds + a.del_off[l];
             T *gW = grad + a.off_w[l], *gb = grad + a.off_b[l];
-            for (int idx = tid; idx < nin * nout; idx += nt) {            // gW = h_{l-1}^T delta_l
-                const int k = idx / nout, j = idx - k * nout;
-                T acc = T(0);
+            // gW = h_{l-1}^T delta_l. 2 x 2 outputs per lane where the layout allows pair accesses: two pair loads feed four
+            // independent b-ordered fma chains (same bits as the scalar form, a quarter of its LDS instructions)
+            const bool pj = (nout % 2 == 0) && ((a.off_w[l] | a.del_off[l]) % 2 == 0);
+            const bool pk = (nin % 2 == 0) && (a.act_off[l - 1] % 2 == 0);
+            if (pj && pk && a.off_b[l] % 2 == 0) {
+                const int hj = nout / 2, items = (nin / 2) * hj;
+                for (int idx = tid; idx < items; idx += nt) {
+                    const int k = 2 * (idx / hj), j = 2 * (idx % hj);
+                    typename Pair<T>::type a0 = {T(0), T(0)}, a1 = {T(0), T(0)}, sb = {T(0), T(0)};
+#pragma unroll 4
+                    for (int b = 0; b < B; ++b) {
+                        const typename Pair<T>::type h = ld2(hin + b * nin + k), d = ld2(dl + b * nout + j);
+                        a0.x = fma_t(h.x, d.x, a0.x); a0.y = fma_t(h.x, d.y, a0.y);
+                        a1.x = fma_t(h.y, d.x, a1.x); a1.y = fma_t(h.y, d.y, a1.y);
+                        sb.x += d.x; sb.y += d.y;                 // gb = delta_l^T 1 rides along (b order, as the loop below)
+                    }
+                    st2(gW + (size_t)k * nout + j, a0);
+                    st2(gW + (size_t)(k + 1) * nout + j, a1);
+                    if (k == 0) st2(gb + j, sb);                  // (the lanes of the first row pair keep it)
+                }
+            } else {
+                for (int idx = tid; idx < nin * nout; idx += nt) {
+                    const int k = idx / nout, j = idx - k * nout;
+                    T acc = T(0);
 #pragma unroll 8
-                for (int b = 0; b < B; ++b) acc = fma_t(hin[b * nin + k], dl[b * nout + j], acc);
-                gW[idx] = acc;
+                    for (int b = 0; b < B; ++b) acc = fma_t(hin[b * nin + k], dl[b * nout + j], acc);
+                    gW[idx] = acc;
+                }
             }
-            for (int j = tid; j < nout; j += nt) {                        // gb = delta_l^T 1
-                T acc = T(0);
+            if (!(pj && pk && a.off_b[l] % 2 == 0)) {
+                for (int j = tid; j < nout; j += nt) {                    // gb = delta_l^T 1
+                    T acc = T(0);
 #pragma unroll 8
-                for (int b = 0; b < B; ++b) acc += dl[b * nout + j];
-                gb[j] = acc;
+                    for (int b = 0; b < B; ++b) acc += dl[b * nout + j];
+                    gb[j] = acc;
+                }
             }
             if (l > 1) {                                                  // delta_{l-1} = (delta_l W^T) (1 - h^2)
                 T *dprev = lds + a.del_off[l - 1];
-                for (int idx = tid; idx < B * nin; idx += nt) {
-                    const int b = idx / nin, k = idx - b * nin;
-                    T acc = T(0);
+                if (pj && pk && a.del_off[l - 1] % 2 == 0) {
+                    // two adjacent k per lane, j in pairs: three pair loads per four fmas; each output keeps its j-ordered chain
+                    const int hk = nin / 2;
+                    for (int idx = tid; idx < B * hk; idx += nt) {
+                        const int b = idx / hk, k = 2 * (idx - b * hk);
+                        T acc0 = T(0), acc1 = T(0);
+#pragma unroll 4
+                        for (int j = 0; j < nout; j += 2) {
+                            const typename Pair<T>::type d = ld2(dl + b * nout + j);
+                            const typename Pair<T>::type w0 = ld2(W + (size_t)k * nout + j), w1 = ld2(W + (size_t)(k + 1) * nout + j);
+                            acc0 = fma_t(d.x, w0.x, acc0); acc0 = fma_t(d.y, w0.y, acc0);
+                            acc1 = fma_t(d.x, w1.x, acc1); acc1 = fma_t(d.y, w1.y, acc1);
+                        }
+                        const typename Pair<T>::type hv = ld2(hin + b * nin + k);
+                        typename Pair<T>::type out = {acc0 * (T(1) - hv.x * hv.x), acc1 * (T(1) - hv.y * hv.y)};
+                        st2(dprev + b * nin + k, out);
+                    }
+                } else {
+                    for (int idx = tid; idx < B * nin; idx += nt) {
+                        const int b = idx / nin, k = idx - b * nin;
+                        T acc = T(0);
 #pragma unroll 8
-                    for (int j = 0; j < nout; ++j) acc = fma_t(dl[b * nout + j], W[(size_t)k * nout + j], acc);
-                    const T hv = hin[idx];
-                    dprev[idx] = acc * (T(1) - hv * hv);
+                        for (int j = 0; j < nout; ++j) acc = fma_t(dl[b * nout + j], W[(size_t)k * nout + j], acc);
+                        const T hv = hin[idx];
+                        dprev[idx] = acc * (T(1) - hv * hv);
+                    }
                 }
             }
             __syncthreads();
@@ -239,11 +340,11 @@ __global__ void __launch_bounds__(FUSED_THREADS) bnn_fused_sghmc_kernel(const Fu
         const T *xi = (a.xi != nullptr && chain == 0) ? a.xi + (size_t)t * a.n_params : nullptr;
         double share;
         if (adapt) {
-            share = xi ? update_phase<T, KIND, true, true>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step)
-                       : update_phase<T, KIND, true, false>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step);
+            share = xi ? update_phase<T, KIND, true, true>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step, wl)
+                       : update_phase<T, KIND, true, false>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step, wl);
         } else {
-            share = xi ? update_phase<T, KIND, false, true>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step)
-                       : update_phase<T, KIND, false, false>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step);
+            share = xi ? update_phase<T, KIND, false, true>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step, wl)
+                       : update_phase<T, KIND, false, false>(a, theta, V, grad, tau, g, vh, minv, xi, seed, step, wl);
         }
         __threadfence_block();
         tsq = block_sum(share, red);                      // barriers inside: the new theta is visible to the block
