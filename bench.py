@@ -103,8 +103,10 @@ def main():
         args.no_gemm_tuning = not args.device_bound_switch["gemm_tuning"]
         if not args.device_bound_switch["plain_graph_launch"]:
             print("bench: the HIP runtime was initialised before bench.py ran: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is NOT in effect", file=sys.stderr)
-    elif args.product_defaults:
-        args.no_gemm_tuning = True
+    # (--product-defaults: NOTHING is set here -- BNNCost picks the GEMM solutions of a device-bound plan in its first evaluation by
+    # itself, models/bayesian_neural_network.py `auto_gemm_tuning`; the runtime's default graph launch stays)
+    if args.no_gemm_tuning:
+        os.environ["PYSGMCMC_AMD_AUTO_GEMM_TUNING"] = "0"      # --no-gemm-tuning means the library's heuristics, in every rank
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: spawn the ranks from here, BEFORE anything in this process touches the GPU
         sys.exit(self_launch(args))

@@ -20,6 +20,8 @@ from benchlib.workloads import WORKLOADS, build_chain
 
 
 class ChainBench(object):
+    ESS_MIN_KEPT = 50                                          # kept samples per chain below which the line reports no ESS
+
     def __init__(self, args, dev, rank, world, dist):
         from pysgmcmc_amd.diagnostics.sampler_diagnostics import ChainMoments, RhatExchange
         from pysgmcmc_amd.profiling import UpdateKernelTimer
@@ -208,7 +210,7 @@ class ChainBench(object):
         self.elapsed = elapsed
         assert torch.isfinite(self.sampler.arena.row("theta")).all()
         self.ess = None
-        if self.kept >= 8:
+        if self.kept >= self.ESS_MIN_KEPT:
             from pysgmcmc_amd.diagnostics.sampler_diagnostics import ess_across_ranks
             self.ess = ess_across_ranks(self.trace[:self.kept].contiguous())     # all-gather of kept x 4 floats (untimed)
 
@@ -259,7 +261,7 @@ class ChainBench(object):
                        "params": n, "batch": BATCH, "chains": world * K, "chains_per_gpu": K,
                        "rhat_every": self.rhat_every if world > 1 else None,
                        "moments_every": args.moments_every, "moments": "fused into the update launch (K4 in K1)",
-                       "hip_graph": bool(sampler.use_hip_graph), "gemm_tuning": not args.no_gemm_tuning,
+                       "hip_graph": bool(sampler.use_hip_graph), "gemm_tuning": getattr(sampler.cost_fun, "gemm_tuning_applied", None) or (not args.no_gemm_tuning),
                        "prime_steps": {"burn_in": PRIME_BURN_IN, "frozen": PRIME_FROZEN + PRIME_STEADY},
                        "max_queue_depth": args.max_queue_depth, "time_every": self.time_every,
                        "launch": kernels.get_launch_config(), "kernel_source_hash": kernel_source_hash(),
@@ -299,6 +301,11 @@ class ChainBench(object):
             self._rccl_fields(line)
         if self.ess is not None:
             line["ess"] = {"kept_per_chain": self.kept, "cost": self.ess[0], "theta_coords": self.ess[1:]}
+        else:
+            # pymc3's effective_n formula is unguarded (diagnostics/sampler_diagnostics.py): on a handful of samples it returns
+            # anything, negative numbers included -- not reported below ESS_MIN_KEPT kept samples per chain
+            line["ess"] = {"kept_per_chain": self.kept, "cost": None, "theta_coords": None,
+                           "note": "fewer than %d kept samples per chain: not estimated" % self.ESS_MIN_KEPT}
         return line
 
     def _rccl_fields(self, line):
@@ -387,6 +394,10 @@ class ChainBench(object):
                 "launches_timed": int(u_us.size), "step_ms_median": round(serial_step_us * 1e-3, 4),
                 "note": "the same chain, %d steps after the timed region with the timer on EVERY update launch and no moments "
                         "steps: the kernel alone in the pipeline, as rounds 1-2 reported `roofline`" % n_legs}
+            # the contract's `roofline` comes from the timed region, where only every time_every-th launch can carry events (5 of the
+            # driver's 20 steps): the every-launch figure of this loop stands beside it in the same object
+            line["roofline"]["every_launch_loop"] = {k: line["roofline_unoverlapped"][k] for k in (
+                "launches_timed", "us_per_launch_mean", "us_per_launch_median", "achieved", "frac")}
             g_us, g_flops, n_fused, n_fused_back = legs.gemm_only_us(sampler)
             c_us = legs.cost_pipeline_us(sampler)
             meas_us = float(np.median(self.step_ms)) * 1e3 if self.step_ms is not None else None

@@ -268,7 +268,8 @@ def launch_table(timer, n, bytes_per_param, moments_every):
 def product_defaults_leg(args, timeout=600):
     """`value` again for the SAME chain with nothing set: a child process (the graph launch path is fixed when the HIP runtime
     initialises, so it cannot be switched back in this one) runs ``bench.py --product-defaults`` -- no
-    ``pysgmcmc_amd.configure_for_device_bound_chains()``: library GEMM heuristics, the runtime's default graph launch -- with the
+    ``pysgmcmc_amd.configure_for_device_bound_chains()``: the runtime's default graph launch; the GEMM solutions picked by
+    ``BNNCost`` itself in the first evaluation of its plan (``auto_gemm_tuning``, the product default since round 6) -- with the
     same workload, steps and warm-up, while this process sits idle. What a user of the public API gets by default."""
     import json
     import os
@@ -287,4 +288,5 @@ def product_defaults_leg(args, timeout=600):
     return {"value": child["value"], "unit": "samples/s", "ms_per_step": child["ms_per_step"],
             "gemm_tuning": child["config"]["gemm_tuning"], "hip_runtime_env": child["config"]["hip_runtime_env"],
             "note": "the same workload, steps and warm-up in a child process WITHOUT pysgmcmc_amd.configure_for_device_bound_chains(): "
-                    "what the public API gives with nothing set; `value` is with that one documented call made first"}
+                    "what the public API gives with nothing set (gemm_tuning 'auto': BNNCost tunes the first evaluation of its plan by itself; the "
+                    "runtime's default graph launch); `value` is with that one documented call made first"}

@@ -14,6 +14,10 @@ import os as _os
 
 __version__ = "0.1.0"
 
+# what the process was started with, recorded before prefer_plain_graph_launch() can write the variable itself
+_PLAIN_LAUNCH_EXPORTED_AT_IMPORT = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+_PLAIN_LAUNCH_SET_IN_TIME = False
+
 
 def prefer_plain_graph_launch():
     """Ask the HIP runtime for its plain hipGraph launch path instead of the pre-recorded AQL packets ("packet capture", the default
@@ -24,15 +28,17 @@ def prefer_plain_graph_launch():
     graph at 9.2 k instead of 14.9 k steps/s. Hence a call, not a default. The runtime reads the variable when it initialises (its
     first HIP call, not ``import torch``): call this before anything touches the GPU. Returns False when that is already too late (HIP initialised, or a
     profiler's tool library preloaded -- unless the variable was already exported by the caller's environment)."""
+    global _PLAIN_LAUNCH_SET_IN_TIME
     import torch
-    already = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
     _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
-    if already:
-        return True               # whoever started the process exported it: the runtime sees it whenever it initialises
+    if _PLAIN_LAUNCH_EXPORTED_AT_IMPORT or _PLAIN_LAUNCH_SET_IN_TIME:
+        return True               # the caller's environment had it, or an earlier call here set it before the runtime came up
     # a profiler's preloaded tool library (rocprofv3) initialises the HIP runtime before Python runs: too late, export it outside
     preloaded = ("rocprof" in _os.environ.get("LD_PRELOAD", "") or "ROCP_TOOL_LIBRARIES" in _os.environ
                  or "HSA_TOOLS_LIB" in _os.environ)
-    return not torch.cuda.is_initialized() and not preloaded
+    # (a call that came too late leaves the variable set all the same; later calls must not read that as "exported by the caller")
+    _PLAIN_LAUNCH_SET_IN_TIME = not torch.cuda.is_initialized() and not preloaded
+    return _PLAIN_LAUNCH_SET_IN_TIME
 
 
 def configure_for_device_bound_chains(gemm_tuning=True, plain_graph_launch=True, tuning_ms=30, tuning_iters=20):

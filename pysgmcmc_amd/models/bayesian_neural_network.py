@@ -64,6 +64,44 @@ def enable_gemm_tuning(enable=True, results_file=None, max_duration_ms=30, max_i
             tempfile.gettempdir(), "pysgmcmc_amd_tunableop_%d.csv" % os.getpid()))
 
 
+# Plans of at least this many parameters are DEVICE-bound (their step is matrix products on the GPU, not launch overhead): their
+# first evaluation picks the library GEMM solutions by measurement (BNNCost.auto_gemm_tuning). Environment opt-out for the
+# whole process: PYSGMCMC_AMD_AUTO_GEMM_TUNING=0.
+AUTO_GEMM_TUNING_MIN_PARAMS = 1000000
+
+
+def _auto_gemm_tuning_default():
+    import os
+    return os.environ.get("PYSGMCMC_AMD_AUTO_GEMM_TUNING", "1").strip().lower() not in ("0", "false", "off", "no")
+
+
+class _GemmTuningScope(object):
+    """TunableOp tuning switched on for ONE evaluation of a cost plan, and off again afterwards. The selections it made stay in
+    use (``tunable.enable`` stays on: with tuning off TunableOp only looks solutions up); nothing is touched when the caller has
+    tuning on already (``enable_gemm_tuning`` / ``pysgmcmc_amd.configure_for_device_bound_chains``) or a stream is capturing."""
+
+    def __init__(self, max_duration_ms=30, max_iterations=20):
+        self.max_duration_ms, self.max_iterations, self.prev, self.active = max_duration_ms, max_iterations, None, False
+
+    def __enter__(self):
+        import torch.cuda.tunable as tunable
+        if torch.cuda.is_current_stream_capturing() or (tunable.is_enabled() and tunable.tuning_is_enabled()):
+            return self
+        self.prev = (tunable.is_enabled(), tunable.tuning_is_enabled(), tunable.get_max_tuning_duration(),
+                     tunable.get_max_tuning_iterations())
+        enable_gemm_tuning(True, max_duration_ms=self.max_duration_ms, max_iterations=self.max_iterations)
+        self.active = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            import torch.cuda.tunable as tunable
+            tunable.tuning_enable(False)                          # look-ups only from here on; the picks stay in use
+            tunable.set_max_tuning_duration(self.prev[2])
+            tunable.set_max_tuning_iterations(self.prev[3])
+        return False
+
+
 # ------------------------------------------------------------------ normalisation
 # pysgmcmc/models/base_model.py:125-137
 
@@ -154,6 +192,8 @@ class _CostPlan(object):
     """The launch sequence one configuration of the MLP cost path runs (built by ``BNNCost._plan``, walked by every step)."""
     __slots__ = ("forward", "head", "backward", "ones_row", "x_ones", "single_out", "gw_batch")
 
+    fresh = True                                                  # not evaluated yet (BNNCost.auto_gemm_tuning acts on the first evaluation)
+
     def __init__(self, forward, head, backward, ones_row, x_ones, single_out, gw_batch=None):
         self.forward, self.head, self.backward = tuple(forward), head, dict(backward)
         self.ones_row, self.x_ones, self.single_out, self.gw_batch = ones_row, x_ones, single_out, gw_batch
@@ -209,6 +249,14 @@ class BNNCost(object):
         # forces them there, but on configs[4]'s 256 x 4864 x 4864 layers the library's stream-K product is within 3 % of the
         # matrix pipe and the step LOSES 25 us of 783 with the fused launches (profiles/r05_dense_rounds.txt).
         self.fused_layers = True
+        # True: the FIRST evaluation of a plan of >= AUTO_GEMM_TUNING_MIN_PARAMS parameters runs with PyTorch's TunableOp tuning on
+        # (a few ms per GEMM shape; the samplers' warm-up step, before any hipGraph capture) and tuning is switched off again
+        # right after it: the library products of the plan then run the solutions that measured fastest instead of the heuristic
+        # picks -- 5 % of the step at 10 M parameters, 22 % at 49.8 M (profiles/r06_product_defaults.txt). Same fp32 arithmetic,
+        # possibly another summation order. Process-wide side effect: TunableOp stays ENABLED (look-ups only). False, or
+        # PYSGMCMC_AMD_AUTO_GEMM_TUNING=0 in the environment: the library's heuristics, nothing touched.
+        self.auto_gemm_tuning = _auto_gemm_tuning_default()
+        self.gemm_tuning_applied = None                           # None: no plan evaluated yet; "auto" | "caller" | "off"
         self._x_ext = {}                                          # pitched feed buffers handed out by static_feed_buffer()
         self._plans = {}
         # (Forking the weight-gradient GEMMs onto a second stream inside the captured graph was measured
@@ -407,13 +455,27 @@ class BNNCost(object):
         return self._plan(params, grad_views, X, self._buffers(params, X.shape[0]), theta_sumsq_partials is not None).as_dict()
 
     def _cost_and_grad_hip(self, params, grad_views, theta_sumsq, theta_sumsq_partials=None):
-        from pysgmcmc_amd import kernels
         X, Y = self.x_placeholder.value, self.y_placeholder.value
-        B = X.shape[0]
-        L = (len(params) - 1) // 2 - 1
-        ws = self._buffers(params, B)
-        hs, ds = ws["h"], ws["d"]
+        ws = self._buffers(params, X.shape[0])
         plan = self._plan(params, grad_views, X, ws, theta_sumsq_partials is not None)
+        if plan.fresh:
+            plan.fresh = False
+            import torch.cuda.tunable as tunable
+            n_total = sum(int(p.numel()) for p in params)
+            if tunable.is_enabled() and tunable.tuning_is_enabled():
+                self.gemm_tuning_applied = "caller"
+            elif self.auto_gemm_tuning and n_total >= AUTO_GEMM_TUNING_MIN_PARAMS and not torch.cuda.is_current_stream_capturing():
+                self.gemm_tuning_applied = "auto"
+                with _GemmTuningScope():
+                    return self._walk_plan(plan, params, grad_views, theta_sumsq, theta_sumsq_partials, X, Y, ws)
+            else:
+                self.gemm_tuning_applied = "off"
+        return self._walk_plan(plan, params, grad_views, theta_sumsq, theta_sumsq_partials, X, Y, ws)
+
+    def _walk_plan(self, plan, params, grad_views, theta_sumsq, theta_sumsq_partials, X, Y, ws):
+        from pysgmcmc_amd import kernels
+        L = (len(params) - 1) // 2 - 1
+        hs, ds = ws["h"], ws["d"]
         fused_head = plan.head == "head+last_layer_backward"
         # ---- forward
         h, mean = X, hs[L].view(-1)                               # mean: the output unit's pre-bias mean, as the loss head reads it

@@ -7,9 +7,11 @@ In the kernels ``safe_divide`` / ``safe_sqrt`` are device functions
 host-side code such as the BNN priors. ``vectorize`` needs no shadow variable:
 the flat arena already *is* the vectorized parameter.
 """
+import math
+
 import torch
 
-__all__ = ["vectorize", "unvectorize", "safe_divide", "safe_sqrt", "uninitialized_params"]
+__all__ = ["vectorize", "unvectorize", "median", "safe_divide", "safe_sqrt", "pdist", "squareform", "uninitialized_params"]
 
 
 def _as_tensor(x, like=None):
@@ -75,3 +77,79 @@ def uninitialized_params(params, session=None):
     """Torch tensors are always initialised; kept for API compatibility
     (the reference initialises TF variables lazily, tensor_utils.py:579-605)."""
     return []
+
+
+def median(tensor):
+    """Median of all elements; an even count averages the two middle values (``tensor_utils.py:159-204``; ``torch.median`` would
+    return the lower one).
+
+    >>> import torch
+    >>> float(median(torch.tensor([1, 3, 5], dtype=torch.float64)))
+    3.0
+    >>> float(median(torch.tensor([1, 3, 5, 7], dtype=torch.float64)))
+    4.0
+    """
+    flat = torch.sort(_as_tensor(tensor).reshape(-1)).values
+    n = flat.numel()
+    mid = n // 2
+    if n % 2 == 1:
+        return flat[mid]
+    return (flat[mid - 1] + flat[mid]) / 2
+
+
+def pdist(tensor, metric="euclidean"):
+    """Condensed pairwise distances of the rows of a 2-d tensor, scipy's order (``tensor_utils.py:326-419``); euclidean only.
+
+    >>> import torch
+    >>> from scipy.spatial.distance import pdist as pdist_scipy
+    >>> x = torch.tensor([[0.77228064, 0.09543156], [0.3918973, 0.96806584], [0.66008144, 0.22163063]], dtype=torch.float64)
+    >>> bool(torch.allclose(pdist(x), torch.from_numpy(pdist_scipy(x.numpy()))))
+    True
+    >>> pdist(x, metric="lengthy_metric")
+    Traceback (most recent call last):
+     ...
+    NotImplementedError: tensor_utils.pdist: Metric 'lengthy_metric' currently not supported!
+    >>> pdist(torch.rand(2, 2, 1))
+    Traceback (most recent call last):
+     ...
+    ValueError: tensor_utils.pdist: A 2-d tensor must be passed.
+    """
+    tensor = _as_tensor(tensor)
+    if tensor.dim() != 2:
+        raise ValueError("tensor_utils.pdist: A 2-d tensor must be passed.")
+    if metric != "euclidean":
+        raise NotImplementedError("tensor_utils.pdist: Metric '{metric}' currently not supported!".format(metric=metric))
+    i, j = torch.triu_indices(tensor.shape[0], tensor.shape[0], offset=1, device=tensor.device)
+    return torch.linalg.vector_norm(tensor[i] - tensor[j], dim=1)
+
+
+def squareform(tensor):
+    """Condensed distance vector -> symmetric distance matrix with a zero diagonal (``tensor_utils.py:422-576``); 1-d input only.
+
+    >>> import torch
+    >>> from scipy.spatial.distance import pdist as scipy_pdist, squareform as scipy_squareform
+    >>> x = torch.rand(4, 2, dtype=torch.float64)
+    >>> bool(torch.allclose(squareform(pdist(x)), torch.from_numpy(scipy_squareform(scipy_pdist(x.numpy())))))
+    True
+    >>> squareform(torch.rand(4, 4))
+    Traceback (most recent call last):
+     ...
+    NotImplementedError: tensor_utils.squareform: Only 1-d (vector) input is supported!
+    >>> squareform(torch.rand(4))
+    Traceback (most recent call last):
+     ...
+    ValueError: Incompatible vector size. It must be a binomial coefficient n choose 2 for some integer n >=2.
+    """
+    tensor = _as_tensor(tensor)
+    if tensor.dim() != 1:
+        raise NotImplementedError("tensor_utils.squareform: Only 1-d (vector) input is supported!")
+    n = tensor.shape[0]
+    if n == 0:
+        return torch.zeros((1, 1), dtype=tensor.dtype, device=tensor.device)
+    dimension = int(math.ceil(math.sqrt(n * 2)))
+    if dimension * (dimension - 1) != n * 2:
+        raise ValueError("Incompatible vector size. It must be a binomial coefficient n choose 2 for some integer n >=2.")
+    out = torch.zeros((dimension, dimension), dtype=tensor.dtype, device=tensor.device)
+    i, j = torch.triu_indices(dimension, dimension, offset=1, device=tensor.device)
+    out[i, j] = tensor
+    return out + out.t()

@@ -52,6 +52,9 @@ def test_default_workload_line_at_n1(gpu):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["launches_timed"] == 5 and 0.3 < r["frac"] < 1.2
     assert r["algorithmic_bytes_per_launch"] == 24 * 10002434 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
     assert "rccl" not in d and "value_ex_exchange" not in d
+    # hygiene: the every-launch figure stands beside the 5-launch one; no ESS from a handful of kept samples
+    assert r["every_launch_loop"]["launches_timed"] >= 20 and 0.3 < r["every_launch_loop"]["frac"] < 1.2
+    assert d["ess"]["kept_per_chain"] < 50 and d["ess"]["cost"] is None and d["ess"]["theta_coords"] is None
     assert "step_breakdown_us" in d and d["step_breakdown_us"]["gemm"] > 0
     assert "small_launches" not in d["step_breakdown_us"] and d["step_breakdown_us"]["cost_pipeline"] >= d["step_breakdown_us"]["gemm"] * 0.9
     # the step against its own rooflines (products at the fp32 matrix peak + the update at the HBM peak): 92.4 + 30.0 us
@@ -60,8 +63,11 @@ def test_default_workload_line_at_n1(gpu):
     sw = d["config"]["device_bound_switch"]
     assert sw == {"gemm_tuning": True, "plain_graph_launch": True} and d["config"]["hip_runtime_env_effective"] is True
     pd = d["value_product_defaults"]
-    assert pd["gemm_tuning"] is False and pd["hip_runtime_env"] == {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": None}
-    assert 0.8 * d["value"] < pd["value"] < 1.05 * d["value"], (pd["value"], d["value"])
+    # nothing set in the child: BNNCost tunes the first evaluation of its device-bound plan by itself (round 6), the graph launch
+    # path is the runtime's default: within 4 % of `value` (>= 0.97 at this workload on a quiet box)
+    assert pd["gemm_tuning"] == "auto" and pd["hip_runtime_env"] == {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": None}
+    assert d["config"]["gemm_tuning"] == "caller"
+    assert 0.96 * d["value"] < pd["value"] < 1.05 * d["value"], (pd["value"], d["value"])
 
 
 @pytest.mark.timeout(900)
@@ -101,3 +107,48 @@ print("RATE", best)
     best = max(_bench(["--gpus", "1", "--steps", "300", "--warmup", "20", "--no-update-only", "--no-cpu-baseline",
                        "--no-product-defaults"])["value"] for _ in range(2))
     assert rate >= 0.97 * best, (rate, best)
+
+
+@pytest.mark.timeout(900)
+def test_bare_bnn_train_steps_near_the_bench_rate_with_nothing_called_first(gpu):
+    """a bare ``BayesianNeuralNetwork(...).train()`` of the 10 M-parameter net -- NOTHING called first, no
+    environment variable -- steps within 4 % of bench.py's `value`: ``BNNCost`` picks the GEMM solutions of its device-bound plan in
+    the plan's first evaluation by itself (``auto_gemm_tuning``); what is left is the runtime's default graph launch path (~2 %).
+    The caller mirrored: pysgmcmc/models/bayesian_neural_network.py:464-468,510-512. Rate = the difference of two ``train()`` calls
+    of 400 and 1 300 iterations in one fresh process (sampler construction, capture and the two log events cancel)."""
+    code = """
+import time, numpy as np, torch
+from pysgmcmc_amd.models import BayesianNeuralNetwork
+from pysgmcmc_amd.sampling import Sampler
+from pysgmcmc_amd.stepsize_schedules import ConstantStepsizeSchedule
+import torch.cuda.tunable as tunable
+assert not tunable.is_enabled() or not tunable.tuning_is_enabled()
+rng = np.random.RandomState(0)
+X, y = rng.randn(20000, 784).astype(np.float32), rng.randn(20000).astype(np.float32)
+def run(n_iters):
+    bnn = BayesianNeuralNetwork(sampling_method=Sampler.SGHMC, batch_size=256, stepsize_schedule=ConstantStepsizeSchedule(1e-3),
+                                n_nets=100, n_iters=n_iters, burn_in_steps=8, sample_steps=1000000, normalize_input=False,
+                                normalize_output=False, seed=1, dtype=torch.float32, hidden=(2048, 2048, 2048))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    bnn.train(X, y)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, bnn
+run(60)
+best = 0.0
+for rep in range(2):
+    t_short, _ = run(400)
+    t_long, bnn = run(1300)
+    best = max(best, 900 / (t_long - t_short))
+assert bnn.cost.gemm_tuning_applied == "auto", bnn.cost.gemm_tuning_applied
+assert tunable.is_enabled() and not tunable.tuning_is_enabled()          # look-ups only after the plan's first evaluation
+assert sum(p.numel() for p in bnn.network_params) == 10002434 and bnn.sampler.use_hip_graph is True
+print("RATE", best)
+"""
+    env = {k: v for k, v in os.environ.items() if k not in ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "PYSGMCMC_AMD_AUTO_GEMM_TUNING",
+                                                             "PYTORCH_TUNABLEOP_ENABLED", "PYTORCH_TUNABLEOP_TUNING")}
+    res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=700, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    rate = float([l for l in res.stdout.splitlines() if l.startswith("RATE")][-1].split()[1])
+    best = max(_bench(["--gpus", "1", "--steps", "300", "--warmup", "20", "--no-update-only", "--no-cpu-baseline",
+                       "--no-product-defaults"])["value"] for _ in range(2))
+    assert rate >= 0.96 * best, (rate, best)

@@ -128,11 +128,23 @@ def test_plain_graph_launch_is_a_call_not_a_default(monkeypatch):
     assert in_time == (not torch.cuda.is_initialized())
     monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
     # under a profiler's preloaded tool library the HIP runtime is up before Python runs: setting the variable here is too late ...
+    monkeypatch.setattr(pysgmcmc_amd, "_PLAIN_LAUNCH_SET_IN_TIME", False)
     monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
     assert pysgmcmc_amd.prefer_plain_graph_launch() is False
-    # ... unless whoever started the process exported it already
-    assert pysgmcmc_amd.prefer_plain_graph_launch() is True      # (the first call left it in the environment)
+    # ... and stays too late: the variable that call left in the environment is not mistaken for the caller's
+    assert pysgmcmc_amd.runtime_env() == {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "0"}
+    assert pysgmcmc_amd.prefer_plain_graph_launch() is False
+    assert pysgmcmc_amd.configure_for_device_bound_chains(gemm_tuning=False)["plain_graph_launch"] is False
+    # ... unless whoever started the process exported it (recorded when the package was imported)
+    monkeypatch.setattr(pysgmcmc_amd, "_PLAIN_LAUNCH_EXPORTED_AT_IMPORT", True)
+    assert pysgmcmc_amd.prefer_plain_graph_launch() is True
     monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
+    monkeypatch.setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+    importlib.reload(pysgmcmc_amd)
+    assert pysgmcmc_amd._PLAIN_LAUNCH_EXPORTED_AT_IMPORT is True
+    monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
+    importlib.reload(pysgmcmc_amd)
+    assert pysgmcmc_amd._PLAIN_LAUNCH_EXPORTED_AT_IMPORT is False
 
 
 def test_device_bound_switch_reports_what_took_effect(monkeypatch):
