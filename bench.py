@@ -79,6 +79,10 @@ def parse():
                          "device time per step); 0 = steps // 5 clamped to [1, 7]")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="N > 1 started without a launcher: wall-clock limit of the ranks this process spawns (s)")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "f64"),
+                    help="arithmetic type of the chain: f64 is the reference's default dtype (pysgmcmc/samplers/base_classes.py:25); the f64 "
+                         "line carries `value`, the step's device time and the update kernel's roofline (16 B per f64 element touch) -- "
+                         "no legs after the timed region")
     ap.add_argument("--product-defaults", action="store_true",
                     help="step the same chain with NOTHING set (no pysgmcmc_amd.configure_for_device_bound_chains()): the rate a "
                          "user of the public API gets by default; the main line runs this as a child process (value_product_defaults)")
@@ -149,7 +153,8 @@ def main():
     run.leave_group(line)                                      # N > 1: the collective alone, then the job ends for every rank
     if rank != 0:
         return
-    run.post_run_legs(line)                                    # kernel alone, step breakdown, HBM-resident sizes, CPU baseline
+    if args.dtype == "f32":
+        run.post_run_legs(line)                                # kernel alone, step breakdown, HBM-resident sizes, CPU baseline
     print(json.dumps(line))
     sys.stdout.flush()
 

@@ -30,7 +30,10 @@ class ChainBench(object):
         # before anything touched the GPU; args.device_bound_switch holds what took effect)
         # burn-in (preconditioner adaptation) happens in the PRIME phase, so every warm-up and every timed step is
         # in the frozen phase whatever --warmup is
-        self.sampler = sampler = build_chain(dev, rank, args.workload, burn_in=PRIME_BURN_IN)
+        self.f64 = getattr(args, "dtype", "f32") == "f64"
+        self.tdtype = torch.float64 if self.f64 else torch.float32
+        self.esize = 2 if self.f64 else 1                      # element size in units of the f32 tables of benchlib/common.py
+        self.sampler = sampler = build_chain(dev, rank, args.workload, burn_in=PRIME_BURN_IN, dtype=self.tdtype)
         self.kind = WORKLOADS[args.workload]["sampler"]
         sampler.sample_format = "view"                         # no D2H copy of 40 MB per sample
         sampler.use_hip_graph = not args.eager
@@ -39,7 +42,7 @@ class ChainBench(object):
         # per-launch kernel timestamps of the update kernel; BENCH_BRACKET=1 also records a hipEventRecord pair around each call
         self.timer = UpdateKernelTimer(bracket=os.environ.get("BENCH_BRACKET", "0") == "1", device=dev)
         sampler.kernel_timer = self.timer
-        self.moments = ChainMoments(n, dev)
+        self.moments = ChainMoments(n, dev, dtype=self.tdtype)
         # --chains-per-gpu K > 1: K - 1 more independent chains on this GPU (chain ids rank + world * c: distinct seeds, initial
         # weights and window streams across the whole job), stepped concurrently with the first one, each on its own stream
         self.K = K = max(int(args.chains_per_gpu), 1)
@@ -49,10 +52,10 @@ class ChainBench(object):
                 raise SystemExit("--chains-per-gpu > 1 is implemented for the SGHMC workload in hipGraph mode")
             from pysgmcmc_amd.samplers import ConcurrentChains
             for c in range(1, K):
-                other = build_chain(dev, rank + world * c, args.workload, burn_in=PRIME_BURN_IN)
+                other = build_chain(dev, rank + world * c, args.workload, burn_in=PRIME_BURN_IN, dtype=self.tdtype)
                 other.sample_format, other.use_hip_graph, other.collect_stats = "view", sampler.use_hip_graph, sampler.collect_stats
                 self.chains.append(other)
-                self.all_moments.append(ChainMoments(n, dev))
+                self.all_moments.append(ChainMoments(n, dev, dtype=self.tdtype))
             self.group = ConcurrentChains(self.chains)
         self.exchange = RhatExchange(n, dev, mode=args.rhat_mode) if world > 1 else None
         # R-hat cadence: --rhat-every steps (configs[3]: 100). A timed region shorter than that would contain no
@@ -64,7 +67,7 @@ class ChainBench(object):
         # appended on the device (no sync); gathered across chains AFTER the timed region
         self.coords = torch.tensor([0, n // 2, n - 1], device=dev)
         total_steps = PRIME_BURN_IN + PRIME_FROZEN + PRIME_STEADY + args.steps + args.warmup
-        self.trace = torch.zeros(total_steps // max(args.moments_every, 1) + PRIME_FROZEN + 2, 4, device=dev)
+        self.trace = torch.zeros(total_steps // max(args.moments_every, 1) + PRIME_FROZEN + 2, 4, device=dev, dtype=self.tdtype)
         self.kept = 0
         self.ex_events = []                                    # (start, packed, finish-begin, finish-end) HIP events
         self.periodic_exchange = False                         # the periodic R-hat exchange runs in the timed region only
@@ -227,14 +230,15 @@ class ChainBench(object):
         br = timer.bracket_us()                     # hipEventRecord bracket around the call (BENCH_BRACKET=1), else empty
         b_us = float(br.mean()) if br.size else None
         ev_us = timer.empty_bracket_us()
-        rows = legs.launch_table(timer, n, BYTES_PER_PARAM[mode], args.moments_every)
+        bpp = BYTES_PER_PARAM[mode] * self.esize                # f64: every element touch is 8 bytes
+        rows = legs.launch_table(timer, n, bpp, args.moments_every, moments_bytes=16 * self.esize)
         plain = [r for r in rows if not r[5]] or rows          # launches without the fused Welford update
         k_us_sum = float(sum(r[3] for r in plain))
         achieved = float(sum(r[4] for r in plain)) / (k_us_sum * 1e-6) / 1e9
         k_us = k_us_sum / max(len(plain), 1)
-        alg_bytes = BYTES_PER_PARAM[mode] * n
+        alg_bytes = bpp * n
         big = alg_bytes > (640 << 20)
-        traffic, traffic_src = pmc_traffic(mode, n, variant="_tsq")       # the pipeline launches the sum-theta^2-only variant
+        traffic, traffic_src = pmc_traffic(mode, n, variant="_tsq") if not self.f64 else (None, "no PMC pass of the f64 instances")       # the pipeline launches the sum-theta^2-only variant
         # per-step device time: from the end of one timed step's update launch to the end of the next one's
         self.step_ms = step_ms = np.array([step_end[j][1].us_until(step_end[j + 1][1]) / (step_end[j + 1][0] - step_end[j][0])
                                            for j in range(len(step_end) - 1)]) * 1e-3 if len(step_end) > 1 else None
@@ -253,7 +257,7 @@ class ChainBench(object):
                                 "max": round(float(self.host_ms.max()), 4), "argmax": int(self.host_ms.argmax()),
                                 "final_fence": round(self.final_fence_ms, 4)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f64" if self.f64 else "f32", "data": "synthetic",
             "config": {"workload": "%s: %s (%s) full next(sampler) step: BNN fwd+bwd + fused update; "
                                    "4-layer tanh MLP BNN %s-1, %d params, batch %d, %d chain(s) per GPU" % (
                                        args.workload, kind.upper(), mode, "-".join(map(str, WORKLOADS[args.workload]["layers"])),
@@ -271,14 +275,14 @@ class ChainBench(object):
             # template args: <Op<float, ADAPT, INJECT>, quads per lane, NT, STATS (2 = sum theta^2 only), LOOP, MOMENTS>, from
             # the launch configuration in effect (library defaults: 1 quad per lane, nt iff the launch streams > 640 MiB,
             # single-pass variant while the grid is uncapped)
-            "roofline": {"bound": "hbm", "kernel": legs.update_kernel_instance(op_name, kind == "rsghmc" or not self.frozen_phase, big, sampler),   # (2nd template arg of RsghmcOp = POW2: m = c = 1)
+            "roofline": {"bound": "hbm", "kernel": legs.update_kernel_instance(op_name, kind == "rsghmc" or not self.frozen_phase, big, sampler, scalar="double" if self.f64 else "float"),   # (2nd template arg of RsghmcOp = POW2: m = c = 1)
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch_mean": round(k_us, 2),
                          "launches_timed": len(rows), "launches_in_the_rate": len(plain),
                          "with_fused_moments": None if not with_mom else {
-                             "launches": len(with_mom), "bytes_per_param": BYTES_PER_PARAM[mode] + 16,
+                             "launches": len(with_mom), "bytes_per_param": bpp + 16 * self.esize,
                              "us_per_launch_mean": round(sum(r[3] for r in with_mom) / len(with_mom), 2),
                              "GBps": round(sum(r[4] for r in with_mom) / sum(r[3] for r in with_mom) / 1e3, 1)},
                          # the conservative figure of round 1: hipEventRecord pair AROUND the call

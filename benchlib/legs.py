@@ -233,7 +233,7 @@ def cost_pipeline_us(sampler, iters=60):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-def update_kernel_instance(op_name, adapt, big, sampler, moments=False):
+def update_kernel_instance(op_name, adapt, big, sampler, moments=False, scalar="float"):
     """Name of the stream_quads_vec instance the library launches for this sampler's update under the launch
     configuration in effect (sampler.launch, else the Python-side default, else the library's defaults)."""
     from pysgmcmc_amd import kernels
@@ -242,24 +242,26 @@ def update_kernel_instance(op_name, adapt, big, sampler, moments=False):
         cfg.update({k: v for k, v in sampler.launch.as_dict().items() if v != (-1 if k == "nontemporal" else 0)})
     qpt = cfg["quads_per_thread"]
     nt = big if cfg["nontemporal"] == 2 else bool(cfg["nontemporal"])
+    if scalar == "double" and cfg["nontemporal"] == 2:
+        nt = False                                         # f64 launches use plain accesses at every size (round 5)
     bt = cfg["block_threads"] if cfg["block_threads"] > 0 else (128 if big else 256)
     loop = qpt != 1 or (sampler.arena.n // 4 + bt - 1) // bt > cfg["max_blocks"]
     stats = {True: 1, "theta_sq": 2}.get(sampler.collect_stats, 0)
     if loop and stats == 2:
         stats = 1                                          # the looping variants reduce every statistic
-    return "stream_quads_vec<%s<float,%s,false>,%d,%s,%d,%s,%s> (%d-lane blocks)" % (
-        op_name, "true" if adapt else "false", qpt, "true" if nt else "false", stats, "true" if loop else "false",
+    return "stream_quads_vec<%s<%s,%s,false>,%d,%s,%d,%s,%s> (%d-lane blocks)" % (
+        op_name, scalar, "true" if adapt else "false", qpt, "true" if nt else "false", stats, "true" if loop else "false",
         "true" if (moments and not loop) else "false", bt)
 
 
-def launch_table(timer, n, bytes_per_param, moments_every):
+def launch_table(timer, n, bytes_per_param, moments_every, moments_bytes=16):
     """Per-launch records of a timed region: (step, lo, hi, microseconds, algorithmic bytes). A launch of a moments
     step also carries the fused Welford update (+16 B per f32 parameter)."""
     rows = []
     for kev, tag in zip(timer.kevents, timer.tags):
         step, lo, hi = tag if tag is not None else (None, 0, n)
         with_mom = step is not None and moments_every and (step + 1) % moments_every == 0
-        rows.append((step, lo, hi, kev.elapsed_us(), (bytes_per_param + (16 if with_mom else 0)) * (hi - lo), bool(with_mom)))
+        rows.append((step, lo, hi, kev.elapsed_us(), (bytes_per_param + (moments_bytes if with_mom else 0)) * (hi - lo), bool(with_mom)))
     return rows
 
 

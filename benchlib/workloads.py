@@ -19,7 +19,7 @@ WORKLOADS = {
 LAYERS = WORKLOADS["bnn10m-sghmc"]["layers"]
 
 
-def build_chain(dev, rank, workload="bnn10m-sghmc", burn_in=8):
+def build_chain(dev, rank, workload="bnn10m-sghmc", burn_in=8, dtype=torch.float32):
     from pysgmcmc_amd.data_batches import Placeholder, generate_batches
     from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
     from pysgmcmc_amd.samplers import RelativisticSGHMCSampler, SGHMCSampler, SGLDSampler
@@ -28,18 +28,18 @@ def build_chain(dev, rank, workload="bnn10m-sghmc", burn_in=8):
     spec = WORKLOADS[workload]
     layers = spec["layers"]
     g = torch.Generator(device=dev).manual_seed(0)             # same synthetic dataset on every rank
-    X = torch.randn(N_DATA, layers[0], device=dev, generator=g)
-    y = torch.randn(N_DATA, device=dev, generator=g)
-    xp = Placeholder(dtype=torch.float32, device=dev, name="X_Minibatch")
-    yp = Placeholder(dtype=torch.float32, device=dev, name="Y_Minibatch")
-    params = init_mlp_params(layers[0], hidden=layers[1:], seed=1000 + rank, dtype=torch.float32, device=dev)
+    X = torch.randn(N_DATA, layers[0], device=dev, generator=g).to(dtype)       # (the same numbers in either dtype)
+    y = torch.randn(N_DATA, device=dev, generator=g).to(dtype)
+    xp = Placeholder(dtype=dtype, device=dev, name="X_Minibatch")
+    yp = Placeholder(dtype=dtype, device=dev, name="Y_Minibatch")
+    params = init_mlp_params(layers[0], hidden=layers[1:], seed=1000 + rank, dtype=dtype, device=dev)
     cost = BNNCost(xp, yp, batch_size=BATCH, n_examples=N_DATA)
     # profiling aid (tools/gpu/r05_prof50m.sh): hidden layers on library products / on the fused launches whatever their tile count
     if os.environ.get("BENCH_FUSED_LAYERS") in ("library", "all"):
         cost.fused_layers = False if os.environ["BENCH_FUSED_LAYERS"] == "library" else "all"
     common = dict(params=params, cost_fun=cost,
                   batch_generator=generate_batches(X, y, xp, yp, batch_size=BATCH, seed=rank),
-                  session=dev, dtype=torch.float32, seed=1234 + rank)
+                  session=dev, dtype=dtype, seed=1234 + rank)
     if spec["sampler"] == "sghmc":
         return SGHMCSampler(stepsize_schedule=ConstantStepsizeSchedule(0.01), mdecay=0.05,
                             scale_grad=float(N_DATA),

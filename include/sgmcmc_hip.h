@@ -43,12 +43,46 @@
 extern "C" {
 #endif
 
-#define SGMCMC_ABI_VERSION 5
+#define SGMCMC_ABI_VERSION 6
 
 #define SGMCMC_EINVAL   (-1)   /* null/invalid argument */
 #define SGMCMC_ENODEV   (-2)   /* no HIP device / not gfx950 code object */
 
 typedef void *sgmcmc_stream_t;     /* hipStream_t */
+
+/* ---- Contract map (ABI v6): what a maintainer of the reference binds, and what is this build's own machinery ------------------
+ * Every entry point below belongs to exactly one group (tests/test_boundary.py checks the lists against the declarations).
+ *
+ * [boundary]  SURVEY.md section 8(b): the update path behind `next(sampler)` and its one cross-chain exchange. THIS is the drop-in
+ *   contract; INTEGRATION.md binds it from the reference's side.
+ *     sgmcmc_abi_version sgmcmc_last_error sgmcmc_device_count
+ *     sgmcmc_sghmc_step_f32 sgmcmc_sghmc_step_f64 sgmcmc_sgld_step_f32 sgmcmc_sgld_step_f64
+ *     sgmcmc_rsghmc_step_f32 sgmcmc_rsghmc_step_f64
+ *     sgmcmc_sghmc_scalars_f32 sgmcmc_sghmc_scalars_f64 sgmcmc_sgld_scalars_f32 sgmcmc_sgld_scalars_f64
+ *     sgmcmc_rsghmc_scalars_f32 sgmcmc_rsghmc_scalars_f64 sgmcmc_counter_add_u64
+ *     sgmcmc_step_stats_records sgmcmc_step_stats_workspace_bytes sgmcmc_step_stats_finish
+ *     sgmcmc_philox_normal_f32 sgmcmc_philox_normal_f64 sgmcmc_philox_bits_u32
+ *     sgmcmc_moments_update_f32 sgmcmc_moments_update_f64
+ *     sgmcmc_rhat_pack_f32 sgmcmc_rhat_pack_f64 sgmcmc_rhat_finish_f32 sgmcmc_rhat_finish_f64
+ *     sgmcmc_summary_workspace_bytes sgmcmc_summary_f32 sgmcmc_summary_f64
+ *     sgmcmc_event_create sgmcmc_event_destroy sgmcmc_event_elapsed_ms sgmcmc_event_synchronize
+ * [cost-path]  internals of the gradient PRODUCER (row a14: BNNCost's launch plans, the replacement of the TF cost graph of
+ *   pysgmcmc/models/bayesian_neural_network.py:28-141,337-388). A maintainer who keeps another gradient producer binds none of
+ *   them; every one is launched by at least one reachable plan (tests/test_bnn_dense_gpu.py walks the plans).
+ *     sgmcmc_window_gather_f32 sgmcmc_window_gather_f64
+ *     sgmcmc_bnn_dense_tanh_dot_parts sgmcmc_bnn_dense_tanh_f32 sgmcmc_bnn_dense_tanh_backward_f32 sgmcmc_colsum_finish_f32
+ *     sgmcmc_bias_tanh_f32 sgmcmc_bias_tanh_f64 sgmcmc_bias_tanh_rowdot_f32 sgmcmc_bias_tanh_rowdot_f64
+ *     sgmcmc_bnn_head_f32 sgmcmc_bnn_head_f64 sgmcmc_bnn_head_last_layer_backward_f32 sgmcmc_bnn_head_last_layer_backward_f64
+ *     sgmcmc_bnn_last_layer_backward_f32 sgmcmc_bnn_last_layer_backward_f64
+ *     sgmcmc_tanh_backward_f32 sgmcmc_tanh_backward_f64 sgmcmc_tanh_backward_colsum_f32 sgmcmc_tanh_backward_colsum_f64
+ * [whole-step]  problems that fit one workgroup or one lane: the whole `next(sampler)` step (or many) in one launch --
+ *   BASELINE configs[1]'s 3 x 50 net and the reference's toy targets.
+ *     sgmcmc_bnn_fused_sghmc_steps_f32 sgmcmc_bnn_fused_sghmc_steps_f64 sgmcmc_bnn_fused_sgld_steps_f32 sgmcmc_bnn_fused_sgld_steps_f64
+ *     sgmcmc_toy_chains_f32 sgmcmc_toy_chains_f64
+ * [svgd]  pysgmcmc/samplers/svgd.py -- OUT OF SCOPE of the hot path, built in round 1 and kept as is.
+ *     sgmcmc_svgd_workspace_bytes sgmcmc_svgd_max_particles sgmcmc_svgd_step_f32 sgmcmc_svgd_step_f64
+ *     sgmcmc_svgd_kernel_f32 sgmcmc_svgd_kernel_f64
+ * ---- end of the contract map ---------------------------------------------------------------------------------------------------- */
 
 int sgmcmc_abi_version(void);
 const char *sgmcmc_last_error(void);
@@ -385,16 +419,13 @@ int sgmcmc_bnn_fused_sgld_steps_f64(double *theta, double *grad, double *tau, do
                                     uint64_t seed_base, const double *xi, double *cost_out, sgmcmc_stream_t stream);
 
 /* Forward of the last hidden layer fused with a single-output layer above it (models/bayesian_neural_network.py:
- * 48-56): a[rows][cols] = tanh(a) in place, out[r] = sum_c a[r][c] * w[c] (no bias: the loss head adds it).
+ * 48-56): a[rows][cols] = tanh(a + bias[c]) in place (bias NULL = none), out[r] = sum_c a[r][c] * w[c] (without the output
+ * unit's bias: the loss head adds it). The forward product before it is then a plain GEMM -- at batch 256 the library's plain
+ * product is 1.4-2.1 us faster than its bias-epilogue one.
  * stats_ws / tsq_parts (both NULL or both given): the first min(16, rows) workgroups also add up one slice each of
  * the sum(theta^2) partials of the previous step kernel's statistics workspace into tsq_parts[0..15] (doubles), for
- * sgmcmc_bnn_head_last_layer_backward_*.                                                                          */
-int sgmcmc_tanh_rowdot_f32(float *a, const float *w, size_t rows, size_t cols, float *out, const void *stats_ws,
-                           double *tsq_parts, sgmcmc_stream_t stream);
-int sgmcmc_tanh_rowdot_f64(double *a, const double *w, size_t rows, size_t cols, double *out, const void *stats_ws,
-                           double *tsq_parts, sgmcmc_stream_t stream);
-/* the same with the layer's bias added first: a = tanh(a + bias[c]) (bias NULL = none); the forward product is then a
- * plain GEMM -- at batch 256 the library's plain product is 1.4-2.1 us faster than its bias-epilogue one.         */
+ * sgmcmc_bnn_head_last_layer_backward_*. (ABI v6 dropped sgmcmc_tanh_rowdot_*, the bias == NULL form as an entry point of its
+ * own: no plan of the cost path launched it any more.)                                                              */
 int sgmcmc_bias_tanh_rowdot_f32(float *a, const float *bias, const float *w, size_t rows, size_t cols, float *out,
                                 const void *stats_ws, double *tsq_parts, sgmcmc_stream_t stream);
 int sgmcmc_bias_tanh_rowdot_f64(double *a, const double *bias, const double *w, size_t rows, size_t cols, double *out,
@@ -533,6 +564,8 @@ int sgmcmc_svgd_kernel_f64(const double *particles, size_t n_particles, size_t d
  *     arguments) did not beat the library products and are no longer exported (round 5 removed the separate
  *     experiments library too; the measurements are kept under profiles/, see profiles/HISTORY.md).
  * 10. f64 variants of everything (the reference's default dtype is float64, base_classes.py:25).
+ * 11. (ABI v6) the contract map at the top of this file says which entry points ARE the section 8(b) boundary and which are the
+ *     cost path's internals; sgmcmc_tanh_rowdot_* (superseded by sgmcmc_bias_tanh_rowdot_*, launched by no plan) is gone.
  */
 
 #ifdef __cplusplus

@@ -37,7 +37,7 @@ def build(force=False):
 
 
 _lib = None
-ABI_VERSION = 5               # SGMCMC_ABI_VERSION of include/sgmcmc_hip.h
+ABI_VERSION = 6               # SGMCMC_ABI_VERSION of include/sgmcmc_hip.h
 
 _u64 = ctypes.c_uint64
 _sz = ctypes.c_size_t
@@ -130,9 +130,6 @@ def _declare(lib):
         f = getattr(lib, "sgmcmc_bnn_fused_sghmc_steps_" + sfx)
         f.argtypes = ([_vp] * 7 + [_sz, _sz, _ci, ctypes.POINTER(_ci), _ci, _vp, _vp, _sz, _vp, _ci]
                       + [ctypes.c_double] * 5 + [real, real, real, _u64, _u64, _u64, _u64, _vp, _vp, _vp])
-        f.restype = _ci
-        f = getattr(lib, "sgmcmc_tanh_rowdot_" + sfx)
-        f.argtypes = [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]
         f.restype = _ci
         f = getattr(lib, "sgmcmc_bias_tanh_rowdot_" + sfx)
         f.argtypes = [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]

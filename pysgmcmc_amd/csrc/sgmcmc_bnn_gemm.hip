@@ -41,6 +41,7 @@
 // fp32 MFMA is an exact fmaf chain (MI355X_MICROARCH.md): the product differs from a library GEMM in summation order only.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <type_traits>
@@ -459,11 +460,23 @@ struct ColumnPlan {
     int parts;                  // column tiles in all = rows of dot_parts: n_full / 64 + (N - n_full) / 32
 };
 
-ColumnPlan plan_columns(int M, int N)
+// Compute units of the current device, queried once per device and kept (the plan a caller sized dot_parts with and the plan a
+// launch uses must be the same split: both read this). 0: no device / the query failed.
+int current_device_cus()
 {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = 256;
+    constexpr int MAX_DEV = 64;
+    static std::atomic<int> cached[MAX_DEV];                // zero-initialised: 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return 0;
+    int cus = cached[dev].load(std::memory_order_relaxed);
+    if (cus > 0) return cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
+    cached[dev].store(cus, std::memory_order_relaxed);
+    return cus;
+}
+
+ColumnPlan plan_columns(int M, int N, int cus)
+{
     const int tiles_m = M / BM, col_tiles = N / 64, tiles = tiles_m * col_tiles;
     ColumnPlan p{N, col_tiles};
     if (tiles <= cus || tiles % cus == 0) return p;
@@ -506,7 +519,8 @@ extern "C" {
 int sgmcmc_bnn_dense_tanh_dot_parts(int M, int N)
 {
     if (M <= 0 || N <= 0 || M % BM || N % 64) return 0;
-    return plan_columns(M, N).parts;
+    const int cus = current_device_cus();                   // (without a device this is host arithmetic for MI355X's 256 CUs;
+    return plan_columns(M, N, cus > 0 ? cus : 256).parts;   //  a launch cannot follow it then)
 }
 
 /* see include/sgmcmc_hip.h */
@@ -522,7 +536,9 @@ int sgmcmc_bnn_dense_tanh_f32(const float *h, const float *W, const float *bias,
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh: needs M %% 32 == 0, N %% 64 == 0, K %% 16 == 0, K >= 64, 16-byte aligned rows");
     if ((double)K * ldw * 4.0 >= 2147483648.0 || (double)M * ldh * 4.0 >= 2147483648.0)
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh: an operand spans more than 2 GiB (32-bit buffer offsets)");
-    const ColumnPlan plan = plan_columns(M, N);
+    const int cus = current_device_cus();
+    if (cus <= 0) return fail(SGMCMC_ENODEV, "bnn_dense_tanh: no HIP device (compute-unit count unavailable)");
+    const ColumnPlan plan = plan_columns(M, N, cus);
     if (stats_ws != nullptr && (M / BM) * (plan.n_full / 64) < TSQ_SLICES)
         return fail(SGMCMC_EINVAL, "bnn_dense_tanh: the sum(theta^2) side job needs at least 16 output tiles (the loss head adds 16 slices)");
     FwdArgs g{};
@@ -555,7 +571,9 @@ int sgmcmc_bnn_dense_tanh_backward_f32(const float *delta, const float *W, const
     g.h = delta; g.W = W; g.out = out; g.M = M; g.N = N; g.K = K; g.ldh = ldd; g.ldw = ldw; g.ldo = ldo;
     g.act = act; g.colsum_parts = colsum_parts; g.lda = lda;
     g.fin_parts = fin_parts; g.fin_bias = fin_bias; g.fin_colsum = fin_colsum; g.fin_beta = fin_beta; g.fin_rows = fin_rows; g.fin_n = fin_n;
-    return launch_dense<true>(g, plan_columns(M, N), static_cast<hipStream_t>(stream), "launch bnn_dense_tanh_backward");
+    const int cus = current_device_cus();
+    if (cus <= 0) return fail(SGMCMC_ENODEV, "bnn_dense_tanh_backward: no HIP device (compute-unit count unavailable)");
+    return launch_dense<true>(g, plan_columns(M, N, cus), static_cast<hipStream_t>(stream), "launch bnn_dense_tanh_backward");
 }
 
 /* see include/sgmcmc_hip.h */

@@ -1017,11 +1017,6 @@ SGMCMC_WINDOW_GATHER(f64, double)
         hipError_t e = hipGetLastError();                                                                            \
         return e == hipSuccess ? 0 : hip_fail(e, "launch tanh_rowdot");                                              \
     }                                                                                                                \
-    int sgmcmc_tanh_rowdot_##SFX(T *a, const T *w, size_t rows, size_t cols, T *out, const void *stats_ws,          \
-                                 double *tsq_parts, sgmcmc_stream_t stream)                                          \
-    {                                                                                                                \
-        return sgmcmc_bias_tanh_rowdot_##SFX(a, nullptr, w, rows, cols, out, stats_ws, tsq_parts, stream);           \
-    }                                                                                                                \
     int sgmcmc_bias_tanh_##SFX(T *a, const T *bias, size_t rows, size_t cols, sgmcmc_stream_t stream)                \
     {                                                                                                                \
         if (rows == 0 || cols == 0) return 0;                                                                        \

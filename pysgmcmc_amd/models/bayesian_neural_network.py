@@ -22,13 +22,14 @@ trainable tensor including biases and ``output_bias`` (``:386``).
     term folded into the GEMM epilogue (``beta * W``), so no gradient tensor is ever
     allocated, gathered or copied between the backward pass and the fused update.
 """
+import collections
 import copy
 import logging
 import math
+import os
+import weakref
 from collections import deque
 from time import time
-
-import os
 
 import numpy as np
 import torch
@@ -190,13 +191,12 @@ def weight_prior_log_like(parameters, wdecay=1.0, dtype=torch.float64):
 
 class _CostPlan(object):
     """The launch sequence one configuration of the MLP cost path runs (built by ``BNNCost._plan``, walked by every step)."""
-    __slots__ = ("forward", "head", "backward", "ones_row", "x_ones", "single_out", "gw_batch")
-
-    fresh = True                                                  # not evaluated yet (BNNCost.auto_gemm_tuning acts on the first evaluation)
+    __slots__ = ("forward", "head", "backward", "ones_row", "x_ones", "single_out", "gw_batch", "fresh")
 
     def __init__(self, forward, head, backward, ones_row, x_ones, single_out, gw_batch=None):
         self.forward, self.head, self.backward = tuple(forward), head, dict(backward)
         self.ones_row, self.x_ones, self.single_out, self.gw_batch = ones_row, x_ones, single_out, gw_batch
+        self.fresh = True                                         # not evaluated yet (BNNCost.auto_gemm_tuning acts on the first evaluation)
 
     def as_dict(self):
         d = {"forward": list(self.forward), "head": self.head, "backward": dict(self.backward),
@@ -214,6 +214,7 @@ class BNNCost(object):
     """
 
     __name__ = "negative_log_likelihood"
+    MAX_CACHED_PLANS = 16
     # the sampler may pass sum(theta^2) reduced by the previous update kernel (weight prior value)
     accepts_theta_sumsq = True
 
@@ -257,8 +258,11 @@ class BNNCost(object):
         # PYSGMCMC_AMD_AUTO_GEMM_TUNING=0 in the environment: the library's heuristics, nothing touched.
         self.auto_gemm_tuning = _auto_gemm_tuning_default()
         self.gemm_tuning_applied = None                           # None: no plan evaluated yet; "auto" | "caller" | "off"
-        self._x_ext = {}                                          # pitched feed buffers handed out by static_feed_buffer()
-        self._plans = {}
+        # pitched feed buffers handed out by static_feed_buffer(), held WEAKLY: a buffer lives as long as a sampler (or a cached
+        # plan) still uses the view it was given; the plan cache is bounded (a ragged last batch, alternating batch sizes or a
+        # second sampler each add a few entries, a long run must not accumulate them)
+        self._x_ext = weakref.WeakValueDictionary()
+        self._plans = collections.OrderedDict()
         # (Forking the weight-gradient GEMMs onto a second stream inside the captured graph was measured
         # on MI355X at batch 256: 291 us/step vs 275 us on one stream -- not kept.)
 
@@ -331,7 +335,7 @@ class BNNCost(object):
                   "tsq_parts": torch.zeros(16, dtype=torch.float64, device=dev),
                   "cost": torch.zeros(1, dtype=dt, device=dev), "mse": torch.zeros(1, dtype=dt, device=dev)}
             self._ws = {key: ws}
-            self._plans = {}
+            self._plans = collections.OrderedDict()
         return ws
 
     @torch.no_grad()
@@ -375,6 +379,7 @@ class BNNCost(object):
                params[0].data_ptr(), grad_views[0].data_ptr())
         plan = self._plans.get(key)
         if plan is not None:
+            self._plans.move_to_end(key)
             return plan
         B, n_layers = int(X.shape[0]), (len(params) - 1) // 2
         L = n_layers - 1
@@ -447,6 +452,8 @@ class BNNCost(object):
         plan = _CostPlan(forward, "head+last_layer_backward" if fused_head else "head", backward, bool(ones_row),
                          ext[:, :D_in + 1] if ones_row else None, single_out, gw_batch)
         self._plans[key] = plan
+        while len(self._plans) > self.MAX_CACHED_PLANS:
+            self._plans.popitem(last=False)                      # least recently used; its feed buffer goes with its last user
         return plan
 
     def plan_summary(self, params, grad_views, theta_sumsq_partials=None):
@@ -458,6 +465,8 @@ class BNNCost(object):
         X, Y = self.x_placeholder.value, self.y_placeholder.value
         ws = self._buffers(params, X.shape[0])
         plan = self._plan(params, grad_views, X, ws, theta_sumsq_partials is not None)
+        if plan.fresh and not X.is_cuda:
+            plan.fresh = False                                    # (host tensors: the kernels below refuse them, loudly)
         if plan.fresh:
             plan.fresh = False
             import torch.cuda.tunable as tunable
@@ -886,23 +895,38 @@ class BayesianNeuralNetwork(object):
         with torch.no_grad():
             return mlp_forward(ps, x).cpu().numpy()
 
+    PREDICT_ACTIVATION_BYTES = 1 << 30           # device memory one batched pass of predict() may spend on activations
+
     def _network_outputs(self, x):
-        """Outputs ``(n_nets, N, 2)`` of EVERY kept network at ``x`` in one pass: the kept weights are stacked per layer and the
-        layers run as batched products on the device, with ONE copy to the host at the end -- the reference (and
-        :meth:`compute_network_output`) evaluates the networks one by one (``:599-607``), 100 small launches and 100 copies."""
+        """Outputs ``(n_nets, N, 2)`` of EVERY kept network at ``x``: the kept weights are stacked per layer and the layers run as
+        batched products on the device, with ONE copy to the host at the end -- the reference (and :meth:`compute_network_output`)
+        evaluates the networks one by one (``:599-607``), 100 small launches and 100 copies. The rows of ``x`` go through in chunks
+        so that the (n_nets, rows, widest layer) activations of a pass stay below ``PREDICT_ACTIVATION_BYTES`` (a large test set
+        must not need n_nets times the memory the network-by-network loop did); kept samples given as numpy arrays are accepted
+        like ``compute_network_output`` accepts them."""
         nets = list(self.samples)
-        dev = nets[0][0].device
-        h = torch.as_tensor(x, dtype=self._torch_dtype, device=dev).unsqueeze(0).expand(len(nets), -1, -1)
+        first = nets[0][0]
+        dev = first.device if isinstance(first, torch.Tensor) else self._device()
+        as_t = lambda p: torch.as_tensor(p, dtype=self._torch_dtype, device=dev)
         n_layers = (len(nets[0]) - 1) // 2
+        Ws = [torch.stack([as_t(net[2 * l]) for net in nets]) for l in range(n_layers)]             # (nets, fan_in, fan_out)
+        bs = [torch.stack([as_t(net[2 * l + 1]).reshape(-1) for net in nets]).unsqueeze(1) for l in range(n_layers)]
+        log_var = torch.stack([as_t(net[-1]).reshape(()) for net in nets]).reshape(-1, 1, 1)
+        x = torch.as_tensor(x, dtype=self._torch_dtype, device=dev)
+        widest = max([int(x.shape[1])] + [int(W.shape[2]) for W in Ws])
+        per_row = 2 * len(nets) * widest * x.element_size()                  # input and output of the widest layer
+        rows = max(1, min(int(x.shape[0]), self.PREDICT_ACTIVATION_BYTES // max(per_row, 1)))
+        out = torch.empty(len(nets), int(x.shape[0]), 2, dtype=self._torch_dtype, device=dev)
         with torch.no_grad():
-            for l in range(n_layers):
-                W = torch.stack([net[2 * l] for net in nets])                # (nets, fan_in, fan_out)
-                b = torch.stack([net[2 * l + 1] for net in nets]).unsqueeze(1)
-                h = torch.baddbmm(b, h, W)
-                if l < n_layers - 1:
-                    h = torch.tanh_(h)
-            log_var = torch.stack([net[-1].reshape(()) for net in nets]).reshape(-1, 1, 1).expand(-1, h.shape[1], 1)
-            return torch.cat([h, log_var], dim=2).cpu().numpy()
+            for lo in range(0, int(x.shape[0]), rows):
+                h = x[lo:lo + rows].unsqueeze(0).expand(len(nets), -1, -1)
+                for l in range(n_layers):
+                    h = torch.baddbmm(bs[l], h, Ws[l])
+                    if l < n_layers - 1:
+                        h = torch.tanh_(h)
+                out[:, lo:lo + rows, 0:1] = h
+            out[:, :, 1:2] = log_var
+        return out.cpu().numpy()
 
     def predict(self, X_test, return_individual_predictions=False, *args, **kwargs):
         """Predictive mean and variance at ``X_test (N, D)`` (``:560-630``): the kept networks' means and noise

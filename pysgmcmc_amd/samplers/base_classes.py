@@ -86,7 +86,7 @@ class MCMCSampler(object):
     # "sghmc" / "sgld" / "rsghmc": the kernel can read its stepsize-derived scalars from a device block
     # (kernels.step_scalars); None: by value only
     _SCALARS_KIND = None
-    MAX_STEPSIZE_GRAPHS = 4               # use_hip_graph='full' on a by-value stepsize kernel: graphs kept before falling back
+    MAX_STEPSIZE_GRAPHS = 4               # use_hip_graph='full' on a by-value stepsize kernel: graphs kept (least recently used one evicted)
     # every parameter starts at a multiple of this many elements in the arena rows (1 = dense)
     _PARAM_ALIGN = 1
 
@@ -150,6 +150,7 @@ class MCMCSampler(object):
         self._scalars_dev = None
         self._scalars_value = None
         self._graphs = {}
+        self._full_graph_misses, self._full_graph_disabled = 0, False
         self._static_feeds = {}
         self._step_ctr = None
         self._ctr_value = -1
@@ -512,17 +513,30 @@ class MCMCSampler(object):
             self._ctr_value = self.n_iterations
         key = self._graph_key()
         if self._SCALARS_KIND is None:
-            # a sampler whose kernel takes its stepsize by value only (SVGD): one graph per stepsize -- for a handful of
-            # stepsizes. A schedule that keeps moving would capture (and keep) a graph per step: after MAX_STEPSIZE_GRAPHS
-            # distinct values the sampler drops to the cost graph + direct update for good.
+            # a sampler whose kernel takes its stepsize by value only (SVGD): one graph per stepsize, the MAX_STEPSIZE_GRAPHS most
+            # recently used ones are kept (a cyclic schedule of a few values keeps replaying them). A schedule that keeps MOVING
+            # would capture a graph per step: after 2 * MAX_STEPSIZE_GRAPHS captures in a row without one replay of a kept graph
+            # the sampler steps with the cost graph + direct update from then on. The caller's `use_hip_graph` stays what it
+            # was set to (state_dict / introspection agree with the configuration); `_full_graph_disabled` holds the decision.
             self._scalars_dev = None
             key = key + (float(eps),)
-            if key not in self._graphs and sum(1 for k in self._graphs if k[:1] == ("full",)) >= self.MAX_STEPSIZE_GRAPHS:
-                logging.warning("pysgmcmc_amd: use_hip_graph='full' met more than %d stepsizes on a sampler whose kernel takes the "
-                                "stepsize by value; stepping with the cost graph + direct update from here on", self.MAX_STEPSIZE_GRAPHS)
-                for k in [k for k in self._graphs if k[:1] == ("full",)]:
-                    del self._graphs[k]
-                self.use_hip_graph = True
+            if not self._full_graph_disabled and key not in self._graphs:
+                self._full_graph_misses += 1
+                if self._full_graph_misses > 2 * self.MAX_STEPSIZE_GRAPHS:
+                    logging.warning("pysgmcmc_amd: use_hip_graph='full' met %d new stepsizes in a row on a sampler whose kernel takes "
+                                    "the stepsize by value; stepping with the cost graph + direct update from here on",
+                                    self._full_graph_misses)
+                    self._full_graph_disabled = True
+                    for k in [k for k in self._graphs if k[:1] == ("full",)]:
+                        del self._graphs[k]
+                else:
+                    kept = [k for k in self._graphs if k[:1] == ("full",)]      # dict order = least recently used first
+                    for k in kept[:max(len(kept) - self.MAX_STEPSIZE_GRAPHS + 1, 0)]:
+                        del self._graphs[k]
+            elif not self._full_graph_disabled:
+                self._full_graph_misses = 0
+                self._graphs[key] = self._graphs.pop(key)            # most recently used last
+            if self._full_graph_disabled:
                 entry = self._graphs.get(("cost",))
                 if entry is None:
                     entry = self._graphs[("cost",)] = self._capture_cost()

@@ -35,7 +35,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in _declared_symbols():
         assert hasattr(handle, name), "libsgmcmc_hip.so does not export %s" % name
     lib = _lib.lib()
-    assert lib.sgmcmc_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.sgmcmc_abi_version() == _lib.ABI_VERSION == 6
     assert lib.sgmcmc_summary_workspace_bytes() >= 1024 * 32
     # the per-call launch geometry is validated on the host before anything is launched: checkable without a
     # GPU (the output pointer is a dummy that is never dereferenced because the call fails first)
@@ -46,6 +46,39 @@ def test_library_loads_and_exports_every_declared_symbol():
     rc = lib.sgmcmc_moments_update_f32(ctypes.c_void_p(4096), ctypes.c_void_p(4096), ctypes.c_void_p(4096), 8, 1,
                                        ctypes.byref(bad), None)
     assert rc == -1 and b"quads_per_thread" in lib.sgmcmc_last_error()
+
+
+def _contract_map():
+    text = open(HEADER).read()
+    block = text[text.index("---- Contract map"):text.index("---- end of the contract map")]
+    groups, cur = {}, None
+    for line in block.splitlines():
+        m = re.match(r"\s*\*\s*\[([a-z-]+)\]", line)
+        if m:
+            cur = groups.setdefault(m.group(1), [])
+        if cur is not None:
+            cur.extend(re.findall(r"\bsgmcmc_[a-z0-9_]+\b(?![*_])", line))
+    return groups
+
+
+def test_contract_map_partitions_the_declared_entry_points():
+    """the header says which entry points are the SURVEY 8(b) boundary and which are the cost path's
+    internals; the map names every declared entry point exactly once, and nothing that is not declared (or not exported)."""
+    from pysgmcmc_amd import _lib
+    groups = _contract_map()
+    assert sorted(groups) == ["boundary", "cost-path", "svgd", "whole-step"]
+    named = [n for g in groups.values() for n in g]
+    assert len(named) == len(set(named)), sorted(n for n in set(named) if named.count(n) > 1)
+    assert sorted(named) == _declared_symbols()
+    handle = ctypes.CDLL(_lib.build())
+    assert all(hasattr(handle, n) for n in named)
+    # the five step functions, moments, R-hat pack / finish, Philox, statistics: the boundary section 8(b) asked for
+    for name in ("sgmcmc_sghmc_step_f32", "sgmcmc_sgld_step_f64", "sgmcmc_rsghmc_step_f32", "sgmcmc_moments_update_f32",
+                 "sgmcmc_rhat_pack_f32", "sgmcmc_rhat_finish_f64", "sgmcmc_philox_normal_f32", "sgmcmc_step_stats_finish"):
+        assert name in groups["boundary"]
+    assert not [n for n in groups["boundary"] if "bnn" in n or "tanh" in n or "svgd" in n]
+    assert not hasattr(handle, "sgmcmc_tanh_rowdot_f32")        # superseded by sgmcmc_bias_tanh_rowdot_*, dropped in ABI v6
+    assert len(named) == 67
 
 
 def test_abi_exports_no_experiment_knobs():

@@ -271,8 +271,9 @@ def test_svgd_sampler_vmap_and_hip_graph_modes_agree():
 
 def test_full_graph_mode_gives_up_on_a_moving_stepsize():
     """SVGD's kernel takes its stepsize by value, so ``use_hip_graph = "full"`` keeps one graph per stepsize: a schedule that
-    keeps moving must not capture one per step -- after MAX_STEPSIZE_GRAPHS values the sampler steps with the cost graph +
-    direct update, and the chain is the eager chain."""
+    keeps moving must not capture one per step -- after 2 * MAX_STEPSIZE_GRAPHS new values in a row the sampler steps with the
+    cost graph + direct update, and the chain is the eager chain. The caller's ``use_hip_graph`` is left as configured (ADVICE r05);
+    a CYCLIC schedule of more values than graphs are kept goes on replaying full graphs (least recently used one evicted)."""
     from pysgmcmc_amd.samplers import SVGDSampler
     from pysgmcmc_amd.stepsize_schedules import StepsizeSchedule
 
@@ -297,7 +298,23 @@ def test_full_graph_mode_gives_up_on_a_moving_stepsize():
         return torch.stack(sample).cpu().numpy(), s
     ref, _ = chain(False)
     got, s = chain("full")
-    assert s.use_hip_graph is True and sum(1 for k in s._graphs if k[:1] == ("full",)) == 0
+    assert s.use_hip_graph == "full" and s._full_graph_disabled and sum(1 for k in s._graphs if k[:1] == ("full",)) == 0
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5)
+
+    class Cycle(Decay):
+        def __next__(self):
+            self.t += 1
+            return 0.1 / (1 + self.t % 2)                  # two values: both graphs stay
+
+    def cyc(graph):
+        s = SVGDSampler(particles=[torch.tensor(r, device=DEV) for r in x0], cost_fun=cost, stepsize_schedule=Cycle(), dtype=torch.float32)
+        s.sample_format, s.use_hip_graph = "device", graph
+        for _ in range(12):
+            sample, _ = next(s)
+        return torch.stack(sample).cpu().numpy(), s
+    ref, _ = cyc(False)
+    got, s = cyc("full")
+    assert s.use_hip_graph == "full" and not s._full_graph_disabled and sum(1 for k in s._graphs if k[:1] == ("full",)) == 2
     np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5)
 
 
