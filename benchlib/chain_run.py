@@ -265,6 +265,7 @@ class ChainBench(object):
                        "params": n, "batch": BATCH, "chains": world * K, "chains_per_gpu": K,
                        "rhat_every": self.rhat_every if world > 1 else None,
                        "moments_every": args.moments_every, "moments": "fused into the update launch (K4 in K1)",
+                       "product_arithmetic": self._product_arithmetic(),
                        "hip_graph": bool(sampler.use_hip_graph), "gemm_tuning": getattr(sampler.cost_fun, "gemm_tuning_applied", None) or (not args.no_gemm_tuning),
                        "prime_steps": {"burn_in": PRIME_BURN_IN, "frozen": PRIME_FROZEN + PRIME_STEADY},
                        "max_queue_depth": args.max_queue_depth, "time_every": self.time_every,
@@ -311,6 +312,18 @@ class ChainBench(object):
             line["ess"] = {"kept_per_chain": self.kept, "cost": None, "theta_coords": None,
                            "note": "fewer than %d kept samples per chain: not estimated" % self.ESS_MIN_KEPT}
         return line
+
+    def _product_arithmetic(self):
+        """What the matrix products of the step are computed in, from the cost plan in use."""
+        cost = self.sampler.cost_fun
+        plans = list(getattr(cost, "_plans", {}).values())
+        if not plans:
+            return None
+        d = plans[-1].as_dict()
+        fused = sum(1 for op in d["forward"] if op.startswith("dense_tanh"))
+        return {"forward / backward layers": "%d of %d forward layers as fp32-MFMA launches with their activation, the rest library %s products"
+                                             % (fused, len(d["forward"]) - 1, "f64" if self.f64 else "fp32"),
+                "batched weight gradients": d.get("batched_weight_gradient_arithmetic", "library product per layer")}
 
     def _rccl_fields(self, line):
         """N > 1: what the one exchange of the path cost, and `value` with that cost taken out. With the driver's 20-step

@@ -37,6 +37,9 @@ def build_chain(dev, rank, workload="bnn10m-sghmc", burn_in=8, dtype=torch.float
     # profiling aid (tools/gpu/r05_prof50m.sh): hidden layers on library products / on the fused launches whatever their tile count
     if os.environ.get("BENCH_FUSED_LAYERS") in ("library", "all"):
         cost.fused_layers = False if os.environ["BENCH_FUSED_LAYERS"] == "library" else "all"
+    # profiling aid (tools/gpu/r06_gw_planes.sh): the batched weight gradients on the library / on the bf16 planes whatever their size
+    if os.environ.get("BENCH_GW_PLANES") in ("off", "on"):
+        cost.gw_on_bf16_planes = os.environ["BENCH_GW_PLANES"] == "on"
     common = dict(params=params, cost_fun=cost,
                   batch_generator=generate_batches(X, y, xp, yp, batch_size=BATCH, seed=rank),
                   session=dev, dtype=dtype, seed=1234 + rank)

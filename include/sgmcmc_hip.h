@@ -71,6 +71,7 @@ typedef void *sgmcmc_stream_t;     /* hipStream_t */
  *   them; every one is launched by at least one reachable plan (tests/test_bnn_dense_gpu.py walks the plans).
  *     sgmcmc_window_gather_f32 sgmcmc_window_gather_f64
  *     sgmcmc_bnn_dense_tanh_dot_parts sgmcmc_bnn_dense_tanh_f32 sgmcmc_bnn_dense_tanh_backward_f32 sgmcmc_colsum_finish_f32
+ *     sgmcmc_bnn_planes_bytes sgmcmc_bnn_split_planes_f32 sgmcmc_bnn_gw_planes_f32
  *     sgmcmc_bias_tanh_f32 sgmcmc_bias_tanh_f64 sgmcmc_bias_tanh_rowdot_f32 sgmcmc_bias_tanh_rowdot_f64
  *     sgmcmc_bnn_head_f32 sgmcmc_bnn_head_f64 sgmcmc_bnn_head_last_layer_backward_f32 sgmcmc_bnn_head_last_layer_backward_f64
  *     sgmcmc_bnn_last_layer_backward_f32 sgmcmc_bnn_last_layer_backward_f64
@@ -507,6 +508,24 @@ int sgmcmc_window_gather_f32(const float *X, const float *y, size_t n_data, size
                              float *x_out, size_t x_out_ld, float *y_out, sgmcmc_stream_t stream);
 int sgmcmc_window_gather_f64(const double *X, const double *y, size_t n_data, size_t start, size_t batch, size_t dim,
                              double *x_out, size_t x_out_ld, double *y_out, sgmcmc_stream_t stream);
+
+/* Weight gradients of wide dense layers, gW = h^T delta (tf.gradients of pysgmcmc/models/bayesian_neural_network.py:30-56), at fp32
+ * accuracy on the bf16 matrix pipe (csrc/sgmcmc_bnn_gw.hip). Both operands are activations [M = batch][features]; each is first
+ * written as three exact bf16 planes x = x0 + x1 + x2 (8 + 8 + 8 significant bits, truncation splits, no rounding) in the layout
+ *   plane p of X [M][N]:  P[p][m / 8][n][m % 8]  (bf16),  planes of a set M * N * 2 bytes apart,
+ * then `count` products C_z [nA][nB] (pitch ldc, overwritten) = sum_m A_z[m][:]^T B_z[m][:] run as ONE launch of six
+ * v_mfma_f32_32x32x16_bf16 per 16 batch rows (the partial products of order <= 2^-16) with fp32 accumulation in a fixed order:
+ * bit-reproducible, error against fp64 no larger than the library's fp32 product on the same operands (tests/test_bnn_dense_gpu.py).
+ *   sgmcmc_bnn_planes_bytes(M, N): bytes of one plane set (0: invalid shape; M % 16 == 0 required).
+ *   split_planes: X_z = X + z * x_stride (elements) [M][ldx >= N] -> planes + z * planes_stride (bytes), z < count.
+ *   gw_planes: plane sets a_planes + z * a_stride, b_planes + z * b_stride (bytes); C + z * c_stride (elements).
+ * Faster than the library's fp32 product where the gradient has many 128 x 128 tiles (two 4864 x 4864 products at batch 256:
+ * 131 against 188 us); at 2048 x 2048 it is not once the planes have to be written (profiles/r06_gw_gate.txt).          */
+size_t sgmcmc_bnn_planes_bytes(int M, int N);
+int sgmcmc_bnn_split_planes_f32(const float *X, int count, size_t x_stride, int M, int N, int ldx, void *planes, size_t planes_stride,
+                                sgmcmc_stream_t stream);
+int sgmcmc_bnn_gw_planes_f32(const void *a_planes, size_t a_stride, const void *b_planes, size_t b_stride, float *C, size_t c_stride,
+                             int count, int M, int nA, int nB, int ldc, sgmcmc_stream_t stream);
 
 /* ---- Stein variational gradient descent: pysgmcmc/samplers/svgd.py:118-181 -----------------------
  * The n particles are the rows of a [n_particles x ld] device matrix (row pitch ld >= dim elements; with

@@ -164,6 +164,12 @@ def _declare(lib):
     lib.sgmcmc_bnn_dense_tanh_backward_f32.restype = _ci
     lib.sgmcmc_colsum_finish_f32.argtypes = [_vp, _ci, _ci, _vp, ctypes.c_float, _vp, _vp]
     lib.sgmcmc_colsum_finish_f32.restype = _ci
+    lib.sgmcmc_bnn_planes_bytes.argtypes = [_ci, _ci]
+    lib.sgmcmc_bnn_planes_bytes.restype = _sz
+    lib.sgmcmc_bnn_split_planes_f32.argtypes = [_vp, _ci, _sz, _ci, _ci, _ci, _vp, _sz, _vp]
+    lib.sgmcmc_bnn_split_planes_f32.restype = _ci
+    lib.sgmcmc_bnn_gw_planes_f32.argtypes = [_vp, _sz, _vp, _sz, _vp, _sz, _ci, _ci, _ci, _ci, _ci, _vp]
+    lib.sgmcmc_bnn_gw_planes_f32.restype = _ci
     lib.sgmcmc_philox_bits_u32.argtypes = [_vp, _sz, _u64, _u64, _vp, _vp]
     lib.sgmcmc_counter_add_u64.argtypes = [_vp, _u64, _vp]
     lib.sgmcmc_counter_add_u64.restype = _ci

@@ -610,6 +610,57 @@ def colsum_finish(parts, colsum, bias=None, beta=0.0):
     return colsum
 
 
+def bnn_planes_bytes(M, N):
+    """Bytes of one set of three bf16 planes of an ``[M, N]`` float32 matrix (``sgmcmc_bnn_planes_bytes``; 0: invalid shape)."""
+    return int(lib().sgmcmc_bnn_planes_bytes(int(M), int(N)))
+
+
+def _stack_stride(ts):
+    """Elements between consecutive tensors of ``ts`` (equal shapes, row-major with one row pitch, equally spaced), or raise."""
+    t0 = ts[0]
+    if any(t.shape != t0.shape or t.dtype != torch.float32 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1
+           or t.stride(0) != t0.stride(0) for t in ts):
+        raise ValueError("pysgmcmc_amd: a batch of equally shaped float32 [rows, cols] device matrices with one row pitch is expected")
+    gaps = {ts[k + 1].data_ptr() - ts[k].data_ptr() for k in range(len(ts) - 1)}
+    if len(gaps) > 1 or any(g <= 0 or g % 4 for g in gaps):
+        raise ValueError("pysgmcmc_amd: the matrices of a batch must lie at one constant, positive stride")
+    return gaps.pop() // 4 if gaps else 0
+
+
+def bnn_split_planes(mats, planes):
+    """Write every ``[M, N]`` float32 matrix of ``mats`` (equally spaced) as three exact bf16 planes into the uint8 buffer
+    ``planes`` (``len(mats) * bnn_planes_bytes(M, N)`` bytes; layout: include/sgmcmc_hip.h) -- the operands of
+    :func:`bnn_gw_planes`. One launch (``sgmcmc_bnn_split_planes_f32``)."""
+    stride = _stack_stride(mats)
+    M, N = int(mats[0].shape[0]), int(mats[0].shape[1])
+    one = bnn_planes_bytes(M, N)
+    if one == 0 or planes.dtype != torch.uint8 or not planes.is_cuda or planes.numel() < one * len(mats) or planes.data_ptr() % 16:
+        raise ValueError("pysgmcmc_amd: bnn_split_planes needs M %% 16 == 0 and a 16-byte aligned uint8 device buffer of "
+                         "len(mats) * bnn_planes_bytes(M, N) bytes")
+    with torch.cuda.device(planes.device):
+        rc = lib().sgmcmc_bnn_split_planes_f32(mats[0].data_ptr(), len(mats), stride, M, N, int(mats[0].stride(0)), planes.data_ptr(),
+                                               one, _stream(planes))
+    check(rc, "sgmcmc_bnn_split_planes_f32")
+    return planes
+
+
+def bnn_gw_planes(a_planes, b_planes, outs, M):
+    """``outs[z][nA, nB] = A_z^T B_z`` for the plane sets written by :func:`bnn_split_planes` (``a_planes``: ``len(outs)`` sets of
+    ``[M, nA]`` matrices, ``b_planes``: of ``[M, nB]``) -- the weight gradients ``h^T delta`` of equally shaped layers as ONE launch
+    on the bf16 matrix pipe at fp32 accuracy (``sgmcmc_bnn_gw_planes_f32``). ``outs``: equally spaced float32 device views."""
+    stride = _stack_stride(outs)
+    nA, nB = int(outs[0].shape[0]), int(outs[0].shape[1])
+    sa, sb = bnn_planes_bytes(M, nA), bnn_planes_bytes(M, nB)
+    if (sa == 0 or a_planes.dtype != torch.uint8 or b_planes.dtype != torch.uint8 or a_planes.numel() < sa * len(outs)
+            or b_planes.numel() < sb * len(outs) or a_planes.device != outs[0].device or b_planes.device != outs[0].device):
+        raise ValueError("pysgmcmc_amd: bnn_gw_planes needs M %% 16 == 0 and plane buffers of len(outs) sets each on the outputs' device")
+    with torch.cuda.device(outs[0].device):
+        rc = lib().sgmcmc_bnn_gw_planes_f32(a_planes.data_ptr(), sa, b_planes.data_ptr(), sb, outs[0].data_ptr(), stride, len(outs),
+                                            int(M), nA, nB, int(outs[0].stride(0)), _stream(outs[0]))
+    check(rc, "sgmcmc_bnn_gw_planes_f32")
+    return outs
+
+
 def tanh_rowdot(a, w, out, stats_workspace=None, tsq_parts=None, bias=None):
     """``a = tanh(a [+ bias])`` in place (``[rows, cols]``) and ``out[r] = a[r] . w`` in one launch. With ``stats_workspace``
     (a ``StepStats.workspace``) and ``tsq_parts`` (float64[16] device tensor) the launch also adds up the

@@ -191,11 +191,12 @@ def weight_prior_log_like(parameters, wdecay=1.0, dtype=torch.float64):
 
 class _CostPlan(object):
     """The launch sequence one configuration of the MLP cost path runs (built by ``BNNCost._plan``, walked by every step)."""
-    __slots__ = ("forward", "head", "backward", "ones_row", "x_ones", "single_out", "gw_batch", "fresh")
+    __slots__ = ("forward", "head", "backward", "ones_row", "x_ones", "single_out", "gw_batch", "gw_planes", "fresh")
 
-    def __init__(self, forward, head, backward, ones_row, x_ones, single_out, gw_batch=None):
+    def __init__(self, forward, head, backward, ones_row, x_ones, single_out, gw_batch=None, gw_planes=False):
         self.forward, self.head, self.backward = tuple(forward), head, dict(backward)
         self.ones_row, self.x_ones, self.single_out, self.gw_batch = ones_row, x_ones, single_out, gw_batch
+        self.gw_planes = bool(gw_planes)                          # the batched weight gradients on the bf16 matrix pipe (3 exact planes)
         self.fresh = True                                         # not evaluated yet (BNNCost.auto_gemm_tuning acts on the first evaluation)
 
     def as_dict(self):
@@ -203,6 +204,8 @@ class _CostPlan(object):
              "first_layer_bias_gradient": "from the [x | 1]^T delta product" if self.ones_row else "column sums"}
         if self.gw_batch is not None:
             d["weight_gradients_in_one_batched_product"] = list(range(self.gw_batch[0], self.gw_batch[1] + 1))
+            d["batched_weight_gradient_arithmetic"] = ("3 exact bf16 planes per operand, 6 bf16 MFMA products, fp32 accumulation"
+                                                       if self.gw_planes else "library fp32 product")
         return d
 
 
@@ -256,6 +259,13 @@ class BNNCost(object):
         # picks -- 5 % of the step at 10 M parameters, 22 % at 49.8 M (profiles/r06_product_defaults.txt). Same fp32 arithmetic,
         # possibly another summation order. Process-wide side effect: TunableOp stays ENABLED (look-ups only). False, or
         # PYSGMCMC_AMD_AUTO_GEMM_TUNING=0 in the environment: the library's heuristics, nothing touched.
+        # The batched weight gradients gW = h^T delta of equally shaped hidden layers on the bf16 matrix pipe at fp32 accuracy
+        # (csrc/sgmcmc_bnn_gw.hip: both operands written as 3 exact bf16 planes, 6 MFMA products): "auto" takes them there when the
+        # gradients have at least 4 tiles of 128 x 128 per compute unit -- configs[4]'s 4864 x 4864 layers (131 + 2 x 5 us against
+        # 188 for the library's fp32 products); the 2048 x 2048 layers of the 10 M-parameter net stay on the library (26 + 2 x 3 us
+        # against 33: nothing once the planes are written). True: whenever the shapes fit; False: never. Needs fold_prior (the
+        # kernel overwrites the gradient slices) and float32.
+        self.gw_on_bf16_planes = "auto"
         self.auto_gemm_tuning = _auto_gemm_tuning_default()
         self.gemm_tuning_applied = None                           # None: no plan evaluated yet; "auto" | "caller" | "off"
         # pitched feed buffers handed out by static_feed_buffer(), held WEAKLY: a buffer lives as long as a sampler (or a cached
@@ -376,7 +386,7 @@ class BNNCost(object):
         ones_row:    the first layer's [gW_0 ; gb_0] = [x | 1]^T delta as one product."""
         from pysgmcmc_amd import kernels
         key = (X.data_ptr(), X.stride(0), tuple(X.shape), bool(have_partials), self.fold_prior, self.fused_layers,
-               params[0].data_ptr(), grad_views[0].data_ptr())
+               params[0].data_ptr(), grad_views[0].data_ptr(), self.gw_on_bf16_planes)
         plan = self._plans.get(key)
         if plan is not None:
             self._plans.move_to_end(key)
@@ -449,8 +459,18 @@ class BNNCost(object):
             if None not in strides and hs[0].is_cuda:
                 gw_batch = (lo, hi) + tuple(strides)
                 break
+        gw_planes = False
+        if gw_batch is not None and self.gw_on_bf16_planes and self.fold_prior and X.dtype == torch.float32 and B % 16 == 0:
+            lo, hi = gw_batch[0], gw_batch[1]
+            fan_in, fan_out = (int(v) for v in params[2 * lo].shape)
+            tiles = (hi - lo + 1) * ((fan_in + 127) // 128) * ((fan_out + 127) // 128)
+            if self.gw_on_bf16_planes is True or tiles >= 4 * max(cus, 1):
+                gw_planes = True
+                n = hi - lo + 1
+                ws["planes_h"] = torch.empty(n * kernels.bnn_planes_bytes(B, fan_in), dtype=torch.uint8, device=X.device)
+                ws["planes_d"] = torch.empty(n * kernels.bnn_planes_bytes(B, fan_out), dtype=torch.uint8, device=X.device)
         plan = _CostPlan(forward, "head+last_layer_backward" if fused_head else "head", backward, bool(ones_row),
-                         ext[:, :D_in + 1] if ones_row else None, single_out, gw_batch)
+                         ext[:, :D_in + 1] if ones_row else None, single_out, gw_batch, gw_planes)
         self._plans[key] = plan
         while len(self._plans) > self.MAX_CACHED_PLANS:
             self._plans.popitem(last=False)                      # least recently used; its feed buffer goes with its last user
@@ -574,7 +594,12 @@ class BNNCost(object):
             # weight gradient
             if plan.gw_batch is not None and plan.gw_batch[0] <= l <= plan.gw_batch[1]:
                 lo, hi, s_h, s_d, s_g, s_w = plan.gw_batch
-                if l == lo:                                       # the last delta of the group exists now: ONE strided batched product
+                if l == lo and plan.gw_planes:                    # ... on the bf16 matrix pipe: both operands as 3 exact planes first
+                    run = range(lo, hi + 1)
+                    kernels.bnn_split_planes([hs[k - 1] for k in run], ws["planes_h"])
+                    kernels.bnn_split_planes([ds[k] for k in run], ws["planes_d"])
+                    kernels.bnn_gw_planes(ws["planes_h"], ws["planes_d"], [grad_views[2 * k] for k in run], B)
+                elif l == lo:                                     # the last delta of the group exists now: ONE strided batched product
                     n = hi - lo + 1
                     stack = lambda t, st: torch.as_strided(t, (n,) + tuple(t.shape), (st,) + tuple(t.stride()))
                     A, D, G = stack(hs[lo - 1], s_h).transpose(1, 2), stack(ds[lo], s_d), stack(grad_views[2 * lo], s_g)

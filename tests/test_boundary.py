@@ -78,7 +78,7 @@ def test_contract_map_partitions_the_declared_entry_points():
         assert name in groups["boundary"]
     assert not [n for n in groups["boundary"] if "bnn" in n or "tanh" in n or "svgd" in n]
     assert not hasattr(handle, "sgmcmc_tanh_rowdot_f32")        # superseded by sgmcmc_bias_tanh_rowdot_*, dropped in ABI v6
-    assert len(named) == 67
+    assert len(named) == 70
 
 
 def test_abi_exports_no_experiment_knobs():

@@ -78,16 +78,17 @@ __global__ void __launch_bounds__(256, 2) gw_bf16x3_kernel(const GwArgs g)
     // every XCD works on whole 8 x 8 blocks of tiles, 16 operand slices of 64 KiB x 3 planes per block in its L2)
     const int per = g.tiles_i * g.tiles_j;
     int id = blockIdx.x, z, ti, tj;
-    if (((g.tiles_i | g.tiles_j) & 7) == 0 && (gridDim.x & 511) == 0) {
-        id = (id & 7) * (gridDim.x >> 3) + (id >> 3);
+    {
+        // workgroup b runs on XCD b % 8: XCD x gets the CONTIGUOUS range of tile numbers [start_x, start_x + count_x) ...
+        const int T = (int)gridDim.x, q8 = T >> 3, r8 = T & 7, x = id & 7;
+        id = x * q8 + (x < r8 ? x : r8) + (id >> 3);
         z = id / per;
-        const int blk = (id % per) >> 6, l = id & 63, bj = g.tiles_j >> 3;
-        ti = (blk / bj) * 8 + (l >> 3);
-        tj = (blk % bj) * 8 + (l & 7);
-    } else {
-        z = id / per;
-        ti = (id % per) / g.tiles_j;
-        tj = (id % per) % g.tiles_j;
+        // ... and tile numbers walk the gradient in panels of 8 tile rows, rows fastest: 64 consecutive numbers = an 8 x 8 block of
+        // tiles = 16 operand slices of 64 KiB x 3 planes in the XCD's L2
+        const int r = id - z * per, panel = 8 * g.tiles_j, gidx = r / panel, rows = (g.tiles_i - 8 * gidx) < 8 ? (g.tiles_i - 8 * gidx) : 8;
+        const int w = r - gidx * panel;
+        ti = 8 * gidx + w % rows;
+        tj = w / rows;
     }
     const int i0 = ti * TILE, j0 = tj * TILE;
     const int nk = g.M / KC;
