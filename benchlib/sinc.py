@@ -9,6 +9,7 @@ update, burn-in switch, up to 100 steps per launch in ONE workgroup) -- and ``mo
 ``next(sampler)`` eagerly, with the cost pipeline replayed from a hipGraph, and with the whole step in one graph."""
 import json
 import sys
+import gc
 import time
 
 import numpy as np
@@ -105,6 +106,10 @@ def run_sinc(args, dev, rank, world, dist):
             dist.barrier()
         sync()
 
+    # host hygiene as in benchlib/chain_run.py: a full garbage collection of a process that has torch loaded stops the host for
+    # ~40 ms; collect now and freeze the survivors, and keep the collector off inside the timed region
+    gc.collect()
+    gc.freeze()
     s = build_sinc_chain(dev, rank)
     assert s.fused_bnn_available(), "the 3 x 50 net must fit the fused whole-step kernel"
     n = s.arena.n
@@ -121,6 +126,8 @@ def run_sinc(args, dev, rank, world, dist):
         launches.append(min(left, CHUNK))
         left -= launches[-1]
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in launches]
+    gc.collect()
+    gc.disable()                                               # (a pause of 40 ms is five times this region at --steps 400)
     fence()
     t0 = time.perf_counter()
     for k, (e0, e1) in zip(launches, pairs):
@@ -129,6 +136,7 @@ def run_sinc(args, dev, rank, world, dist):
         e1.record()
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -197,6 +205,7 @@ def run_sinc(args, dev, rank, world, dist):
                      "frac": round(alg_bytes / (us_per_step * 1e-6) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
                      "algorithmic_bytes_per_step": alg_bytes, "us_per_step": round(us_per_step, 2),
                      "us_per_launch_mean": round(float(launch_us.mean()), 1), "launches_timed": len(launches),
+                     "us_per_launch": [round(float(v), 1) for v in launch_us[:16]],
                      "note": "latency-bound, one workgroup: the chain's whole state (%d KB) lives in LDS / L2 for the length of a "
                              "launch, so the HBM roofline does not bind -- a step is ~25 barrier-separated phases of 8 waves "
                              "on one CU (DESIGN.md section 3, K8); the figure that matters is us_per_step. rocprofv3 launch "
