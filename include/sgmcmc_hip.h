@@ -142,7 +142,17 @@ int sgmcmc_event_synchronize(void *event);      /* host waits until the event ha
  *   scalars_dev: NULL, or a DEVICE block of 5 elements of the dtype filled by sgmcmc_{sghmc,sgld,rsghmc}_scalars_*;
  *                the kernel then takes its derived scalars (stepsize etc.) from there instead of the by-value
  *                arguments. A hipGraph replays identical arguments: a captured step follows a stepsize SCHEDULE
- *                through this block (one graph per phase instead of one per stepsize).                           */
+ *                through this block (one graph per phase instead of one per stepsize).
+ *   gather_*:    (ABI v6) the NEXT step's minibatch window as a side job of this launch -- what sgmcmc_window_gather_* does
+ *                (pysgmcmc/data_batches.py:118-123: rows [gather_start, gather_start + gather_batch) of X [n_data][gather_dim] into
+ *                gather_x_out [gather_batch][gather_x_out_ld], the same rows of y into gather_y_out), X / y of the step's dtype.
+ *                A tiny launch of its own costs ~5 us on the device's timeline (dispatch, ramp); inside the step launch --
+ *                the one launch of a graph-stepped chain that takes per-step arguments by value -- the copy is done by a
+ *                few extra workgroups in front of the update's and costs nothing measurable. All NULL / 0 = none. Needs
+ *                gather_dim * sizeof(T) and gather_x_out_ld * sizeof(T) multiples of 16 and a 16-byte aligned source window
+ *                and destination (SGMCMC_EINVAL otherwise: use sgmcmc_window_gather_*); the feed buffers must not be read by
+ *                anything still running on the stream behind this launch's predecessor. Launch variants without a fused
+ *                form (grid-capped, element-wise) run the copy as a small launch of its own behind the step.          */
 #define SGMCMC_STATS_THETA_SQ        1
 #define SGMCMC_STEP_HBM_RESIDENT     1u
 #define SGMCMC_STEP_SKIP_MINV_STORE  2u
@@ -156,6 +166,15 @@ typedef struct sgmcmc_step_opts {
     void *moments_m2;
     uint64_t moments_count;
     const void *scalars_dev;
+    const void *gather_x;
+    const void *gather_y;
+    void *gather_x_out;
+    void *gather_y_out;
+    uint64_t gather_start;
+    uint32_t gather_batch;
+    uint32_t gather_dim;
+    uint32_t gather_x_out_ld;
+    uint32_t reserved0;           /* 0 */
 } sgmcmc_step_opts_t;
 
 /* Number of statistics records (one per block = the grid) a vector-path step launch of n elements writes under

@@ -59,7 +59,10 @@ class StepOptsStruct(ctypes.Structure):
     _fields_ = [("first_element", ctypes.c_uint64), ("stats_record_base", ctypes.c_uint32),
                 ("stats_record_total", ctypes.c_uint32), ("stats_select", ctypes.c_int), ("flags", ctypes.c_uint),
                 ("moments_mean", ctypes.c_void_p), ("moments_m2", ctypes.c_void_p), ("moments_count", ctypes.c_uint64),
-                ("scalars_dev", ctypes.c_void_p)]
+                ("scalars_dev", ctypes.c_void_p),
+                ("gather_x", ctypes.c_void_p), ("gather_y", ctypes.c_void_p), ("gather_x_out", ctypes.c_void_p),
+                ("gather_y_out", ctypes.c_void_p), ("gather_start", ctypes.c_uint64), ("gather_batch", ctypes.c_uint32),
+                ("gather_dim", ctypes.c_uint32), ("gather_x_out_ld", ctypes.c_uint32), ("reserved0", ctypes.c_uint32)]
 
 
 _op = ctypes.POINTER(StepOptsStruct)

@@ -34,7 +34,8 @@ int rsghmc_step(T *theta, T *p, const T *grad, size_t n, T eps, T mass, T c, T D
     double *sp = static_cast<double *>(stats_ws);
     bool vec_ok = aligned16(theta) && aligned16(p) && aligned16(grad) && aligned16(xi) &&
                   aligned16(se.ex.mom_mean) && aligned16(se.ex.mom_m2);
-    bool mom_done = false;
+    bool mom_done = false, copy_done = false;
+    se.copy_done = &copy_done;
     int rc;
     // m^2 c^2 a power of two (the default m = c = 1): the divisions by it are exact multiplications (RsghmcOp POW2). Not with
     // device-resident scalars: the block may be refreshed with another mass / c after this launch was captured.
@@ -56,6 +57,7 @@ int rsghmc_step(T *theta, T *p, const T *grad, size_t n, T eps, T mass, T c, T D
         lc_mom.start_event = lc_mom.stop_event = nullptr;           // belong to the step kernel above
         rc = launch(mop, n, aligned16(theta) && aligned16(se.ex.mom_mean) && aligned16(se.ex.mom_m2), 5 * sizeof(T), lc ? &lc_mom : nullptr, st);
     }
+    if (rc == 0) rc = finish_side_copy<T>(se, copy_done, st);      // opts.gather_* on a path without a fused form
     return rc;
 }
 

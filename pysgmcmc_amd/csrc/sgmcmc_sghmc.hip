@@ -39,7 +39,8 @@ int sghmc_step(T *theta, T *V, const T *grad, T *tau, T *g, T *v_hat, T *minv, T
     bool vec_ok = aligned16(theta) && aligned16(V) && aligned16(grad) && aligned16(minv) && aligned16(xi) &&
                   (!adapt || (aligned16(tau) && aligned16(g) && aligned16(v_hat) && aligned16(r))) &&
                   aligned16(se.ex.mom_mean) && aligned16(se.ex.mom_m2);
-    bool mom_done = false;
+    bool mom_done = false, copy_done = false;
+    se.copy_done = &copy_done;
     int rc;
 #define SGHMC_GO(AD, INJ)                                                                                        \
     {                                                                                                            \
@@ -56,6 +57,7 @@ int sghmc_step(T *theta, T *V, const T *grad, T *tau, T *g, T *v_hat, T *minv, T
         lc_mom.start_event = lc_mom.stop_event = nullptr;           // belong to the step kernel above
         rc = launch(mop, n, aligned16(theta) && aligned16(se.ex.mom_mean) && aligned16(se.ex.mom_m2), 5 * sizeof(T), lc ? &lc_mom : nullptr, st);
     }
+    if (rc == 0) rc = finish_side_copy<T>(se, copy_done, st);      // opts.gather_* on a path without a fused form
     return rc;
 }
 

@@ -33,8 +33,39 @@ using sgmcmc_host::hip_fail;
 
 // Per-launch extras of a step kernel (by value): where this launch's per-block statistics go, and the Welford
 // moments a step may update in the same pass (K4 fused into the step, sgmcmc_step_opts_t).
+// Side job of a step launch (sgmcmc_step_opts_t.gather_*): the NEXT step's minibatch window -- `rows` consecutive rows of the
+// dataset, contiguous in memory -- copied into the feed buffers by the first `copy_blocks` workgroups of the launch, which do
+// nothing else. 16-byte units: row_quads per row, destination rows dst_pitch_quads apart; y as `y_words` 32-bit words.
+struct SideCopy {
+    const void *xsrc = nullptr;
+    void *xdst = nullptr;
+    const void *ysrc = nullptr;
+    void *ydst = nullptr;
+    unsigned rows = 0, row_quads = 0, dst_pitch_quads = 0, y_words = 0;
+};
+
+__device__ __forceinline__ void side_copy(const SideCopy &c, unsigned block, unsigned blocks)
+{
+    struct alignas(16) Q { unsigned v[4]; };
+    const size_t G = (size_t)blocks * blockDim.x, gid = (size_t)block * blockDim.x + threadIdx.x;
+    const size_t nq = (size_t)c.rows * c.row_quads;
+    const Q *__restrict__ src = static_cast<const Q *>(c.xsrc);
+    Q *__restrict__ dst = static_cast<Q *>(c.xdst);
+    for (size_t q = gid; q < nq; q += G) {
+        const size_t r = q / c.row_quads, col = q - r * c.row_quads;
+        dst[r * c.dst_pitch_quads + col] = src[q];
+    }
+    const unsigned *__restrict__ ys = static_cast<const unsigned *>(c.ysrc);
+    unsigned *__restrict__ yd = static_cast<unsigned *>(c.ydst);
+    for (size_t i = gid; i < c.y_words; i += G) yd[i] = ys[i];
+}
+
+__global__ void __launch_bounds__(256) __attribute__((unused)) side_copy_kernel(const SideCopy c) { side_copy(c, blockIdx.x, gridDim.x); }
+
 template <typename T>
 struct StreamExtras {
+    unsigned copy_blocks = 0;     // single-pass vector variant: workgroups [0, copy_blocks) run the side job `cp` and nothing else
+    SideCopy cp;
     unsigned part_base = 0;       // block b writes statistics record part_base + b
     unsigned part_total = 0;      // record count written to the workspace header (0 = this launch's grid)
     T *mom_mean = nullptr;        // Welford running mean / sum of squared deviations (MOM variants only)
@@ -54,7 +85,7 @@ struct StreamExtras {
 // MASK = the statistics reduced (the others are written as 0 without any reduction work).
 template <typename T, unsigned MASK, typename ACC>
 __device__ __forceinline__ void stats_block_write(ACC (&acc)[4], double *__restrict__ part, unsigned part_base,
-                                                  unsigned part_total)
+                                                  unsigned part_total, unsigned block, unsigned blocks)
 {
     __shared__ T lds[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -72,10 +103,10 @@ __device__ __forceinline__ void stats_block_write(ACC (&acc)[4], double *__restr
         if ((MASK >> threadIdx.x) & 1u)
             for (int w = 0; w < nw; ++w) v += (double)lds[w][threadIdx.x];
         // workspace = 32-byte header {number of records} + block-major records [nrecords][4]
-        part[4 + 4 * ((size_t)part_base + blockIdx.x) + threadIdx.x] = v;
+        part[4 + 4 * ((size_t)part_base + block) + threadIdx.x] = v;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        reinterpret_cast<unsigned long long *>(part)[0] = part_total ? part_total : gridDim.x;
+    if (block == 0 && threadIdx.x == 0)
+        reinterpret_cast<unsigned long long *>(part)[0] = part_total ? part_total : blocks;
 }
 
 // Welford update of (mean, m2) with the sample x, one IEEE rounding per op (the arithmetic of MomentsOp / K4, so the
@@ -101,10 +132,23 @@ __global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t n
                                                         const StreamExtras<typename Op::real> ex)
 {
     typedef typename Op::real T;
+    unsigned block = blockIdx.x, blocks = gridDim.x;
+    if constexpr (!LOOP) {
+        // side job (uniform per workgroup): the first copy_blocks workgroups copy the next minibatch window and leave; the update
+        // runs on the others exactly as without it (same quads per block, same statistics records)
+        if (ex.copy_blocks != 0) {
+            if (block < ex.copy_blocks) {
+                side_copy(ex.cp, block, ex.copy_blocks);
+                return;
+            }
+            block -= ex.copy_blocks;
+            blocks -= ex.copy_blocks;
+        }
+    }
     Op op = op_in;
     op.prepare();
-    const size_t G = (size_t)gridDim.x * blockDim.x;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t G = (size_t)blocks * blockDim.x;
+    const size_t gid = (size_t)block * blockDim.x + threadIdx.x;
     // running sums of this lane: the single-pass variant adds at most one quad (+ the ragged tail) -> the kernel's own
     // dtype, no f64 round trip in front of the wave reduction; the looping variants add many quads -> double
     typedef typename std::conditional<LOOP, double, T>::type acc_t;
@@ -170,7 +214,7 @@ __global__ void __launch_bounds__(256) stream_quads_vec(const Op op_in, size_t n
         if constexpr (stats) op.template accumulate<tsq_only>(R, tail_cnt, acc);
     }
     if constexpr (stats)
-        stats_block_write<T, tsq_only ? (Op::stats_mask & 1u) : Op::stats_mask>(acc, op.stats_part, ex.part_base, ex.part_total);
+        stats_block_write<T, tsq_only ? (Op::stats_mask & 1u) : Op::stats_mask>(acc, op.stats_part, ex.part_base, ex.part_total, block, blocks);
 }
 
 // element-wise path for misaligned arrays: same quads, same results
@@ -192,7 +236,8 @@ __global__ void __launch_bounds__(256) stream_quads_scalar(const Op op_in, size_
         op.store_part_(q, cnt, R);
         if constexpr (stats) op.template accumulate<false>(R, cnt, acc);
     }
-    if constexpr (stats) stats_block_write<typename Op::real, Op::stats_mask>(acc, op.stats_part, ex.part_base, ex.part_total);
+    if constexpr (stats)
+        stats_block_write<typename Op::real, Op::stats_mask>(acc, op.stats_part, ex.part_base, ex.part_total, blockIdx.x, gridDim.x);
 }
 
 // --------------------------------------------------------------------------
@@ -278,7 +323,18 @@ struct StepExtras {
     int stats_mode = 1;            // with a stats workspace: 1 = all statistics of the operator, 2 = sum theta'^2 only
     bool want_moments = false;
     bool big_hint = false;         // the launch is a slice of a working set larger than NT_AUTO_BYTES
+    bool want_copy = false;        // ex.cp holds a window to gather (opts.gather_*)
+    bool *copy_done = nullptr;     // set by launch_vec when the side job rode in the step launch
 };
+
+constexpr unsigned SIDE_COPY_MAX_BLOCKS = 256;      // workgroups of 256 lanes x 16 bytes a window copy is spread over
+
+inline unsigned side_copy_blocks(const SideCopy &c, int bt)
+{
+    const size_t units = (size_t)c.rows * c.row_quads + c.y_words;
+    const size_t want = (units + (size_t)bt - 1) / (size_t)bt;
+    return (unsigned)(want < SIDE_COPY_MAX_BLOCKS ? (want ? want : 1) : SIDE_COPY_MAX_BLOCKS);
+}
 
 // grid of a vector launch of n elements with bt-lane blocks and QPT quads per lane (before the max_blocks cap)
 inline size_t want_blocks(size_t n, int bt, int qpt)
@@ -301,12 +357,18 @@ int launch_vec(const Op &op, size_t n, const LaunchCfg &cfg, const StepExtras<ty
     size_t cap = (size_t)cfg.max_blocks;
     unsigned grid = (unsigned)(want < cap ? want : cap);
     const bool with_stats = op.stats_part != nullptr;
-    const StreamExtras<typename Op::real> &ex = se.ex;
+    StreamExtras<typename Op::real> ex = se.ex;
+    ex.copy_blocks = 0;
     if (moments_done) *moments_done = false;
     if constexpr (QPT == 1) {
         if (want <= cap) {                                 // one quad per lane, whole array in one pass
             const int smode = with_stats ? (FAST_VARIANTS ? se.stats_mode : 1) : 0;
             const bool mom = FAST_VARIANTS && se.want_moments;
+            if (se.want_copy && se.copy_done != nullptr) { // the window gather rides in this launch: extra workgroups in front
+                ex.copy_blocks = side_copy_blocks(ex.cp, bt);
+                grid += ex.copy_blocks;
+                *se.copy_done = true;
+            }
 #define SGMCMC_FAST(SM, MOMV) SGMCMC_LAUNCH((stream_quads_vec<Op, 1, NT, SM, false, MOMV>), grid, bt, st, cfg, op, nq_full, tail, ex)
             if constexpr (FAST_VARIANTS) {
                 if (mom) {
@@ -415,8 +477,41 @@ int resolve_step_opts(const sgmcmc_step_opts_t *o, size_t n, void *stats_ws, Ste
         se.ex.mom_inv = T(1) / (T)o->moments_count;
     }
     se.big_hint = (o->flags & SGMCMC_STEP_HBM_RESIDENT) != 0;
+    if (o->gather_x != nullptr || o->gather_x_out != nullptr || o->gather_batch != 0) {
+        // the next step's minibatch window (sgmcmc_window_gather_*'s job) as a side job of this launch
+        const size_t es = sizeof(T);
+        if (!o->gather_x || !o->gather_x_out || !o->gather_y || !o->gather_y_out || o->gather_batch == 0 || o->gather_dim == 0 ||
+            o->gather_x_out_ld < o->gather_dim)
+            return fail(SGMCMC_EINVAL, "%s: opts.gather_* needs X, y, both outputs, batch > 0, dim > 0 and x_out_ld >= dim", who);
+        const unsigned char *src = static_cast<const unsigned char *>(o->gather_x) + (size_t)o->gather_start * o->gather_dim * es;
+        if (((size_t)o->gather_dim * es) % 16 || ((size_t)o->gather_x_out_ld * es) % 16 ||
+            ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(o->gather_x_out)) & 15u) ||
+            (size_t)o->gather_batch * o->gather_dim * es / 16 >= 0xffffffffull)
+            return fail(SGMCMC_EINVAL, "%s: opts.gather_* needs rows of a multiple of 16 bytes, 16-byte aligned source window and "
+                                       "destination (use sgmcmc_window_gather_* otherwise)", who);
+        se.want_copy = true;
+        se.ex.cp.xsrc = src;
+        se.ex.cp.xdst = o->gather_x_out;
+        se.ex.cp.ysrc = static_cast<const unsigned char *>(o->gather_y) + (size_t)o->gather_start * es;
+        se.ex.cp.ydst = o->gather_y_out;
+        se.ex.cp.rows = o->gather_batch;
+        se.ex.cp.row_quads = (unsigned)((size_t)o->gather_dim * es / 16);
+        se.ex.cp.dst_pitch_quads = (unsigned)((size_t)o->gather_x_out_ld * es / 16);
+        se.ex.cp.y_words = (unsigned)((size_t)o->gather_batch * es / 4);
+    }
     (void)n;
     return 0;
+}
+
+// The window gather of a step call whose launch had no fused form for it (looping / element-wise variants): its own small launch
+// behind the step on the same stream -- same bytes either way.
+template <typename T>
+int finish_side_copy(const StepExtras<T> &se, bool rode_in_the_step, hipStream_t st)
+{
+    if (!se.want_copy || rode_in_the_step) return 0;
+    hipLaunchKernelGGL(side_copy_kernel, dim3(side_copy_blocks(se.ex.cp, 256)), dim3(256), 0, st, se.ex.cp);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "launch side_copy");
 }
 
 }  // namespace

@@ -192,12 +192,14 @@ class StepOpts(object):
     ``theta_sq_only``  reduce only sum theta'^2;  ``hbm_resident``  geometry hint for slices of a large arena;
     ``skip_minv_store``  burn-in step that does not write minv;
     ``moments`` = (mean, m2, count)  fold theta' into the Welford moments in the same pass (K4 fused);
-    ``scalars_dev``  device block from :func:`step_scalars` that overrides the by-value scalars."""
+    ``scalars_dev``  device block from :func:`step_scalars` that overrides the by-value scalars;
+    ``gather`` = (X, y, start, x_out, y_out)  the NEXT step's minibatch window as a side job of the launch (what
+    :func:`window_gather` does, without a launch of its own; see :func:`gather_fits_step_launch`)."""
 
     __slots__ = ("_c", "_keep")
 
     def __init__(self, first_element=0, stats_base=0, stats_total=0, theta_sq_only=False, hbm_resident=False,
-                 skip_minv_store=False, moments=None, scalars_dev=None, like=None):
+                 skip_minv_store=False, moments=None, scalars_dev=None, gather=None, like=None):
         from pysgmcmc_amd import _lib
         flags = (_lib.STEP_HBM_RESIDENT if hbm_resident else 0) | (_lib.STEP_SKIP_MINV_STORE if skip_minv_store else 0)
         mean = m2 = None
@@ -210,10 +212,35 @@ class StepOpts(object):
                         raise TypeError("pysgmcmc_amd: fused moments must match theta in dtype, length and device")
         if scalars_dev is not None and like is not None and (scalars_dev.dtype != like.dtype or scalars_dev.numel() < 5):
             raise TypeError("pysgmcmc_amd: scalars_dev must hold 5 elements of the step's dtype")
-        self._keep = (mean, m2, scalars_dev)
+        gx = gy = gxo = gyo = None
+        gstart = gbatch = gdim = gld = 0
+        if gather is not None:
+            gx, gy, gstart, gxo, gyo = gather
+            if not gather_fits_step_launch(gx, gy, gstart, gxo, gyo) or (like is not None and (gx.dtype != like.dtype or gx.device != like.device)):
+                raise ValueError("pysgmcmc_amd: this window cannot ride in a step launch (see kernels.gather_fits_step_launch)")
+            gbatch, gdim, gld = int(gxo.shape[0]), int(gx.shape[1]), int(gxo.stride(0))
+        self._keep = (mean, m2, scalars_dev, gx, gy, gxo, gyo)
         self._c = _lib.StepOptsStruct(int(first_element), int(stats_base), int(stats_total),
                                       _lib.STATS_THETA_SQ if theta_sq_only else 0, flags, _ptr(mean), _ptr(m2), int(count),
-                                      _ptr(scalars_dev))
+                                      _ptr(scalars_dev), *[None if t is None else t.data_ptr() for t in (gx, gy, gxo, gyo)],     # (x_out is a pitched view)
+                                      int(gstart), gbatch, gdim, gld, 0)
+
+
+def gather_fits_step_launch(X, y, start, x_out, y_out):
+    """True when the window ``X[start:start + B]``, ``y[start:start + B]`` -> ``x_out [B, D]`` (row pitch ``x_out.stride(0)``),
+    ``y_out [B]`` can be gathered as the side job of a step launch (``StepOpts(gather=...)``): one dtype and device, contiguous
+    dataset, rows of a multiple of 16 bytes, 16-byte aligned source window and destination."""
+    if not (isinstance(X, torch.Tensor) and X.is_cuda and X.dim() == 2 and X.is_contiguous() and y.is_contiguous() and y.dim() == 1):
+        return False
+    if not (X.dtype == y.dtype == x_out.dtype == y_out.dtype and X.device == y.device == x_out.device == y_out.device):
+        return False
+    if X.dtype not in (torch.float32, torch.float64) or x_out.dim() != 2 or x_out.stride(1) != 1 or not y_out.is_contiguous():
+        return False
+    B, D, es = int(x_out.shape[0]), int(X.shape[1]), X.element_size()
+    if x_out.shape[1] != D or y_out.numel() != B or B == 0 or start < 0 or start + B > X.shape[0] or y.numel() != X.shape[0]:
+        return False
+    return ((D * es) % 16 == 0 and (x_out.stride(0) * es) % 16 == 0 and (X.data_ptr() + start * D * es) % 16 == 0
+            and x_out.data_ptr() % 16 == 0 and y_out.data_ptr() % 4 == 0)
 
 
 def _opts(opts, like):

@@ -218,6 +218,7 @@ class BNNCost(object):
 
     __name__ = "negative_log_likelihood"
     MAX_CACHED_PLANS = 16
+    AUTO_GEMM_TUNING_WARM_EVALUATIONS = 20                   # untuned evaluations of a plan before its tuning evaluation (auto_gemm_tuning)
     # the sampler may pass sum(theta^2) reduced by the previous update kernel (weight prior value)
     accepts_theta_sumsq = True
 
@@ -495,6 +496,10 @@ class BNNCost(object):
                 self.gemm_tuning_applied = "caller"
             elif self.auto_gemm_tuning and n_total >= AUTO_GEMM_TUNING_MIN_PARAMS and not torch.cuda.is_current_stream_capturing():
                 self.gemm_tuning_applied = "auto"
+                # once with the library's own picks first: candidates timed on a device that has just woken up (clocks still
+                # ramping, cold caches) give noisy picks -- a chain could lose 15 % for good to one bad pick (round 6)
+                for _ in range(self.AUTO_GEMM_TUNING_WARM_EVALUATIONS):
+                    self._walk_plan(plan, params, grad_views, theta_sumsq, theta_sumsq_partials, X, Y, ws)
                 with _GemmTuningScope():
                     return self._walk_plan(plan, params, grad_views, theta_sumsq, theta_sumsq_partials, X, Y, ws)
             else:

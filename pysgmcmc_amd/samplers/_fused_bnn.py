@@ -53,7 +53,14 @@ class FusedBNNStepsMixin(object):
             raise ValueError("fused_bnn_steps needs a constant stepsize over the chunk")
         self.epsilon = eps[0]
         gen, cost, a = self.batch_generator, self.cost_fun, self.arena
-        starts = torch.as_tensor(gen.next_starts(n_steps), dtype=torch.int32).to(self.device)
+        pending, self._pending_window = getattr(self, "_pending_window", None), None
+        if pending is None:
+            first = []
+        else:                                     # a window next(sampler) drew one step ahead (base_classes._window_to_prefetch)
+            first = [int(pending[0])]
+        import numpy as np
+        starts_host = np.concatenate([np.asarray(first, dtype=np.int32), gen.next_starts(n_steps - len(first))]) if first else gen.next_starts(n_steps)
+        starts = torch.as_tensor(starts_host, dtype=torch.int32).to(self.device)
         costs = torch.empty(n_steps, dtype=self._torch_dtype, device=self.device)
         self._fused_bnn_launch(starts, costs, eps[0], n_steps)
         self.n_iterations += n_steps

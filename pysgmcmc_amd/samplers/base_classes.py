@@ -152,6 +152,12 @@ class MCMCSampler(object):
         self._graphs = {}
         self._full_graph_misses, self._full_graph_disabled = 0, False
         self._static_feeds = {}
+        # The NEXT step's minibatch window gathered by THIS step's update launch (`sgmcmc_step_opts_t.gather_*`): a graph-stepped
+        # chain then has no gather launch of its own (4.9 us of the 10 M-parameter step's 178). `prefetch_windows = False`
+        # switches it off. `_pending_window`: (start, in_the_buffers) of a window drawn from the generator but not consumed yet.
+        self.prefetch_windows = True
+        self._pending_window = None
+        self._fed_from_generator = False         # the current step's window came from the generator through the static buffers
         self._step_ctr = None
         self._ctr_value = -1
         self._capturing = False
@@ -407,8 +413,33 @@ class MCMCSampler(object):
         if moments is not None:
             moments.count += 1
         # (a captured launch replays its arguments and cannot carry the by-value Welford count: see _step_graph_full)
-        self._timed_kernel_step(eps, xi, opts=self._update_opts(0, self.arena.n, moments=moments),
-                                tag=(self.n_iterations, 0, self.arena.n))
+        opts = self._update_opts(0, self.arena.n, moments=moments)
+        gather = self._window_to_prefetch()
+        if gather is not None:
+            opts = dict(opts or {}, gather=gather)
+        self._timed_kernel_step(eps, xi, opts=opts, tag=(self.n_iterations, 0, self.arena.n))
+
+    def _window_to_prefetch(self):
+        """(X, y, start, x_out, y_out) of the NEXT step's minibatch window if this step's update launch should gather it: the
+        chain is fed by a window generator through static feed buffers (the hipGraph stepping modes, ``BNNCost``'s eager mode),
+        this step took its window from the generator, and the launch takes per-step arguments (not being captured). The draw
+        is the generator's next one, made one step early; ``state_dict`` keeps it."""
+        gen = self.batch_generator
+        if (not self.prefetch_windows or self._capturing or self.device.type != "cuda" or self._pending_window is not None
+                or not self._fed_from_generator or not hasattr(gen, "next_starts")):
+            return None
+        bx, by = self._static_feeds.get(gen.x_placeholder), self._static_feeds.get(gen.y_placeholder)
+        if bx is None or by is None or gen.x_placeholder.value is not bx:
+            return None
+        X, y = gen.x_dev, gen.y_dev.reshape(-1)
+        if X.dtype != self._torch_dtype or not kernels.gather_fits_step_launch(X, y, 0, bx, by.reshape(-1)):
+            return None
+        start = int(gen.next_starts(1)[0])
+        if not kernels.gather_fits_step_launch(X, y, start, bx, by.reshape(-1)):      # (a misaligned source window)
+            self._pending_window = (start, False)
+            return None
+        self._pending_window = (start, True)
+        return (X, y, start, bx, by.reshape(-1))
 
     def _step(self, feed_dict):
         assert (feed_dict is None or hasattr(feed_dict, "update"))
@@ -452,10 +483,24 @@ class MCMCSampler(object):
             # window generator with static feed buffers in place: the next window goes into them with ONE launch
             # (same RandomState draw as next(generator)); otherwise two slice copies below
             bx, by = self._static_feeds[gen.x_placeholder], self._static_feeds[gen.y_placeholder]
-            kernels.window_gather(gen.x_dev, gen.y_dev.reshape(-1), int(gen.next_starts(1)[0]), bx, by)
+            self._fed_from_generator = True
+            pending, self._pending_window = self._pending_window, None
+            if pending is None:
+                kernels.window_gather(gen.x_dev, gen.y_dev.reshape(-1), int(gen.next_starts(1)[0]), bx, by)
+            elif not pending[1]:                  # drawn already, but the buffers were used for something else since
+                kernels.window_gather(gen.x_dev, gen.y_dev.reshape(-1), pending[0], bx, by)
+            # (else: the previous step's update launch put this window into the buffers)
             gen.x_placeholder.value, gen.y_placeholder.value = bx, by
         else:
-            feed_dict.update(self._next_batch())
+            self._fed_from_generator = False
+            if self._pending_window is not None:
+                # the generator's next window was drawn one step ahead (_window_to_prefetch): it IS this step's batch
+                start, B = self._pending_window[0], gen.batch_size
+                self._pending_window = None
+                feed_dict.update({gen.x_placeholder: gen.x_dev[start:start + B],
+                                  gen.y_placeholder: gen.y_dev[start:start + B].reshape(-1, 1)})
+            else:
+                feed_dict.update(self._next_batch())
         for placeholder, value in feed_dict.items():
             if not hasattr(placeholder, "feed"):
                 continue
@@ -620,6 +665,8 @@ class MCMCSampler(object):
         for key, obj in (("batch_generator", self.batch_generator), ("stepsize_schedule", self.stepsize_schedule)):
             if hasattr(obj, "state_dict"):
                 state[key] = obj.state_dict()
+        if self._pending_window is not None:      # the generator stands one draw ahead: the window the next step will take
+            state["pending_window"] = int(self._pending_window[0])
         return state
 
     def load_state_dict(self, state):
@@ -631,6 +678,7 @@ class MCMCSampler(object):
         for key, obj in (("batch_generator", self.batch_generator), ("stepsize_schedule", self.stepsize_schedule)):
             if key in state and hasattr(obj, "load_state_dict"):
                 obj.load_state_dict(state[key])
+        self._pending_window = (int(state["pending_window"]), False) if state.get("pending_window") is not None else None
 
 
 class BurnInMCMCSampler(MCMCSampler):

@@ -656,3 +656,53 @@ def test_numpy_format_large_chain_uses_fresh_host_buffers(gpu):
     for a, b in zip(kept, snaps):
         assert isinstance(a, np.ndarray) and np.array_equal(a, b)
     assert not np.array_equal(kept[0], kept[-1])
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_window_prefetch_in_the_update_launch_gives_the_same_chain(gpu, graph):
+    """Round 6: the NEXT step's minibatch window is gathered by THIS step's update launch (``prefetch_windows``, the default)
+    instead of by a launch of its own at the start of the next step -- same windows (the generator's draws, one step early), same
+    chain bit for bit, in eager and in graph stepping; a step called with a feed_dict in between, whole-step kernel launches after
+    ``next()`` and a checkpoint taken while a window is pending all see the generator's sequence unchanged."""
+    from pysgmcmc_amd.data_batches import Placeholder, generate_batches
+    from pysgmcmc_amd.models.bayesian_neural_network import BNNCost, init_mlp_params
+    rng = np.random.RandomState(0)
+    X, y = rng.rand(300, 4), rng.rand(300)
+
+    def chain(prefetch):
+        xp, yp = Placeholder(dtype=torch.float32, device=gpu), Placeholder(dtype=torch.float32, device=gpu)
+        params = init_mlp_params(4, hidden=(32, 32), seed=5, dtype=torch.float32, device=gpu)
+        s = SGHMCSampler(params=params, cost_fun=BNNCost(xp, yp, batch_size=16, n_examples=300),
+                         batch_generator=generate_batches(X, y, xp, yp, batch_size=16, seed=2),
+                         stepsize_schedule=ConstantStepsizeSchedule(1e-2), burn_in_steps=5,
+                         scale_grad=300.0, session=gpu, dtype=torch.float32, seed=9)
+        s.sample_format, s.use_hip_graph, s.prefetch_windows = "view", graph, prefetch
+        return s, xp, yp
+    runs = {}
+    for prefetch in (False, True):
+        s, xp, yp = chain(prefetch)
+        costs = [float(next(s)[1]) for _ in range(8)]
+        assert (s._pending_window is not None) == prefetch            # a window is waiting in the feed buffers
+        if prefetch:
+            assert s._pending_window[1] is True
+        # a step given a feed_dict (which the generator's batch overrides, pysgmcmc/samplers/base_classes.py:287-291: the pending
+        # window must be taken, not a fresh draw): the generator's sequence goes on unchanged
+        xe = torch.full((16, 4), 0.25, device=gpu)
+        ye = torch.full((16, 1), 0.5, device=gpu)
+        costs.append(float(s.__next__({xp: xe, yp: ye})[1]))
+        costs += [float(next(s)[1]) for _ in range(4)]
+        ckpt = s.state_dict()
+        assert ("pending_window" in ckpt) == prefetch
+        costs += [float(next(s)[1]) for _ in range(3)]
+        if s.fused_bnn_available():
+            costs += [float(c) for c in s.fused_bnn_steps(4)]
+            costs += [float(next(s)[1]) for _ in range(2)]
+        theta = s.arena.row("theta").clone()
+        # resume from the checkpoint in a fresh sampler
+        r, _, _ = chain(prefetch)
+        r.load_state_dict(ckpt)
+        resumed = [float(next(r)[1]) for _ in range(3)]
+        runs[prefetch] = (costs, theta, resumed)
+        assert resumed == costs[13:16], (prefetch, resumed, costs[13:16])
+    assert runs[True][0] == runs[False][0]
+    assert torch.equal(runs[True][1], runs[False][1])

@@ -230,3 +230,44 @@ def test_burn_in_without_minv_stores_gives_the_same_chain(gpu):
                     assert torch.allclose(got, want, rtol=1e-6)                          # ... and .minv comes from v_hat
             for row in ("theta", "minv", "tau", "g", "v_hat"):
                 assert torch.equal(a.arena.row(row), b.arena.row(row)), (ctor.__name__, graph, row)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("kind,adapt", CASES)
+def test_window_gather_rides_in_the_step_launch(gpu, dt, kind, adapt):
+    """``opts.gather_*`` (round 6): the NEXT step's minibatch window -- ``sgmcmc_window_gather_*``'s job,
+    pysgmcmc/data_batches.py:118-123 -- copied by extra workgroups in front of the update's. The update of every element, the
+    statistics records and the noise stream are those of the plain launch bit for bit; the window lands in the pitched feed buffer
+    with the columns behind the data untouched; launch variants without a fused form (grid-capped, element-wise) still deliver it."""
+    from pysgmcmc_amd import kernels
+    n, B, D, N = 70_003, 32, 12, 500
+    g = torch.Generator(device=gpu).manual_seed(3)
+    X = torch.randn(N, D, dtype=dt, device=gpu, generator=g)
+    y = torch.randn(N, dtype=dt, device=gpu, generator=g)
+    for variant in ("single pass", "grid-capped", "element-wise"):
+        ref = _state(n + 1, dt, gpu)
+        got = {k: v.clone() for k, v in ref.items()}
+        sl = slice(1, n + 1) if variant == "element-wise" else slice(0, n)          # a misaligned slice takes the element-wise path
+        launch = kernels.LaunchConfig(max_blocks=40) if variant == "grid-capped" else None
+        st_ref, st_got = kernels.StepStats(n, gpu), kernels.StepStats(n, gpu)
+        xbuf = torch.full((B, D + 4), -7.0, dtype=dt, device=gpu)
+        ybuf = torch.full((B,), -7.0, dtype=dt, device=gpu)
+        start = 100 if dt == torch.float64 else 96                                   # 16-byte aligned source windows
+        _call(kind, ref, adapt, sl=sl, seed=11, step=7, stats=st_ref, launch=launch)
+        _call(kind, got, adapt, sl=sl, seed=11, step=7, stats=st_got, launch=launch,
+              opts=dict(gather=(X, y, start, xbuf[:, :D], ybuf)))
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), (variant, k)
+        assert torch.equal(kernels.step_stats_finish(st_ref), kernels.step_stats_finish(st_got)), variant
+        assert torch.equal(xbuf[:, :D], X[start:start + B]) and torch.all(xbuf[:, D:] == -7.0), variant
+        assert torch.equal(ybuf, y[start:start + B]), variant
+    # what cannot ride is refused, loudly: rows that are no multiple of 16 bytes, a misaligned window, another dtype
+    st = _state(4096, dt, gpu)
+    bad_rows = torch.randn(N, 3, dtype=dt, device=gpu)
+    with pytest.raises(ValueError):
+        _call(kind, st, adapt, opts=dict(gather=(bad_rows, y, 0, torch.empty(B, 3, dtype=dt, device=gpu), ybuf)))
+    assert kernels.gather_fits_step_launch(X, y, 1, xbuf[:, :D], ybuf)              # (rows of 48 / 96 bytes: every window is aligned)
+    assert not kernels.gather_fits_step_launch(X.view(-1)[1:1 + 40 * D].view(40, D), y[:40], 0, xbuf[:, :D], ybuf)   # a dataset that starts off a 16-byte boundary
+    assert not kernels.gather_fits_step_launch(X, y, N - 3, xbuf[:, :D], ybuf)      # runs off the end of the dataset
+    other = torch.float64 if dt == torch.float32 else torch.float32
+    assert not kernels.gather_fits_step_launch(X.to(other), y.to(other), 0, xbuf[:, :D], ybuf)
