@@ -218,7 +218,7 @@ class BNNCost(object):
 
     __name__ = "negative_log_likelihood"
     MAX_CACHED_PLANS = 16
-    AUTO_GEMM_TUNING_WARM_EVALUATIONS = 20                   # untuned evaluations of a plan before its tuning evaluation (auto_gemm_tuning)
+    AUTO_GEMM_TUNING_WARM_EVALUATIONS = 8                    # untuned evaluations of a plan before its tuning evaluation
     # the sampler may pass sum(theta^2) reduced by the previous update kernel (weight prior value)
     accepts_theta_sumsq = True
 
@@ -492,18 +492,27 @@ class BNNCost(object):
             plan.fresh = False
             import torch.cuda.tunable as tunable
             n_total = sum(int(p.numel()) for p in params)
-            if tunable.is_enabled() and tunable.tuning_is_enabled():
-                self.gemm_tuning_applied = "caller"
-            elif self.auto_gemm_tuning and n_total >= AUTO_GEMM_TUNING_MIN_PARAMS and not torch.cuda.is_current_stream_capturing():
-                self.gemm_tuning_applied = "auto"
-                # once with the library's own picks first: candidates timed on a device that has just woken up (clocks still
-                # ramping, cold caches) give noisy picks -- a chain could lose 15 % for good to one bad pick (round 6)
-                for _ in range(self.AUTO_GEMM_TUNING_WARM_EVALUATIONS):
-                    self._walk_plan(plan, params, grad_views, theta_sumsq, theta_sumsq_partials, X, Y, ws)
+            walk = lambda: self._walk_plan(plan, params, grad_views, theta_sumsq, theta_sumsq_partials, X, Y, ws)
+            by_caller = tunable.is_enabled() and tunable.tuning_is_enabled()
+            device_bound = n_total >= AUTO_GEMM_TUNING_MIN_PARAMS and not torch.cuda.is_current_stream_capturing()
+            if by_caller or (self.auto_gemm_tuning and device_bound):
+                self.gemm_tuning_applied = "caller" if by_caller else "auto"
+                if device_bound:
+                    # the library's own picks first: candidates should not be timed on a device that has just woken up (clocks
+                    # still ramping, cold caches)
+                    if by_caller:
+                        tunable.tuning_enable(False)
+                    try:
+                        for _ in range(self.AUTO_GEMM_TUNING_WARM_EVALUATIONS):
+                            walk()
+                    finally:
+                        if by_caller:
+                            tunable.tuning_enable(True)
+                if by_caller:
+                    return walk()                                 # tuned under the caller's own TunableOp settings
                 with _GemmTuningScope():
-                    return self._walk_plan(plan, params, grad_views, theta_sumsq, theta_sumsq_partials, X, Y, ws)
-            else:
-                self.gemm_tuning_applied = "off"
+                    return walk()
+            self.gemm_tuning_applied = "off"
         return self._walk_plan(plan, params, grad_views, theta_sumsq, theta_sumsq_partials, X, Y, ws)
 
     def _walk_plan(self, plan, params, grad_views, theta_sumsq, theta_sumsq_partials, X, Y, ws):
