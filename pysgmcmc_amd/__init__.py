@@ -44,12 +44,17 @@ def prefer_plain_graph_launch():
 def configure_for_device_bound_chains(gemm_tuning=True, plain_graph_launch=True, tuning_ms=30, tuning_iters=20):
     """ONE switch for chains whose step is DEVICE-bound -- hipGraph stepping (the default of the samplers' ``use_hip_graph`` and of
     ``BayesianNeuralNetwork.train``) on models of millions of parameters. It applies what ``bench.py`` runs its BNN workloads
-    with, so a chain built through the public API after this call steps at the rate the benchmark line reports as ``value``
-    (without it: ``value_product_defaults`` in the same line, ~4 % less at 10 M parameters):
+    with, so a chain built through the public API after this call steps at the rate the benchmark line reports as ``value``.
+    Without it a chain gets ``value_product_defaults`` of the same line: 0.98-1.0 of ``value`` at 10 M parameters, 0.98 at 49.8 M
+    (round 6, ``profiles/r06_bench_*.json``; two processes on one box differ by +-4 % on their own) -- since round 6 ``BNNCost``
+    picks the GEMM solutions of a device-bound plan by itself (``auto_gemm_tuning``), so all this call still adds is the graph
+    launch path:
 
-    * ``gemm_tuning``: PyTorch's TunableOp picks the library GEMM solution per shape during the chain's first (warm-up) step
-      (``models.bayesian_neural_network.enable_gemm_tuning``; process-wide PyTorch setting, same fp32 arithmetic);
-    * ``plain_graph_launch``: :func:`prefer_plain_graph_launch` -- only effective BEFORE the first HIP call of the process.
+    * ``gemm_tuning``: PyTorch's TunableOp stays in tuning mode for every GEMM shape the process meets (not only the plan's
+      evaluation that ``BNNCost`` tunes on its own; ``models.bayesian_neural_network.enable_gemm_tuning``; process-wide PyTorch
+      setting, same fp32 arithmetic);
+    * ``plain_graph_launch``: :func:`prefer_plain_graph_launch` -- only effective BEFORE the first HIP call of the process
+      (~2 % of the step at 10 M and at 49.8 M parameters).
 
     Host-bound chains (the 3 x 50 BNN of the reference's tests) lose with the second one: do not call this for them.
     Returns what took effect: ``{"gemm_tuning": bool, "plain_graph_launch": bool}``."""
