@@ -176,7 +176,13 @@ class MCMCSampler(object):
 
     # ------------------------------------------------------------------ feeds
     def _next_batch(self):
-        """Next ``{placeholder: value}`` dict, or ``{}`` without a generator."""
+        """Next ``{placeholder: value}`` dict, or ``{}`` without a generator. A window the previous step's update launch
+        drew ahead (``_window_to_prefetch``) IS the generator's next batch: it is handed out here before any fresh draw."""
+        if self._pending_window is not None:
+            gen, (start, _) = self.batch_generator, self._pending_window
+            self._pending_window = None
+            B = gen.batch_size
+            return {gen.x_placeholder: gen.x_dev[start:start + B], gen.y_placeholder: gen.y_dev[start:start + B].reshape(-1, 1)}
         if self.batch_generator is not None:
             return next(self.batch_generator)
         return dict()
@@ -493,14 +499,7 @@ class MCMCSampler(object):
             gen.x_placeholder.value, gen.y_placeholder.value = bx, by
         else:
             self._fed_from_generator = False
-            if self._pending_window is not None:
-                # the generator's next window was drawn one step ahead (_window_to_prefetch): it IS this step's batch
-                start, B = self._pending_window[0], gen.batch_size
-                self._pending_window = None
-                feed_dict.update({gen.x_placeholder: gen.x_dev[start:start + B],
-                                  gen.y_placeholder: gen.y_dev[start:start + B].reshape(-1, 1)})
-            else:
-                feed_dict.update(self._next_batch())
+            feed_dict.update(self._next_batch())      # (a window drawn one step ahead is handed out first)
         for placeholder, value in feed_dict.items():
             if not hasattr(placeholder, "feed"):
                 continue

@@ -697,6 +697,11 @@ def test_window_prefetch_in_the_update_launch_gives_the_same_chain(gpu, graph):
         if s.fused_bnn_available():
             costs += [float(c) for c in s.fused_bnn_steps(4)]
             costs += [float(next(s)[1]) for _ in range(2)]
+        # ... and on to a path that does not feed through the static buffers at all (torch restatement of the cost, eager): the
+        # window drawn ahead is still the next batch
+        s.use_hip_graph, s.cost_fun.use_hip_kernels = False, False
+        costs += [float(next(s)[1]) for _ in range(2)]
+        assert s._pending_window is None
         theta = s.arena.row("theta").clone()
         # resume from the checkpoint in a fresh sampler
         r, _, _ = chain(prefetch)
