@@ -1,10 +1,10 @@
-# round 6 gate record: SQ counters of the weight-gradient kernels (through gpurun: bash tools/gpu/gw_counters.sh), shape 0 = two batched 2048 x 2048 products
+# round 6 gate record: SQ counters of the weight-gradient kernels (through gpurun: bash tools/gpu/gw_counters.sh), SHAPE=0 (default) = two batched 2048 x 2048 products, SHAPE=3 = two 4864 x 4864
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/gw_counters; rm -rf $O; mkdir -p $O
-tools/gpu/bnn_gw_bf16x3 0 > $O/run.txt 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- tools/gpu/bnn_gw_bf16x3 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq -o q -- tools/gpu/bnn_gw_bf16x3 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM --output-format csv -d $O/sq2 -o q -- tools/gpu/bnn_gw_bf16x3 0 > /dev/null 2>&1
+tools/gpu/bnn_gw_bf16x3 ${SHAPE:-0} > $O/run.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- tools/gpu/bnn_gw_bf16x3 ${SHAPE:-0} > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq -o q -- tools/gpu/bnn_gw_bf16x3 ${SHAPE:-0} > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM --output-format csv -d $O/sq2 -o q -- tools/gpu/bnn_gw_bf16x3 ${SHAPE:-0} > /dev/null 2>&1
 find $O -name "*agent_info.csv" -delete
 python3 - <<'PY'
 import csv, glob, collections
