@@ -85,6 +85,13 @@ void launch_p(const GwArgs &g, int grid)
     hipLaunchKernelGGL((gw_bf16x3_persistent_kernel<TWO, PROBE>), dim3(grid), dim3(512), 0, 0, g);
 }
 
+template <int WM, bool TWO>
+void launch_w(const GwArgs &g, int batch)
+{
+    const int rows = 64 * WM, tiles_i = (g.nA + rows - 1) / rows;
+    hipLaunchKernelGGL((gw_bf16x3_wide_kernel<WM, TWO>), dim3(batch * tiles_i * g.tiles_j), dim3(128 * WM), 0, 0, g);
+}
+
 }  // namespace
 
 int main(int argc, char **argv)
@@ -183,6 +190,25 @@ int main(int argc, char **argv)
                    time_us([&] { launch_p<true, 1>(g, grid); }), time_us([&] { launch_p<true, 2>(g, grid); }), time_us([&] { launch_p<true, 4>(g, grid); }),
                    time_us([&] { launch_p<true, 6>(g, grid); }), time_us([&] { launch_p<true, 7>(g, grid); }),
                    time_us([&] { launch_p<true, 14>(g, grid); }), time_us([&] { launch_p<true, 12>(g, grid); }));
+        }
+        {
+            hipMemset(C, 0xff, ec * 4 * batch);
+            launch_w<4, true>(g, batch);
+            hipError_t e3 = hipDeviceSynchronize();
+            if (e3 != hipSuccess) { printf("    wide kernel failed: %s\n", hipGetErrorString(e3)); return 1; }
+            hipMemcpy(c1.data(), C + (batch - 1) * ec, ec * 4, hipMemcpyDeviceToHost);
+            size_t d3 = 0;
+            for (size_t i = 0; i < ec; ++i) d3 += (c1[i] != c[i]);
+            hipMemset(C, 0xff, ec * 4 * batch);
+            launch_w<6, true>(g, batch);
+            hipDeviceSynchronize();
+            hipMemcpy(c1.data(), C + (batch - 1) * ec, ec * 4, hipMemcpyDeviceToHost);
+            size_t d4 = 0;
+            for (size_t i = 0; i < ec; ++i) d4 += (c1[i] != c[i]);
+            printf("    WIDE tiles: 256 x 128 differs from 128 x 128 in %zu elements, 384 x 128 in %zu\n", d3, d4);
+            printf("    WIDE tiles, us per launch: 128x128 two acc %.2f | 256x128 two acc %.2f | 256x128 one acc %.2f | 384x128 two acc %.2f | 384x128 one acc %.2f\n",
+                   time_us([&] { launch_w<2, true>(g, batch); }), time_us([&] { launch_w<4, true>(g, batch); }), time_us([&] { launch_w<4, false>(g, batch); }),
+                   time_us([&] { launch_w<6, true>(g, batch); }), time_us([&] { launch_w<6, false>(g, batch); }));
         }
         // bit-reproducible?
         launch<3, true>(g, batch);

@@ -399,6 +399,115 @@ __global__ void __launch_bounds__(512, 1) gw_bf16x3_persistent_kernel(const GwAr
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Wider tiles (round 6, after the gate): WM x 64 rows by 128 columns per workgroup of 2 WM waves (64 x 64 each), ring of two stages.
+// Operand delivery per output falls with the tile: (64 WM + 128) / (64 WM x 128) -- 128 x 128: 1, 256 x 128: 0.75, 384 x 128: 0.67.
+// Pieces of a chunk (1 KiB each: plane, m8, 64 features) are dealt round-robin to the waves; with two stages every wait is vmcnt(0).
+template <int WM, bool TWO_ACC>
+__global__ void __launch_bounds__(128 * WM, 1) gw_bf16x3_wide_kernel(const GwArgs g)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = 2 * WM, ROWS = 64 * WM, A_PIECES = 6 * WM, PIECES = A_PIECES + 12, STAGE = PIECES * 1024;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2][STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int tiles_i = (g.nA + ROWS - 1) / ROWS, tiles_j = g.tiles_j, per = tiles_i * tiles_j;
+    int id = blockIdx.x, z, ti, tj;
+    {
+        const int T = (int)gridDim.x, q8 = T >> 3, r8 = T & 7, x = id & 7;
+        id = x * q8 + (x < r8 ? x : r8) + (id >> 3);
+        z = id / per;
+        const int r = id - z * per, panel = 8 * tiles_j, gidx = r / panel, rows = (tiles_i - 8 * gidx) < 8 ? (tiles_i - 8 * gidx) : 8;
+        const int w = r - gidx * panel;
+        ti = 8 * gidx + w % rows;
+        tj = w / rows;
+    }
+    const int i0 = ti * ROWS, j0 = tj * TILE;
+    const int nk = g.M / KC;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(g.A[z]), 0, (int)(2u * g.plane_a_bytes + (unsigned)(g.M / 8) * (unsigned)g.nA * 16u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(g.B[z]), 0, (int)(2u * g.plane_b_bytes + (unsigned)(g.M / 8) * (unsigned)g.nB * 16u), 0x00020000);
+    const unsigned big = 0x7ffffff0u;
+    const unsigned chunk_a = 2u * (unsigned)g.nA * 16u, chunk_b = 2u * (unsigned)g.nB * 16u;
+    // piece q: A pieces first -- q = (p * 2 + m8) * WM + seg --, then B -- q - A_PIECES = (p * 2 + m8) * 2 + seg
+    constexpr int PER_WAVE = (PIECES + NW - 1) / NW;
+    auto issue = [&](int c, int st) {
+#pragma unroll
+        for (int u = 0; u < PER_WAVE; ++u) {
+            const int q = wave + u * NW;
+            if (q < A_PIECES) {
+                const int pm = q / WM, seg = q - pm * WM, p = pm >> 1, m8 = pm & 1;
+                const unsigned so = (unsigned)p * g.plane_a_bytes + (unsigned)(m8 * g.nA + i0 + 64 * seg) * 16u + (unsigned)c * chunk_a;
+                const unsigned vo = (i0 + 64 * seg + lane < g.nA) ? (unsigned)lane * 16u : big;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, &lds[st][q * 1024], 16, vo, so, 0, 0);
+            } else if (q < PIECES) {
+                const int qb = q - A_PIECES, pm = qb >> 1, seg = qb & 1, p = pm >> 1, m8 = pm & 1;
+                const unsigned so = (unsigned)p * g.plane_b_bytes + (unsigned)(m8 * g.nB + j0 + 64 * seg) * 16u + (unsigned)c * chunk_b;
+                const unsigned vo = (j0 + 64 * seg + lane < g.nB) ? (unsigned)lane * 16u : big;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, &lds[st][q * 1024], 16, vo, so, 0, 0);
+            }
+        }
+    };
+    const int fm = lane & 31, kh = lane >> 5;
+    const int offA = (kh * ROWS + wi * 64 + fm) * 16, offB = A_PIECES * 1024 + (kh * 128 + wj * 64 + fm) * 16;
+    f32x16 accm[2][2], accs[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accm[a][b][r] = accs[a][b][r] = 0.f;
+    auto chunk_mfmas = [&](int st) {
+        const unsigned char *S = &lds[st][0];
+        u32x4 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                fa[x][p] = *reinterpret_cast<const u32x4 *>(S + offA + p * (2 * ROWS * 16) + x * 512);
+                fb[x][p] = *reinterpret_cast<const u32x4 *>(S + offB + p * 4096 + x * 512);
+            }
+#define GW_MF(I, J, PA, PB, ACC)                                                                                                    \
+    ACC[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[I][PA]), __builtin_bit_cast(bf16x8, fb[J][PB]), \
+                                                        ACC[I][J], 0, 0, 0)
+#define GW_ALL(PA, PB, ACC) GW_MF(0, 0, PA, PB, ACC); GW_MF(0, 1, PA, PB, ACC); GW_MF(1, 0, PA, PB, ACC); GW_MF(1, 1, PA, PB, ACC)
+        if constexpr (TWO_ACC) {
+            GW_ALL(0, 0, accm);
+            GW_ALL(0, 2, accs); GW_ALL(2, 0, accs); GW_ALL(1, 1, accs); GW_ALL(0, 1, accs); GW_ALL(1, 0, accs);
+        } else {
+            GW_ALL(0, 2, accm); GW_ALL(2, 0, accm); GW_ALL(1, 1, accm); GW_ALL(0, 1, accm); GW_ALL(1, 0, accm);
+            GW_ALL(0, 0, accm);
+        }
+#undef GW_ALL
+#undef GW_MF
+    };
+    issue(0, 0);
+    int st = 0;
+    for (int c = 0; c < nk; ++c) {
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (c + 1 < nk) issue(c + 1, st ^ 1);
+        chunk_mfmas(st);
+        st ^= 1;
+    }
+    float *__restrict__ C = g.C[z];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int col = j0 + wj * 64 + 32 * y + fm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wi * 64 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const float v = TWO_ACC ? accm[x][y][r] + accs[x][y][r] : accm[x][y][r];
+                if (row < g.nA && col < g.nB) C[(size_t)row * g.ldc + col] = v;
+            }
+        }
+#endif
+}
+
 // X [M][N] (pitch ldx) -> three bf16 planes in the layout above; the producers' epilogues do this themselves, this launch serves
 // the inputs that have no producer kernel of ours and the tests. One lane = 8 batch rows of one feature.
 __global__ void __launch_bounds__(256) split_planes_kernel(const float *__restrict__ X, int M, int N, int ldx, void *__restrict__ planes,
