@@ -95,6 +95,8 @@ def parse():
 
 def main():
     args = parse()
+    if args.dtype != "f32" and WORKLOADS[args.workload]["sampler"] not in ("sghmc", "sgld", "rsghmc"):
+        raise SystemExit("--dtype f64 is implemented for the BNN chain workloads (bnn10m-sghmc, bnn50m-sgld, bnn50m-rsghmc)")
     args.device_bound_switch = None
     if WORKLOADS[args.workload]["sampler"] in ("sghmc", "sgld", "rsghmc") and not args.eager and not args.product_defaults:
         # device-bound hipGraph steps (10 M / 49.8 M parameters): the package's one documented switch -- TunableOp GEMM selection in

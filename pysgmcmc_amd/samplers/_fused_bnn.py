@@ -1,5 +1,6 @@
 """Whole steps of a small BNN in one kernel (csrc/sgmcmc_bnn_fused.hip), shared by the two samplers the
 reference's BNN accepts (``pysgmcmc/sampling.py:40,64``: SGHMC and SGLD)."""
+import numpy as np
 import torch
 
 from pysgmcmc_amd import kernels
@@ -58,7 +59,6 @@ class FusedBNNStepsMixin(object):
             first = []
         else:                                     # a window next(sampler) drew one step ahead (base_classes._window_to_prefetch)
             first = [int(pending[0])]
-        import numpy as np
         starts_host = np.concatenate([np.asarray(first, dtype=np.int32), gen.next_starts(n_steps - len(first))]) if first else gen.next_starts(n_steps)
         starts = torch.as_tensor(starts_host, dtype=torch.int32).to(self.device)
         costs = torch.empty(n_steps, dtype=self._torch_dtype, device=self.device)
