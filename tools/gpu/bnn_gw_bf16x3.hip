@@ -210,6 +210,11 @@ int main(int argc, char **argv)
                    time_us([&] { launch_w<2, true>(g, batch); }), time_us([&] { launch_w<4, true>(g, batch); }), time_us([&] { launch_w<4, false>(g, batch); }),
                    time_us([&] { launch_w<6, true>(g, batch); }), time_us([&] { launch_w<6, false>(g, batch); }));
         }
+        printf("    nontemporal stores of the gradient: NS=2 two acc %.2f us (plain %.2f) | NS=3 two acc %.2f (plain %.2f)\n",
+               time_us([&] { hipLaunchKernelGGL((gw_bf16x3_kernel<2, true, 0, false, true>), dim3(batch * g.tiles_i * g.tiles_j), dim3(256), 0, 0, g); }),
+               time_us([&] { launch<2, true>(g, batch); }),
+               time_us([&] { hipLaunchKernelGGL((gw_bf16x3_kernel<3, true, 0, false, true>), dim3(batch * g.tiles_i * g.tiles_j), dim3(256), 0, 0, g); }),
+               time_us([&] { launch<3, true>(g, batch); }));
         // bit-reproducible?
         launch<3, true>(g, batch);
         hipDeviceSynchronize();
@@ -220,7 +225,7 @@ int main(int argc, char **argv)
         printf("    time per launch: library %.2f us | NS=3 two acc %.2f | NS=3 one acc %.2f | NS=2 two acc %.2f | NS=2 one acc %.2f\n",
                time_us(lib), time_us([&] { launch<3, true>(g, batch); }), time_us([&] { launch<3, false>(g, batch); }),
                time_us([&] { launch<2, true>(g, batch); }), time_us([&] { launch<2, false>(g, batch); }));
-        if (nA == 2048)
+        if (nA == 2048 || nA == 4864)
             printf("    probes (NS=3, two acc): no MFMA %.2f | no loads in the loop %.2f | no stores %.2f | no MFMA, no stores %.2f | no loads, no stores %.2f | nothing but the ring %.2f\n",
                    time_us([&] { launch<3, true, 1>(g, batch); }), time_us([&] { launch<3, true, 2>(g, batch); }), time_us([&] { launch<3, true, 4>(g, batch); }),
                    time_us([&] { launch<3, true, 5>(g, batch); }), time_us([&] { launch<3, true, 6>(g, batch); }), time_us([&] { launch<3, true, 7>(g, batch); }));

@@ -66,7 +66,7 @@ __device__ __forceinline__ Pair3 split_pair(float x, float y)
 }
 
 // NS ring stages; TWO_ACC: the five small partial products get accumulators of their own (added to a0 b0's at the end)
-template <int NS, bool TWO_ACC, int PROBE = 0, bool STORE16 = false>       // PROBE (timing experiments only): 1 no MFMA, 2 no loads in the loop, 4 no stores, 8 no fragment reads in the loop
+template <int NS, bool TWO_ACC, int PROBE = 0, bool STORE16 = false, bool NTS = false>       // NTS: nontemporal stores of the gradient; PROBE (timing experiments only): 1 no MFMA, 2 no loads in the loop, 4 no stores, 8 no fragment reads in the loop
 __global__ void __launch_bounds__(256, 2) gw_bf16x3_kernel(const GwArgs g)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -210,7 +210,10 @@ __global__ void __launch_bounds__(256, 2) gw_bf16x3_kernel(const GwArgs g)
                 for (int r = 0; r < 16; ++r) {
                     const int row = i0 + wi * 64 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * kh;
                     const float v = TWO_ACC ? accm[x][y][r] + accs[x][y][r] : accm[x][y][r];
-                    if ((PROBE & 4) ? (v == 123.456f) : (row < g.nA && col < g.nB)) C[(size_t)row * g.ldc + col] = v;
+                    if ((PROBE & 4) ? (v == 123.456f) : (row < g.nA && col < g.nB)) {
+                        if constexpr (NTS) __builtin_nontemporal_store(v, &C[(size_t)row * g.ldc + col]);
+                        else C[(size_t)row * g.ldc + col] = v;
+                    }
                 }
             }
     }
