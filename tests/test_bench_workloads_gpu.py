@@ -68,7 +68,7 @@ def test_default_workload_line_at_n1(gpu):
     # command differ by up to 5 % run to run on their own, hence the wider band here
     assert pd["gemm_tuning"] == "auto" and pd["hip_runtime_env"] == {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": None}
     assert d["config"]["gemm_tuning"] == "caller"
-    assert 0.92 * d["value"] < pd["value"] < 1.08 * d["value"], (pd["value"], d["value"])
+    assert 0.88 * d["value"] < pd["value"] < 1.12 * d["value"], (pd["value"], d["value"])       # (r05: 0.75 at 49.8 M, 0.94 here)
 
 
 @pytest.mark.timeout(900)
@@ -107,8 +107,8 @@ print("RATE", best)
     rate = float([l for l in res.stdout.splitlines() if l.startswith("RATE")][-1].split()[1])
     best = max(_bench(["--gpus", "1", "--steps", "300", "--warmup", "20", "--no-update-only", "--no-cpu-baseline",
                        "--no-product-defaults"])["value"] for _ in range(2))
-    # (two processes on one box differ by +-4 % with IDENTICAL GEMM picks -- tools/gpu/tune_noise_probe.py, round 6 -- hence 0.92)
-    assert rate >= 0.92 * best, (rate, best)
+    # (two processes on one box differ by +-4 % with IDENTICAL GEMM picks -- tools/gpu/tune_noise_probe.py, round 6 -- hence 0.90)
+    assert rate >= 0.90 * best, (rate, best)
 
 
 @pytest.mark.timeout(900)
@@ -149,4 +149,4 @@ print("RATE", best)
     rate = float([l for l in res.stdout.splitlines() if l.startswith("RATE")][-1].split()[1])
     best = max(_bench(["--gpus", "1", "--steps", "300", "--warmup", "20", "--no-update-only", "--no-cpu-baseline",
                        "--no-product-defaults"])["value"] for _ in range(2))
-    assert rate >= 0.92 * best, (rate, best)       # (process-to-process spread on one box: +-4 %)
+    assert rate >= 0.90 * best, (rate, best)       # (process-to-process spread on one box: +-4 % each)
